@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ by running the REFERENCE's own Python.
+
+Run only in the build container (``/root/reference`` does not exist on the GPU box):
+
+    python tools/gen_golden.py
+
+What is executed from the reference (imported from /root/reference/point_cloud_lib, never
+copied): ``PNEConvLayerRotEquivFactory`` / ``PNEConvLayerRotEquiv`` (forward through
+``IConvLayer.forward`` incl. the EMA pre-process branch, ``get_rot_tenors``, the kernel MLP,
+``FeatBasisProj`` autograd function, einsum, scalings, parameter init), ``PointcloudRotEquiv``
+(random frames), ``BQNeighborhood``, and ``RotationFunctions.*``.
+
+What is NOT the reference: three native modules are not installed here and cannot be built
+(no nvcc): ``point_cloud_lib_ops`` (CUDA), ``torch_scatter``, ``torch_cluster``.  The
+stand-ins below are deliberately naive loop/index_add implementations of their documented
+semantics, written independently of ``oracle/se3conv_oracle.py`` so the fixtures cross-check
+the oracle instead of echoing it.  Everything stored is data (inputs + outputs), no source.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/point_cloud_lib"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# ----------------------------------------------------------------------------- stand-ins
+def _install_shims():
+    ops = types.ModuleType("point_cloud_lib_ops")
+
+    def feat_basis_proj(basis, feats, neighbors, ends):
+        m, c, k = ends.shape[0], feats.shape[1], basis.shape[1]
+        out = torch.zeros((m, c, k), dtype=feats.dtype)
+        start = 0
+        for row in range(m):
+            end = int(ends[row])
+            if end > start:
+                f = feats[neighbors[start:end, 1].long()]  # [n,C]
+                out[row] = f.t() @ basis[start:end]
+            start = end
+        return out
+
+    def feat_basis_proj_grad(basis, feats, neighbors, ends, grads):
+        g_feat = torch.zeros_like(feats)
+        g_basis = torch.zeros_like(basis)
+        start = 0
+        for row in range(ends.shape[0]):
+            end = int(ends[row])
+            if end > start:
+                src = neighbors[start:end, 1].long()
+                g = grads[row]  # [C,K]
+                g_basis[start:end] = feats[src] @ g
+                g_feat.index_add_(0, src, basis[start:end] @ g.t())
+            start = end
+        return [g_feat, g_basis]
+
+    def ball_query(src, dst, bsrc, bdst, min_pt, num_cells, radius, max_neighbors):
+        assert max_neighbors == 0
+        inv = torch.reciprocal(radius)
+        nbrs, ends, total = [], [], 0
+        for s in range(dst.shape[0]):
+            d = (dst[s][None, :] - src) * inv[None, :]
+            dist = torch.sqrt((d * d).sum(1))
+            hit = torch.nonzero((dist < 1.0) & (bsrc == bdst[s]))[:, 0]
+            nbrs.append(torch.stack((torch.full_like(hit, s), hit), 1))
+            total += hit.shape[0]
+            ends.append(total)
+        return torch.cat(nbrs).long(), torch.tensor(ends, dtype=torch.int32)
+
+    def _unavailable(*a, **k):
+        raise RuntimeError("native op not available in the fixture generator")
+
+    ops.feat_basis_proj = feat_basis_proj
+    ops.feat_basis_proj_grad = feat_basis_proj_grad
+    ops.ball_query = ball_query
+    ops.knn_query = _unavailable
+    ops.compute_keys = _unavailable
+    sys.modules["point_cloud_lib_ops"] = ops
+
+    ts = types.ModuleType("torch_scatter")
+
+    def _size(index, dim_size):
+        return int(index.max()) + 1 if dim_size is None else dim_size
+
+    def scatter_add(src, index, dim=0, out=None, dim_size=None):
+        assert dim == 0
+        n = _size(index, dim_size)
+        res = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+        return res.index_add_(0, index.long(), src)
+
+    def _reduce(src, index, how, dim_size):
+        n = _size(index, dim_size)
+        idx = index.long()
+        if src.dim() > 1:
+            idx = idx[:, None].expand_as(src)
+        init = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+        return init.scatter_reduce(0, idx, src, how, include_self=False)
+
+    ts.scatter_add = scatter_add
+    ts.scatter_mean = lambda src, index, dim=0, out=None, dim_size=None: _reduce(src, index, "mean", dim_size)
+    ts.scatter_max = lambda src, index, dim=0, out=None, dim_size=None: (_reduce(src, index, "amax", dim_size), None)
+    ts.scatter_min = lambda src, index, dim=0, out=None, dim_size=None: (_reduce(src, index, "amin", dim_size), None)
+    sys.modules["torch_scatter"] = ts
+
+    tc = types.ModuleType("torch_cluster")
+    for name in ("knn", "knn_graph", "fps", "radius"):
+        setattr(tc, name, _unavailable)
+    sys.modules["torch_cluster"] = tc
+    sys.modules["h5py"] = types.ModuleType("h5py")
+    # the reference's data_sets package imports a file that is not in the repository
+    sys.modules["point_cloud_lib.data_sets"] = types.ModuleType("point_cloud_lib.data_sets")
+    for name in ("wandb", "trimesh", "webdataset"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, REF)
+
+
+def _import_reference():
+    _install_shims()
+    import point_cloud_lib as pclib  # noqa: E402
+
+    return pclib
+
+
+# ----------------------------------------------------------------------------- cases
+def _radius(n, k):
+    return float((3.0 * k / (4.0 * np.pi * n)) ** (1.0 / 3.0))
+
+
+def layer_case(pclib, seed, n_in, n_out, f, c_in, c_out, k_deg, num_basis=32, batches=1):
+    """One conv between an input cloud and an output cloud (same cloud when n_out is None)."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    cfg = {"pca": False, "n_frames": f, "fixed_axis": False}
+    pts_in = torch.rand(n_in, 3)
+    bid_in = torch.sort(torch.randint(0, batches, (n_in,), dtype=torch.int32)).values
+    pc_in = pclib.pc.PointcloudRotEquiv(pts_in, bid_in, cfg)
+    if n_out is None:
+        pc_out = pc_in
+    else:
+        pts_out = torch.rand(n_out, 3)
+        bid_out = torch.sort(torch.randint(0, batches, (n_out,), dtype=torch.int32)).values
+        pc_out = pclib.pc.PointcloudRotEquiv(pts_out, bid_out, cfg)
+    r = _radius(n_in / batches, k_deg)
+    neigh = pclib.pc.BQNeighborhood(pc_in, pc_out, r)
+
+    factory = pclib.layers.PNEConvLayerRotEquivFactory(9, num_basis, "mlp_gelu")
+    conv = factory.create_conv_layer(c_in, c_out)
+    with torch.no_grad():
+        conv.proj_biases_.uniform_(-0.5, 0.5)  # the init is 0; make the bias path visible
+
+    x = torch.randn(n_in * f, c_in)
+    ema = []
+    conv.start_pre_process()
+    with torch.no_grad():
+        for _ in range(3):
+            pclib.layers.PNEConvLayerRotEquiv.empty_rot_tenors_cache()
+            conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=neigh)
+            ema.append((float(conv.norm_neigh_dist_), float(conv.norm_num_neighs_)))
+    conv.end_pre_process()
+    # use converged normalisers for the numeric case (the EMA trajectory is stored separately)
+    conv.norm_neigh_dist_ = torch.tensor(1.0 / r, dtype=torch.float32)
+    conv.norm_num_neighs_ = torch.tensor(neigh.start_ids_.shape[0] / neigh.neighbors_.shape[0], dtype=torch.float32)
+
+    pclib.layers.PNEConvLayerRotEquiv.empty_rot_tenors_cache()
+    x.requires_grad_(True)
+    out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=neigh)
+    g = torch.randn_like(out)
+    out.backward(g)
+    rt = pclib.layers.PNEConvLayerRotEquiv.get_rot_tenors(pc_in, pc_out, neigh, conv.norm_neigh_dist_)
+
+    return {
+        "pts_in": pc_in.pts_.numpy(), "pts_out": pc_out.pts_.numpy(),
+        "batch_in": pc_in.batch_ids_.numpy(), "batch_out": pc_out.batch_ids_.numpy(),
+        "frames_in": pc_in.local_frames_.numpy(), "frames_out": pc_out.local_frames_.numpy(),
+        "radius": np.float64(r),
+        "neighbors": neigh.neighbors_.numpy().astype(np.int32), "ends": neigh.start_ids_.numpy().astype(np.int32),
+        "proj_axes": conv.proj_axes_.detach().numpy(), "proj_biases": conv.proj_biases_.detach().numpy(),
+        "conv_weights": conv.conv_weights_.detach().numpy(),
+        "rho": conv.norm_neigh_dist_.numpy(), "nu": conv.norm_num_neighs_.numpy(),
+        "x": x.detach().numpy(), "out": out.detach().numpy(), "grad_out": g.numpy(),
+        "dx": x.grad.numpy(), "dA": conv.proj_axes_.grad.numpy(), "dbeta": conv.proj_biases_.grad.numpy(),
+        "dW": conv.conv_weights_.grad.numpy(),
+        "rt_desc": rt["rel_pts_rel_orient"].numpy(), "rt_neighbs": rt["neighbs"].numpy().astype(np.int32),
+        "rt_ends": rt["neighbs_start_ids"].numpy().astype(np.int32),
+        "ema": np.asarray(ema, dtype=np.float64),
+    }
+
+
+def rotation_case(pclib, seed):
+    """get_relative_rot / change_direction_to_local_frame / all_index_combinations on tiny inputs."""
+    torch.manual_seed(seed)
+    fa = pclib.pc.sample_reference_frames(5, 2)
+    fb = pclib.pc.sample_reference_frames(5, 4)
+    d = torch.randn(5, 3)
+    return {
+        "frames_a": fa.numpy(), "frames_b": fb.numpy(), "dirs": d.numpy(),
+        "rel6": pclib.pc.get_relative_rot(fa, fb, "6D").numpy(),
+        "relmat": pclib.pc.get_relative_rot(fa, fb, "matrix").numpy(),
+        "local": pclib.pc.change_direction_to_local_frame(d, fa).numpy(),
+        "combos": pclib.pc.all_index_combinations(2, 4).numpy(),
+    }
+
+
+CASES = [
+    # name,             seed, n_in, n_out, F, c_in, c_out, k, batches
+    ("cfg1_n1024_f1_c32", 0, 1024, None, 1, 32, 32, 16, 1),   # BASELINE.json configs[0]
+    ("n256_f2_c64",       1, 256, None, 2, 64, 64, 16, 1),
+    ("n256_f4_c32",       2, 256, None, 4, 32, 32, 12, 1),
+    ("n256_f2_c1_c32",    3, 256, None, 2, 1, 32, 16, 1),     # DFaust input layer (C_in = 1)
+    ("n256_f1_c3_c64",    4, 256, None, 1, 3, 64, 16, 1),     # ScanNet input layer (C_in = 3)
+    ("down_n512_n128_f2", 5, 512, 128, 2, 32, 64, 24, 2),     # two clouds, two batches, ragged
+    ("sparse_n200_f2",    6, 200, None, 2, 32, 32, 1.5, 1),   # many 1-neighbour (self only) rows
+]
+
+
+def main():
+    pclib = _import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for name, seed, n_in, n_out, f, c_in, c_out, k, b in CASES:
+        data = layer_case(pclib, seed, n_in, n_out, f, c_in, c_out, k, batches=b)
+        path = os.path.join(OUT, f"layer_{name}.npz")
+        np.savez_compressed(path, **data)
+        print(f"{path}: E={data['neighbors'].shape[0]} rows_out={data['out'].shape[0]} "
+              f"size={os.path.getsize(path) / 1e6:.2f} MB")
+    np.savez_compressed(os.path.join(OUT, "rotation_fns.npz"), **rotation_case(pclib, 7))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
