@@ -1,0 +1,176 @@
+/*
+ * se3conv.h -- C ABI of libse3conv_hip.so, the MI355X (gfx950) implementation of the
+ * PNEConvLayerRotEquiv hot path of lisaweijler/SE3Conv3D.
+ *
+ * Each entry point replaces one function of the reference's native boundary
+ * (pybind module `point_cloud_lib_ops`, point_cloud_lib/custom_ops/ops_list.cpp:19-25) or one
+ * Python-level stage of PNEConvLayerRotEquiv that the reference runs as a chain of torch ops.
+ * The citation next to each declaration names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - all floating point is fp32, all indices int32 (keys int64), tensors dense row-major;
+ *   - caller allocates every output and the workspace (size from the matching *_workspace_bytes);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), makes no hidden host synchronisation, keeps no global state and is re-entrant;
+ *   - return value: SE3_OK (0) or a negative SE3_ERR_* code; no exceptions cross the boundary.
+ *
+ * Layouts: points [N,3]; frames [N,F,9] = row-major 3x3 per (point,frame)
+ * whose COLUMNS are the basis vectors; feature rows are point*F + frame; neighbours [E,2] int32
+ * (col0 = sample / output point, col1 = source / input point) grouped by col0; `ends[M]` =
+ * inclusive end offset of every sample's group (the reference's `start_ids_`).
+ */
+#ifndef SE3CONV_H_
+#define SE3CONV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE3_OK 0
+#define SE3_ERR_INVALID_ARGUMENT (-1) /* null pointer, negative size, misaligned buffer        */
+#define SE3_ERR_UNSUPPORTED (-2)      /* shape outside what the kernels implement (see below)  */
+#define SE3_ERR_WORKSPACE (-3)        /* workspace too small                                   */
+#define SE3_ERR_LAUNCH (-4)           /* HIP reported a launch/runtime error                   */
+
+/* Number of descriptor dimensions of the '6D' relative-rotation form (3 local offset + 6):
+ * PNEConvLayerRotEquiv.rel_rot_type = '6D', p_dims = 9 (tasks/SemSeg/seg_models.py:72-79). */
+#define SE3_DESC_DIMS 9
+
+typedef struct se3conv_shape {
+  int64_t n_in;    /* points of the input (source) cloud                    */
+  int64_t n_out;   /* points of the output (sample) cloud                   */
+  int64_t n_edges; /* point-level edges E                                   */
+  int32_t f_in;    /* frames per input point  (PointcloudRotEquiv.n_frames_) */
+  int32_t f_out;   /* frames per output point                               */
+  int32_t c_in;    /* input feature channels                                */
+  int32_t c_out;   /* output feature channels                               */
+  int32_t num_basis; /* K = p_num_basis; the MFMA kernels implement K == 32 */
+} se3conv_shape;
+
+/* Library / build identification. */
+int se3_abi_version(void);
+const char* se3_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * compute_keys  <-  point_cloud_lib_ops.compute_keys
+ *   (custom_ops/ball_query/compute_keys.cuh:26-31, kernel compute_keys.cu:32-71,
+ *    grid_utils.cuh:57-93).  D = 3 only.
+ *   pts [n,3] f32, batch_ids [n] i32, aabb_min [B,3] f32, num_cells [3] i32 (device),
+ *   cell_size [3] f32 (device) -> keys [n] i64.
+ * ------------------------------------------------------------------------------------------- */
+int se3_compute_keys(const float* pts, const int32_t* batch_ids, const float* aabb_min,
+                     const int32_t* num_cells, const float* cell_size, int64_t n, int64_t* keys,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ball query  <-  point_cloud_lib_ops.ball_query
+ *   (custom_ops/ball_query/ball_query.cuh:30-38, host ball_query.cu:22-103; max_neighbors = 0,
+ *    the only value any model path uses, BQNeighborhood.py:20).
+ * Two phases so that the caller (PyTorch) allocates the edge list between them:
+ *   count: keys -> radix sort -> 9 pencil windows per sample -> per-sample count -> `ends`
+ *          (inclusive scan).  The edge total is ends[n_dst-1]; reading it is the caller's one
+ *          host sync (the reference has four, ball_query.cu:46,49,50 + store_neighbors.cu:264).
+ *   store: second pass over the same windows; writes neighbors[E,2] = (sample, source) grouped
+ *          by sample.  Order inside a sample is deterministic here (pencil order, then sorted
+ *          position); the reference's is not (atomics).
+ * Predicate: sqrt(sum(((s - p) * (1/r))^2)) < 1 in fp32 and equal batch id
+ *   (count_neighbors.cu:84-89).  `aabb_min`/`num_cells` as BallQuery.py:34-38 builds them.
+ * The workspace written by `count` must be passed unchanged to `store`.
+ * ------------------------------------------------------------------------------------------- */
+size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst);
+int se3_ball_query_count(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                         const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                         float radius, int64_t n_src, int64_t n_dst, void* workspace,
+                         size_t workspace_bytes, int32_t* ends, void* stream);
+int se3_ball_query_store(const float* pts_dst, const int32_t* batch_dst, float radius,
+                         int64_t n_src, int64_t n_dst, const void* workspace,
+                         size_t workspace_bytes, const int32_t* ends, int64_t n_edges,
+                         int32_t* neighbors, void* stream);
+
+/* Source-major (transposed) copy of an edge list, used by the backward pass in place of the
+ * reference's global float atomics on the feature gradient (feat_basis_proj_grads.cu:126,140):
+ * t_samples[E] = sample id of every edge, grouped by source point (ascending sample inside a
+ * group), t_ends[n_src] = inclusive end offsets. */
+size_t se3_csr_transpose_workspace_bytes(int64_t n_edges);
+int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, void* workspace,
+                      size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * rot tensors  <-  PNEConvLayerRotEquiv.get_rot_tenors
+ *   (point_cloud_lib/layers/PNEConvLayerRotEquiv.py:62-128).  Materialises what the reference
+ *   caches: desc[E',9] (3 local offsets + 6-D relative rotation), frame-level edges
+ *   fe_neighbors[E',2] = (s*F_out+a, p*F_in+b) sorted by col0 and fe_ends[N_out*F_out]
+ *   (inclusive).  E' = E*F_out*F_in.  Only needed for API parity / FeatBasisProj users; the
+ *   fused operator below never materialises these.
+ * ------------------------------------------------------------------------------------------- */
+int se3_rot_tensors(const float* pts_in, const float* pts_out, const float* frames_in,
+                    const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                    const float* rho, const se3conv_shape* shape, float* desc,
+                    int32_t* fe_neighbors, int32_t* fe_ends, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * feat_basis_proj / feat_basis_proj_grad  <-  point_cloud_lib_ops.feat_basis_proj{,_grad}
+ *   (custom_ops/feature_aggregation/feat_basis_proj.cuh:27-31, feat_basis_proj_grads.cuh:29-34;
+ *    Python wrapper custom_ops/FeatBasisProj.py:10-65).
+ *   T[m,c,k] = sum_{e in [ends[m-1], ends[m])} basis[e,k] * feat[neighbors[e,1], c]
+ *   basis [E,K] f32, feat [n_feat,C] f32, neighbors [E,2] i32, ends [M] i32 -> T [M,C,K].
+ *   grad: gT [M,C,K] -> g_feat [n_feat,C], g_basis [E,K]  (both fully overwritten).
+ *   Any C >= 1 and K in {8,16,32,64} (the reference's set, feat_basis_utils.cuh:35-41).
+ * ------------------------------------------------------------------------------------------- */
+int se3_feat_basis_proj(const float* basis, const float* feat, const int32_t* neighbors,
+                        const int32_t* ends, int64_t n_edges, int64_t n_rows, int64_t n_feat,
+                        int32_t channels, int32_t num_basis, float* out, void* stream);
+int se3_feat_basis_proj_grad(const float* basis, const float* feat, const int32_t* neighbors,
+                             const int32_t* ends, const float* grad_out, int64_t n_edges,
+                             int64_t n_rows, int64_t n_feat, int32_t channels, int32_t num_basis,
+                             float* g_feat, float* g_basis, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * the fused operator  <-  PNEConvLayerRotEquiv.__compute_convolution__
+ *   (point_cloud_lib/layers/PNEConvLayerRotEquiv.py:160-216: get_rot_tenors :62-128, kernel MLP
+ *    :199-203, FeatBasisProj :206-207, einsum :210, scalings :213-216).
+ *
+ *   out[(s,a),o] = (nu/F_in) * sum_{(s,p) in E} sum_b sum_k sum_i
+ *                    GELU_erf([rho*(x_p-y_s)^T R_{s,a}, rows 0,1 of R_{s,a}^T R_{p,b}] . A + beta)_k
+ *                    * feat[(p,b),i] * W[i,k,o]
+ *
+ *   proj_axes [9,K], proj_biases [K], conv_weights [C_in,K,C_out]; rho, nu: device scalars
+ *   (the module's norm_neigh_dist_ / norm_num_neighs_ buffers, IConvLayer.py:33-36).
+ *   out [N_out*F_out, C_out].  `t_save` (optional, may be NULL): [N_out*F_out, C_in, K] --
+ *   the aggregated basis tensor, kept for the weight gradient like autograd keeps the
+ *   reference's `result_tensor`.
+ *
+ * backward: grad_out [N_out*F_out, C_out] -> any of grad_feat [N_in*F_in, C_in],
+ *   grad_axes [9,K], grad_biases [K], grad_weights [C_in,K,C_out] (NULL = not wanted).  No
+ *   gradient flows to points or frames (the reference builds geometry under no_grad, :67).
+ *   `t_samples`/`t_ends` = se3_csr_transpose of `neighbors` (needed only for grad_feat);
+ *   `t_save` = the tensor written by the forward (needed for grad_weights; if NULL it is
+ *   recomputed into the workspace).
+ * ------------------------------------------------------------------------------------------- */
+size_t se3conv_fwd_workspace_bytes(const se3conv_shape* shape, int save_t);
+int se3conv_fwd(const float* pts_in, const float* pts_out, const float* frames_in,
+                const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                const float* feat, const float* proj_axes, const float* proj_biases,
+                const float* conv_weights, const float* rho, const float* nu,
+                const se3conv_shape* shape, float* out, float* t_save, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+size_t se3conv_bwd_workspace_bytes(const se3conv_shape* shape, int want_feat, int want_params,
+                                   int have_t_save);
+int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_in,
+                const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                const int32_t* t_samples, const int32_t* t_ends, const float* feat,
+                const float* proj_axes, const float* proj_biases, const float* conv_weights,
+                const float* rho, const float* nu, const float* t_save, const float* grad_out,
+                const se3conv_shape* shape, float* grad_feat, float* grad_axes,
+                float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE3CONV_H_ */

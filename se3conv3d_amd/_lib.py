@@ -1,0 +1,80 @@
+"""ctypes binding of libse3conv_hip.so (C ABI declared in include/se3conv.h).
+
+There is no CPU fallback: if the library is missing or a call fails the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libse3conv_hip.so")
+
+SE3_OK = 0
+
+
+class Se3Shape(C.Structure):
+    """struct se3conv_shape (include/se3conv.h)."""
+
+    _fields_ = [
+        ("n_in", C.c_int64), ("n_out", C.c_int64), ("n_edges", C.c_int64),
+        ("f_in", C.c_int32), ("f_out", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32),
+        ("num_basis", C.c_int32),
+    ]
+
+
+class Se3LibraryError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_SZ = C.c_size_t
+_F = C.c_float
+_SHP = C.POINTER(Se3Shape)
+
+# name -> (restype, argtypes); must list every symbol include/se3conv.h declares
+SIGNATURES = {
+    "se3_abi_version": (C.c_int, []),
+    "se3_error_string": (C.c_char_p, [C.c_int]),
+    "se3_compute_keys": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "se3_ball_query_workspace_bytes": (_SZ, [_I64, _I64]),
+    "se3_ball_query_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _SZ, _P, _P]),
+    "se3_ball_query_store": (C.c_int, [_P, _P, _F, _I64, _I64, _P, _SZ, _P, _I64, _P, _P]),
+    "se3_csr_transpose_workspace_bytes": (_SZ, [_I64]),
+    "se3_csr_transpose": (C.c_int, [_P, _I64, _I64, _P, _SZ, _P, _P, _P]),
+    "se3_rot_tensors": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SHP, _P, _P, _P, _P]),
+    "se3_feat_basis_proj": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P]),
+    "se3_feat_basis_proj_grad": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P]),
+    "se3conv_fwd_workspace_bytes": (_SZ, [_SHP, C.c_int]),
+    "se3conv_fwd": (C.c_int, [_P] * 12 + [_SHP, _P, _P, _P, _SZ, _P]),
+    "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
+    "se3conv_bwd": (C.c_int, [_P] * 16 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises Se3LibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Se3LibraryError(
+            f"{LIB_PATH} not found: build it with `python -m se3conv3d_amd.build` "
+            "(there is deliberately no CPU fallback for the HIP path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != SE3_OK:
+        msg = load().se3_error_string(code).decode()
+        raise Se3LibraryError(f"{what} failed with code {code}: {msg}")

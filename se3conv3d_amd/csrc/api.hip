@@ -1,0 +1,403 @@
+// extern "C" entry points of the fused operator + the API-parity ops (see include/se3conv.h).
+#include "common.h"
+
+namespace se3 {
+
+namespace {
+
+// [A; beta] as one [10, K] matrix: the constant-1 descriptor slot carries the bias through the MFMA.
+__global__ void build_axes_ext_kernel(const float* __restrict__ axes, const float* __restrict__ biases,
+                                      float* __restrict__ ext) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < SE3_DESC_DIMS * kBasis) ext[i] = axes[i];
+  else if (i < kDescExt * kBasis) ext[i] = biases[i - SE3_DESC_DIMS * kBasis];
+}
+
+// dst[c][r] = src[r][c]   (src [rows, cols])
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / rows), r = (int)(i % rows);
+    dst[i] = src[(int64_t)r * cols + c];
+  }
+}
+
+// w2[(o*K + k), i] = w[i, k, o]
+__global__ void permute_weights_oki_kernel(const float* __restrict__ w, float* __restrict__ w2, int c_in, int kb,
+                                           int c_out) {
+  const int64_t total = (int64_t)c_in * kb * c_out;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % c_in);
+    const int ok = (int)(idx / c_in);
+    const int k = ok % kb, o = ok / kb;
+    w2[idx] = w[((int64_t)i * kb + k) * c_out + o];
+  }
+}
+
+__global__ void reduce_param_partials_kernel(const float* __restrict__ partials, int n_partials,
+                                             float* __restrict__ grad_axes, float* __restrict__ grad_biases) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kDescExt * kBasis) return;
+  float s = 0.f;
+  for (int p = 0; p < n_partials; ++p) s += partials[(int64_t)p * kDescExt * kBasis + i];
+  if (i < SE3_DESC_DIMS * kBasis) {
+    if (grad_axes) grad_axes[i] = s;
+  } else if (grad_biases) {
+    grad_biases[i - SE3_DESC_DIMS * kBasis] = s;
+  }
+}
+
+// ---- API-parity kernels (not on the fused path) ------------------------------------------------
+
+// get_rot_tenors materialised (PNEConvLayerRotEquiv.py:62-128): one thread per (edge, a, b).
+__global__ void rot_tensors_kernel(const float* __restrict__ pts_in, const float* __restrict__ pts_out,
+                                   const float* __restrict__ frames_in, const float* __restrict__ frames_out,
+                                   const int32_t* __restrict__ neighbors, const int32_t* __restrict__ ends,
+                                   const float* __restrict__ rho_p, int64_t n_edges, int f_in, int f_out,
+                                   float* __restrict__ desc, int32_t* __restrict__ fe_neighbors) {
+  const float rho = *rho_p;
+  const int ff = f_in * f_out;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_edges * ff;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = t / ff;
+    const int ab = (int)(t - e * ff);
+    const int a = ab / f_in, b = ab % f_in;
+    const int s = neighbors[e * 2], p = neighbors[e * 2 + 1];
+    const int start = s > 0 ? ends[s - 1] : 0;
+    const int deg = ends[s] - start;
+    const int64_t idx = (int64_t)ff * start + (int64_t)a * deg * f_in + (e - start) * f_in + b;
+    float x[3], y[3], ri[9], ro[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[i] = pts_in[(int64_t)p * 3 + i], y[i] = pts_out[(int64_t)s * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      ri[i] = frames_in[((int64_t)p * f_in + b) * 9 + i], ro[i] = frames_out[((int64_t)s * f_out + a) * 9 + i];
+    edge_descriptor(x, ri, y, ro, rho, d);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) desc[idx * 9 + i] = d[i];
+    fe_neighbors[idx * 2] = s * f_out + a;
+    fe_neighbors[idx * 2 + 1] = p * f_in + b;
+  }
+}
+
+__global__ void rot_tensor_ends_kernel(const int32_t* __restrict__ ends, int64_t n_out, int f_in, int f_out,
+                                       int32_t* __restrict__ fe_ends) {
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_out * f_out;
+       m += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = m / f_out;
+    const int a = (int)(m - s * f_out);
+    const int start = s > 0 ? ends[s - 1] : 0;
+    const int deg = ends[s] - start;
+    fe_ends[m] = f_in * f_out * start + (a + 1) * deg * f_in;
+  }
+}
+
+// T[m,c,k] = sum_e basis[e,k] feat[src(e),c]  (feat_basis_proj.cu:24-123): one block per row,
+// thread = (channel group, k); generic in C and K.
+__global__ __launch_bounds__(256) void feat_basis_proj_kernel(const float* __restrict__ basis,
+                                                              const float* __restrict__ feat,
+                                                              const int32_t* __restrict__ neighbors,
+                                                              const int32_t* __restrict__ ends, int channels, int kb,
+                                                              float* __restrict__ out) {
+  const int64_t m = blockIdx.x;
+  const int start = m > 0 ? ends[m - 1] : 0, end = ends[m];
+  const int k = threadIdx.x % kb, cg = threadIdx.x / kb, ncg = blockDim.x / kb;
+  for (int c = cg; c < channels; c += ncg) {
+    float acc = 0.f;
+    for (int e = start; e < end; ++e)
+      acc += basis[(int64_t)e * kb + k] * feat[(int64_t)neighbors[(int64_t)e * 2 + 1] * channels + c];
+    out[(m * channels + c) * kb + k] = acc;
+  }
+}
+
+__device__ __forceinline__ int row_of_edge(const int32_t* __restrict__ ends, int64_t n_rows, int64_t e) {
+  int64_t lo = 0, hi = n_rows;  // first row with ends[row] > e
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (ends[mid] <= e) lo = mid + 1; else hi = mid;
+  }
+  return (int)lo;
+}
+
+// gBasis[e,k] = sum_c gT[m,c,k] feat[p,c]   (feat_basis_proj_grads.cu:113-126)
+__global__ void feat_basis_proj_grad_basis_kernel(const float* __restrict__ feat, const int32_t* __restrict__ neighbors,
+                                                  const int32_t* __restrict__ ends, const float* __restrict__ grad_t,
+                                                  int64_t n_edges, int64_t n_rows, int channels, int kb,
+                                                  float* __restrict__ g_basis) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_edges * kb;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = t / kb;
+    const int k = (int)(t - e * kb);
+    const int64_t m = row_of_edge(ends, n_rows, e);
+    const float* f = feat + (int64_t)neighbors[e * 2 + 1] * channels;
+    const float* g = grad_t + m * channels * kb + k;
+    float acc = 0.f;
+    for (int c = 0; c < channels; ++c) acc += g[(int64_t)c * kb] * f[c];
+    g_basis[t] = acc;
+  }
+}
+
+// gFeat[p,c] += sum_k gT[m,c,k] basis[e,k]   (feat_basis_proj_grads.cu:129-140; float atomics as there)
+__global__ void feat_basis_proj_grad_feat_kernel(const float* __restrict__ basis, const int32_t* __restrict__ neighbors,
+                                                 const int32_t* __restrict__ ends, const float* __restrict__ grad_t,
+                                                 int64_t n_edges, int64_t n_rows, int channels, int kb,
+                                                 float* __restrict__ g_feat) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_edges * channels;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = t / channels;
+    const int c = (int)(t - e * channels);
+    const int64_t m = row_of_edge(ends, n_rows, e);
+    const float* g = grad_t + (m * channels + c) * kb;
+    const float* b = basis + e * kb;
+    float acc = 0.f;
+    for (int k = 0; k < kb; ++k) acc += g[k] * b[k];
+    atomicAdd(&g_feat[(int64_t)neighbors[e * 2 + 1] * channels + c], acc);
+  }
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 1 << 20) b = 1 << 20;
+  return (unsigned)b;
+}
+
+bool shape_ok(const se3conv_shape* s) {
+  return s && s->n_in >= 0 && s->n_out >= 0 && s->n_edges >= 0 && s->f_in >= 1 && s->f_out >= 1 && s->c_in >= 1 &&
+         s->c_out >= 1 && s->num_basis >= 1;
+}
+int shape_supported(const se3conv_shape* s) {
+  if (s->num_basis != kBasis) return SE3_ERR_UNSUPPORTED;  // every shipped config uses K = 32
+  if (s->n_in * s->f_in >= (1ll << 31) || s->n_out * s->f_out >= (1ll << 31) ||
+      s->n_edges * s->f_in * s->f_out >= (1ll << 31))
+    return SE3_ERR_UNSUPPORTED;  // row / frame-edge ids are int32 inside the kernels
+  return SE3_OK;
+}
+
+struct FwdLayout { size_t axes_ext, t, total; };
+FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
+  FwdLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  l.axes_ext = take(kDescExt * kBasis * 4);
+  l.t = save_t ? 0 : take((size_t)s->n_out * s->f_out * s->c_in * s->num_basis * 4);
+  l.total = off;
+  return l;
+}
+
+struct BwdLayout { size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, total; int n_param_partials, tn_splits; };
+BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
+  BwdLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t kb = s->num_basis;
+  const size_t rows_out = (size_t)s->n_out * s->f_out, rows_in = (size_t)s->n_in * s->f_in;
+  const size_t wsz = (size_t)s->c_in * kb * s->c_out * 4;
+  l.axes_ext = take(kDescExt * kBasis * 4);
+  l.wt = want_params ? take(wsz) : 0;
+  l.w2 = want_feat ? take(wsz) : 0;
+  size_t big = 0;
+  if (want_params) big = rows_out * s->c_in * kb * 4;
+  if (want_feat && rows_in * s->c_out * kb * 4 > big) big = rows_in * s->c_out * kb * 4;
+  l.big = take(big);
+  l.t = (want_params && !have_t) ? take(rows_out * s->c_in * kb * 4) : 0;
+  l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
+  l.param_partials = want_params ? take((size_t)l.n_param_partials * kDescExt * kBasis * 4) : 0;
+  l.tn_splits = gemm_tn_splits((int64_t)rows_out, s->c_in * (int)kb, s->c_out);
+  l.tn_partials = want_params ? take((size_t)l.tn_splits * wsz) : 0;
+  l.total = off;
+  return l;
+}
+
+EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
+                      const int32_t* neighbors, const int32_t* ends, const se3conv_shape* s) {
+  EdgeGeom g{};
+  g.ctr_pts = pts_out, g.ctr_frames = frames_out, g.nb_pts = pts_in, g.nb_frames = frames_in;
+  g.nbr = neighbors, g.nbr_stride = 2, g.nbr_offset = 1, g.ends = ends;
+  g.n_ctr = s->n_out, g.f_ctr = s->f_out, g.f_nb = s->f_in, g.transposed = 0;
+  return g;
+}
+
+}  // namespace
+}  // namespace se3
+
+using namespace se3;
+
+extern "C" int se3_abi_version(void) { return 1; }
+
+extern "C" const char* se3_error_string(int code) {
+  switch (code) {
+    case SE3_OK: return "ok";
+    case SE3_ERR_INVALID_ARGUMENT: return "invalid argument (null pointer, negative size or bad shape)";
+    case SE3_ERR_UNSUPPORTED: return "unsupported shape (the MFMA kernels need num_basis == 32 and int32-sized clouds)";
+    case SE3_ERR_WORKSPACE: return "workspace too small";
+    case SE3_ERR_LAUNCH: return "HIP launch/runtime error";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int se3_rot_tensors(const float* pts_in, const float* pts_out, const float* frames_in,
+                               const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                               const float* rho, const se3conv_shape* s, float* desc, int32_t* fe_neighbors,
+                               int32_t* fe_ends, void* stream_) {
+  if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->n_edges * s->f_in * s->f_out >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (s->n_out > 0) {
+    if (!ends || !fe_ends) return SE3_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(rot_tensor_ends_kernel, dim3(grid_for(s->n_out * s->f_out)), dim3(256), 0, stream, ends, s->n_out,
+                       s->f_in, s->f_out, fe_ends);
+  }
+  if (s->n_edges > 0) {
+    if (!pts_in || !pts_out || !frames_in || !frames_out || !neighbors || !ends || !rho || !desc || !fe_neighbors)
+      return SE3_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(rot_tensors_kernel, dim3(grid_for(s->n_edges * s->f_in * s->f_out)), dim3(256), 0, stream, pts_in,
+                       pts_out, frames_in, frames_out, neighbors, ends, rho, s->n_edges, s->f_in, s->f_out, desc,
+                       fe_neighbors);
+  }
+  return check_launch();
+}
+
+static bool basis_count_ok(int kb) { return kb == 8 || kb == 16 || kb == 32 || kb == 64; }
+
+extern "C" int se3_feat_basis_proj(const float* basis, const float* feat, const int32_t* neighbors, const int32_t* ends,
+                                   int64_t n_edges, int64_t n_rows, int64_t n_feat, int32_t channels,
+                                   int32_t num_basis, float* out, void* stream) {
+  if (n_edges < 0 || n_rows < 0 || n_feat < 0 || channels < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (!basis_count_ok(num_basis)) return SE3_ERR_UNSUPPORTED;  // feat_basis_utils.cuh:35-41
+  if (n_rows == 0) return SE3_OK;
+  if (!ends || !out || (n_edges > 0 && (!basis || !feat || !neighbors))) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_rows >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(feat_basis_proj_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, basis, feat,
+                     neighbors, ends, channels, num_basis, out);
+  return check_launch();
+}
+
+extern "C" int se3_feat_basis_proj_grad(const float* basis, const float* feat, const int32_t* neighbors,
+                                        const int32_t* ends, const float* grad_out, int64_t n_edges, int64_t n_rows,
+                                        int64_t n_feat, int32_t channels, int32_t num_basis, float* g_feat,
+                                        float* g_basis, void* stream_) {
+  if (n_edges < 0 || n_rows < 0 || n_feat < 0 || channels < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (!basis_count_ok(num_basis)) return SE3_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_feat > 0) {
+    if (!g_feat) return SE3_ERR_INVALID_ARGUMENT;
+    if (hipMemsetAsync(g_feat, 0, (size_t)n_feat * channels * 4, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+  }
+  if (n_edges == 0) return SE3_OK;
+  if (!basis || !feat || !neighbors || !ends || !grad_out || !g_basis) return SE3_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(feat_basis_proj_grad_basis_kernel, dim3(grid_for(n_edges * num_basis)), dim3(256), 0, stream, feat,
+                     neighbors, ends, grad_out, n_edges, n_rows, channels, num_basis, g_basis);
+  hipLaunchKernelGGL(feat_basis_proj_grad_feat_kernel, dim3(grid_for(n_edges * channels)), dim3(256), 0, stream, basis,
+                     neighbors, ends, grad_out, n_edges, n_rows, channels, num_basis, g_feat);
+  return check_launch();
+}
+
+extern "C" size_t se3conv_fwd_workspace_bytes(const se3conv_shape* s, int save_t) {
+  return shape_ok(s) ? fwd_layout(s, save_t).total : 0;
+}
+
+extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
+                           const int32_t* neighbors, const int32_t* ends, const float* feat, const float* proj_axes,
+                           const float* proj_biases, const float* conv_weights, const float* rho, const float* nu,
+                           const se3conv_shape* s, float* out, float* t_save, void* workspace, size_t workspace_bytes,
+                           void* stream_) {
+  if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
+  if (int rc = shape_supported(s)) return rc;
+  if (s->n_out == 0) return SE3_OK;
+  if (!pts_out || !frames_out || !ends || !proj_axes || !proj_biases || !conv_weights || !rho || !nu || !out ||
+      !workspace || (s->n_edges > 0 && (!pts_in || !frames_in || !neighbors || !feat)))
+    return SE3_ERR_INVALID_ARGUMENT;
+  const FwdLayout l = fwd_layout(s, t_save != nullptr);
+  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  float* axes_ext = (float*)(ws + l.axes_ext);
+  float* t = t_save ? t_save : (float*)(ws + l.t);
+
+  hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
+  const EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
+  if (int rc = launch_edge_t(g, feat, s->c_in, axes_ext, rho, t, stream)) return rc;
+  // einsum('nik,iko->no') :210, /F_in :213, *norm_num_neighs_ :216
+  return launch_gemm_nn(t, conv_weights, out, s->n_out * s->f_out, s->c_out, s->c_in * s->num_basis, nu,
+                        1.0f / (float)s->f_in, stream);
+}
+
+extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
+  return shape_ok(s) ? bwd_layout(s, want_feat, want_params, have_t).total : 0;
+}
+
+extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
+                           const int32_t* neighbors, const int32_t* ends, const int32_t* t_samples,
+                           const int32_t* t_ends, const float* feat, const float* proj_axes, const float* proj_biases,
+                           const float* conv_weights, const float* rho, const float* nu, const float* t_save,
+                           const float* grad_out, const se3conv_shape* s, float* grad_feat, float* grad_axes,
+                           float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
+                           void* stream_) {
+  if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
+  if (int rc = shape_supported(s)) return rc;
+  const bool want_feat = grad_feat != nullptr;
+  const bool want_params = grad_axes || grad_biases || grad_weights;
+  if (!want_feat && !want_params) return SE3_OK;
+  if (!proj_axes || !proj_biases || !conv_weights || !rho || !nu || !workspace) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->n_out > 0 && (!pts_out || !frames_out || !ends || !grad_out)) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->n_in > 0 && (!pts_in || !frames_in || !feat)) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->n_edges > 0 && !neighbors) return SE3_ERR_INVALID_ARGUMENT;
+  if (want_feat && s->n_in > 0 && (!t_ends || (s->n_edges > 0 && !t_samples))) return SE3_ERR_INVALID_ARGUMENT;
+  const BwdLayout l = bwd_layout(s, want_feat, want_params, t_save != nullptr);
+  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  float* axes_ext = (float*)(ws + l.axes_ext);
+  float* big = (float*)(ws + l.big);
+  const int kb = s->num_basis;
+  const int ck = s->c_in * kb;
+  const int64_t rows_out = s->n_out * s->f_out, rows_in = s->n_in * s->f_in;
+  const float inv_fin = 1.0f / (float)s->f_in;
+
+  hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
+  const EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
+
+  if (want_params) {
+    // gT[m,(i,k)] = alpha * sum_o g[m,o] W[i,k,o]
+    float* wt = (float*)(ws + l.wt);
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream, conv_weights, wt,
+                       ck, s->c_out);
+    if (int rc = launch_gemm_nn(grad_out, wt, big, rows_out, ck, s->c_out, nu, inv_fin, stream)) return rc;
+    if (grad_axes || grad_biases) {
+      float* partials = (float*)(ws + l.param_partials);
+      if (int rc = launch_edge_param_grad(g, feat, s->c_in, axes_ext, rho, big, partials, l.n_param_partials, stream))
+        return rc;
+      hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(2), dim3(256), 0, stream, partials, l.n_param_partials,
+                         grad_axes, grad_biases);
+    }
+    if (grad_weights) {
+      const float* t = t_save;
+      if (!t) {
+        float* tt = (float*)(ws + l.t);
+        if (int rc = launch_edge_t(g, feat, s->c_in, axes_ext, rho, tt, stream)) return rc;
+        t = tt;
+      }
+      // dW[(i,k),o] = alpha * sum_m T[m,(i,k)] g[m,o]
+      if (int rc = launch_gemm_tn(t, grad_out, grad_weights, (float*)(ws + l.tn_partials), l.tn_splits, rows_out, ck,
+                                  s->c_out, nu, inv_fin, stream))
+        return rc;
+    }
+  }
+
+  if (want_feat && rows_in > 0) {
+    // Transposed convolution instead of scatter atomics:
+    //   U[(p,b),o,k] = sum_{edges into p} sum_a phi(s,a,p,b)[k] g[(s,a),o];  dX[(p,b),i] = alpha * sum_{o,k} U W[i,k,o]
+    EdgeGeom gt{};
+    gt.ctr_pts = pts_in, gt.ctr_frames = frames_in, gt.nb_pts = pts_out, gt.nb_frames = frames_out;
+    gt.nbr = t_samples, gt.nbr_stride = 1, gt.nbr_offset = 0, gt.ends = t_ends;
+    gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.transposed = 1;
+    if (int rc = launch_edge_t(gt, grad_out, s->c_out, axes_ext, rho, big, stream)) return rc;
+    float* w2 = (float*)(ws + l.w2);
+    hipLaunchKernelGGL(permute_weights_oki_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream,
+                       conv_weights, w2, s->c_in, kb, s->c_out);
+    if (int rc = launch_gemm_nn(big, w2, grad_feat, rows_in, s->c_in, s->c_out * kb, nu, inv_fin, stream)) return rc;
+  }
+  return check_launch();
+}

@@ -1,0 +1,190 @@
+// fp32 MFMA GEMMs for the dense contractions of the operator (gfx950).
+//
+//   gemm_nn : C[M,N]  = alpha * A[M,K]  @ B[K,N]       M = rows of the cloud (1e5..1e6), N = channels
+//   gemm_tn : C[Ka,N] = alpha * A[M,Ka]^T @ B[M,N]     reduction over the rows (weight gradient)
+//
+// Both use v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), one 32x64 output strip per
+// wavefront.  alpha = (*alpha_num) * alpha_scale so that the module's device-resident normaliser
+// (norm_num_neighs_) never has to be read back to the host.
+#include "common.h"
+
+namespace se3 {
+
+namespace {
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int AS_LD = BK + 1;  // +1: lanes (rows) r and r+1 land on different banks for the A-operand read
+
+__device__ __forceinline__ float4 ld4_guard(const float* p, int64_t avail, bool vec) {
+  // up to 4 consecutive floats starting at p, `avail` of them readable (<= 0: none)
+  if (avail >= 4 && vec) return *reinterpret_cast<const float4*>(p);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (avail > 0) v.x = p[0];
+  if (avail > 1) v.y = p[1];
+  if (avail > 2) v.z = p[2];
+  if (avail > 3) v.w = p[3];
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ c, int64_t m, int n, int k,
+                                                      const float* __restrict__ alpha_num, float alpha_scale) {
+  __shared__ float as[2][BM][AS_LD];
+  __shared__ __attribute__((aligned(16))) float bs[2][BK][BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const bool a_vec = (k % 4) == 0, b_vec = (n % 4) == 0;
+
+  float4 ra[4], rb[2];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 32 + (tid >> 3), kq = (tid & 7) * 4;
+      const int64_t gr = m0 + row;
+      ra[p] = gr < m ? ld4_guard(a + gr * k + k0 + kq, k - (k0 + kq), a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int kr = p * 16 + (tid >> 4), nq = (tid & 15) * 4;
+      rb[p] = (k0 + kr) < k ? ld4_guard(b + (int64_t)(k0 + kr) * n + n0 + nq, n - (n0 + nq), b_vec)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 32 + (tid >> 3), kq = (tid & 7) * 4;
+      as[buf][row][kq + 0] = ra[p].x, as[buf][row][kq + 1] = ra[p].y;
+      as[buf][row][kq + 2] = ra[p].z, as[buf][row][kq + 3] = ra[p].w;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int kr = p * 16 + (tid >> 4), nq = (tid & 15) * 4;
+      *reinterpret_cast<float4*>(&bs[buf][kr][nq]) = rb[p];
+    }
+  };
+
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  const int nk = (k + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int t = 0; t < BK / 2; ++t) {
+      const float av = as[buf][wave * 32 + rl][2 * t + h];
+      const float b0 = bs[buf][2 * t + h][rl], b1 = bs[buf][2 * t + h][32 + rl];
+      acc0 = mfma32(av, b0, acc0);
+      acc1 = mfma32(av, b1, acc1);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t gr = m0 + wave * 32 + acc_row(r, h);
+    if (gr < m) {
+      const int gc = n0 + rl;
+      if (gc < n) c[gr * n + gc] = alpha * acc0[r];
+      if (gc + 32 < n) c[gr * n + gc + 32] = alpha * acc1[r];
+    }
+  }
+}
+
+// One block: 128 (ka) x 64 (n) outputs over rows [split*chunk, (split+1)*chunk).  Operands are read
+// from global directly in MFMA layout: half-wave h reads 32 consecutive floats of row m+h.
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ partials, int64_t m, int ka, int n,
+                                                      int64_t chunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rl = lane & 31, h = lane >> 5;
+  const int ka0 = blockIdx.x * 128 + wave * 32;
+  const int n0 = blockIdx.y * BN;
+  if (ka0 >= ka) return;
+  const int64_t mb = (int64_t)blockIdx.z * chunk;
+  const int64_t me = min(m, mb + chunk);
+  const bool a_ok = ka0 + rl < ka, b0_ok = n0 + rl < n, b1_ok = n0 + 32 + rl < n;
+  const float* ap = a + (a_ok ? ka0 + rl : 0);
+  const float* bp0 = b + (b0_ok ? n0 + rl : 0);
+  const float* bp1 = b + (b1_ok ? n0 + 32 + rl : 0);
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  constexpr int U = 8;
+  for (int64_t mm = mb; mm < me; mm += 2 * U) {
+    float av[U], bv0[U], bv1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = mm + 2 * u + h;
+      const bool ok = row < me;
+      const int64_t rr = ok ? row : mb;
+      av[u] = ok && a_ok ? ap[rr * ka] : 0.f;
+      bv0[u] = ok && b0_ok ? bp0[rr * n] : 0.f;
+      bv1[u] = ok && b1_ok ? bp1[rr * n] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc0 = mfma32(av[u], bv0[u], acc0);
+      acc1 = mfma32(av[u], bv1[u], acc1);
+    }
+  }
+  float* out = partials + (int64_t)blockIdx.z * ka * n;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ka0 + acc_row(r, h);
+    if (row < ka) {
+      if (b0_ok) out[(int64_t)row * n + n0 + rl] = acc0[r];
+      if (b1_ok) out[(int64_t)row * n + n0 + 32 + rl] = acc1[r];
+    }
+  }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, float* __restrict__ out, int64_t count,
+                                       int splits, const float* __restrict__ alpha_num, float alpha_scale) {
+  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < splits; ++p) s += partials[(int64_t)p * count + i];
+    out[i] = alpha * s;
+  }
+}
+
+}  // namespace
+
+int launch_gemm_nn(const float* a, const float* b, float* c, int64_t m, int n, int k, const float* alpha_num,
+                   float alpha_scale, hipStream_t stream) {
+  if (m == 0 || n == 0) return SE3_OK;
+  const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN - 1) / BN));
+  hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, a, b, c, m, n, k, alpha_num, alpha_scale);
+  return check_launch();
+}
+
+int gemm_tn_splits(int64_t m, int ka, int n) {
+  const int64_t tiles = (int64_t)((ka + 127) / 128) * ((n + BN - 1) / BN);
+  int64_t s = (2048 + tiles - 1) / tiles;
+  const int64_t max_s = (m + 255) / 256;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+int launch_gemm_tn(const float* a, const float* b, float* c, float* partials, int splits, int64_t m, int ka, int n,
+                   const float* alpha_num, float alpha_scale, hipStream_t stream) {
+  if (ka == 0 || n == 0) return SE3_OK;
+  int64_t chunk = (m + splits - 1) / splits;
+  chunk += chunk & 1;  // keep every split's first row even so the (m, m+1) pairing never straddles splits
+  if (chunk == 0) chunk = 2;
+  const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  const int64_t count = (int64_t)ka * n;
+  const int rb = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, stream, partials, c, count, splits, alpha_num,
+                     alpha_scale);
+  return check_launch();
+}
+
+}  // namespace se3

@@ -1,0 +1,330 @@
+// Neighbourhood construction for gfx950: grid keys, radius (ball) query, edge-list transpose.
+//
+// Ball query (replaces custom_ops/ball_query/*.cu of the reference):
+//   keys(src) -> radix sort (hipCUB) -> per sample 9 key windows [(x+dx, y+dy, z-1) .. (.., z+1)]
+//   located by binary search in the sorted keys (no dense pencil table, so the grid size never has
+//   to travel to the host) -> one wavefront per sample tests the flattened candidate list 64 at a
+//   time; hits are compacted with ballot + popcount, so the order inside a sample is deterministic
+//   (the reference scatters with atomics, store_neighbors.cu:129-175).
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace se3 {
+
+namespace {
+
+__device__ __forceinline__ void cell_of(const float* __restrict__ pts, const int32_t* __restrict__ batch_ids,
+                                        const float* __restrict__ aabb_min, const int nc[3], const float inv[3],
+                                        int64_t i, int cell[3], int& b) {
+  b = batch_ids[i];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    // (p - min) * (1/cell), floor, clamp: grid_utils.cuh:57-67
+    const float rel = __fmul_rn(__fsub_rn(pts[i * 3 + d], aabb_min[(int64_t)b * 3 + d]), inv[d]);
+    int c = (int)floorf(rel);
+    cell[d] = min(max(c, 0), nc[d] - 1);
+  }
+}
+
+__device__ __forceinline__ int64_t key_of(const int cell[3], const int nc[3], int b) {
+  // grid_utils.cuh:79-93
+  return (((int64_t)b * nc[0] + cell[0]) * nc[1] + cell[1]) * nc[2] + cell[2];
+}
+
+__global__ void compute_keys_kernel(const float* __restrict__ pts, const int32_t* __restrict__ batch_ids,
+                                    const float* __restrict__ aabb_min, const int32_t* __restrict__ num_cells,
+                                    const float* __restrict__ cell_size, float cell_scalar, int64_t n,
+                                    int64_t* __restrict__ keys, int32_t* __restrict__ iota) {
+  // cell_size == nullptr: the same cell size `cell_scalar` in every dimension (ball query: cell = radius)
+  const int nc[3] = {num_cells[0], num_cells[1], num_cells[2]};
+  const float inv[3] = {1.0f / (cell_size ? cell_size[0] : cell_scalar), 1.0f / (cell_size ? cell_size[1] : cell_scalar),
+                        1.0f / (cell_size ? cell_size[2] : cell_scalar)};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int cell[3], b;
+    cell_of(pts, batch_ids, aabb_min, nc, inv, i, cell, b);
+    keys[i] = key_of(cell, nc, b);
+    if (iota) iota[i] = (int32_t)i;
+  }
+}
+
+__global__ void gather_sorted_points_kernel(const float* __restrict__ pts, const int32_t* __restrict__ ids, int64_t n,
+                                            float4* __restrict__ spts) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int id = ids[i];
+    spts[i] = make_float4(pts[(int64_t)id * 3], pts[(int64_t)id * 3 + 1], pts[(int64_t)id * 3 + 2], __int_as_float(id));
+  }
+}
+
+__device__ __forceinline__ int lower_bound_key(const int64_t* __restrict__ keys, int n, int64_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ranges[s][o] = [lo, hi) positions in the sorted source order of pencil window o = (dx+1)*3 + (dy+1)
+__global__ void find_ranges_kernel(const float* __restrict__ pts_dst, const int32_t* __restrict__ batch_dst,
+                                   const float* __restrict__ aabb_min, const int32_t* __restrict__ num_cells,
+                                   float radius, const int64_t* __restrict__ skeys, int n_src, int64_t n_dst,
+                                   int2* __restrict__ ranges) {
+  const int nc[3] = {num_cells[0], num_cells[1], num_cells[2]};
+  const float inv_r = 1.0f / radius;
+  const float inv[3] = {inv_r, inv_r, inv_r};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst * 9; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = i / 9;
+    const int o = (int)(i - s * 9);
+    int cell[3], b;
+    cell_of(pts_dst, batch_dst, aabb_min, nc, inv, s, cell, b);
+    const int x = cell[0] + o / 3 - 1, y = cell[1] + o % 3 - 1;
+    int2 r = make_int2(0, 0);
+    if (x >= 0 && x < nc[0] && y >= 0 && y < nc[1]) {
+      const int z0 = max(cell[2] - 1, 0), z1 = min(cell[2] + 1, nc[2] - 1);
+      const int64_t base = (((int64_t)b * nc[0] + x) * nc[1] + y) * nc[2];
+      r.x = lower_bound_key(skeys, n_src, base + z0);
+      r.y = lower_bound_key(skeys, n_src, base + z1 + 1);
+    }
+    ranges[i] = r;
+  }
+}
+
+// One wavefront per sample.  STORE = false: counts[s] = #hits.  STORE = true: neighbors[base + j] =
+// (s, source id) for the j-th hit in candidate order.
+template <bool STORE>
+__global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __restrict__ pts_dst, float inv_r,
+                                                              const float4* __restrict__ spts,
+                                                              const int2* __restrict__ ranges, int64_t n_dst,
+                                                              int32_t* __restrict__ counts,
+                                                              const int32_t* __restrict__ ends,
+                                                              int32_t* __restrict__ neighbors) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_dst) return;
+  const float sx = pts_dst[s * 3], sy = pts_dst[s * 3 + 1], sz = pts_dst[s * 3 + 2];
+  int lo[9], pre[10];
+  pre[0] = 0;
+#pragma unroll
+  for (int o = 0; o < 9; ++o) {
+    const int2 r = ranges[s * 9 + o];
+    lo[o] = r.x;
+    pre[o + 1] = pre[o] + (r.y - r.x);
+  }
+  const int total = pre[9];
+  int found = 0;
+  int base = 0;
+  if (STORE) base = s > 0 ? ends[s - 1] : 0;
+  for (int c0 = 0; c0 < total; c0 += 64) {
+    const int c = c0 + lane;
+    bool hit = false;
+    int id = 0;
+    if (c < total) {
+      int o = 0;
+#pragma unroll
+      for (int t = 1; t < 9; ++t) o += (c >= pre[t]) ? 1 : 0;
+      int pos = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if (t == o) pos = lo[t] + (c - pre[t]);
+      const float4 p = spts[pos];
+      // length((s - p) * invR) < 1, un-fused so that it is bit-identical to the CPU oracle
+      const float dx = __fmul_rn(__fsub_rn(sx, p.x), inv_r);
+      const float dy = __fmul_rn(__fsub_rn(sy, p.y), inv_r);
+      const float dz = __fmul_rn(__fsub_rn(sz, p.z), inv_r);
+      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      hit = __fsqrt_rn(d2) < 1.0f;
+      id = __float_as_int(p.w);
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (STORE && hit) {
+      const int slot = base + found + __popcll(mask & ((1ull << lane) - 1ull));
+      neighbors[(int64_t)slot * 2] = (int32_t)s;
+      neighbors[(int64_t)slot * 2 + 1] = id;
+    }
+    found += __popcll(mask);
+  }
+  if (!STORE && lane == 0) counts[s] = found;
+}
+
+__global__ void split_edges_kernel(const int32_t* __restrict__ neighbors, int64_t e, int32_t* __restrict__ src,
+                                   int32_t* __restrict__ smp) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    smp[i] = neighbors[i * 2];
+    src[i] = neighbors[i * 2 + 1];
+  }
+}
+
+__global__ void group_ends_kernel(const int32_t* __restrict__ sorted_keys, int64_t e, int64_t n_groups,
+                                  int32_t* __restrict__ ends) {
+  // ends[p] = number of sorted keys <= p
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_groups; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = 0, hi = e;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sorted_keys[mid] <= (int32_t)p) lo = mid + 1; else hi = mid;
+    }
+    ends[p] = (int32_t)lo;
+  }
+}
+
+inline unsigned blocks_for(int64_t n, int per = 256) {
+  int64_t b = (n + per - 1) / per;
+  if (b < 1) b = 1;
+  if (b > 65535 * 16) b = 65535 * 16;
+  return (unsigned)b;
+}
+
+struct BqLayout {
+  size_t keys, skeys, ids, sids, spts, ranges, counts, temp, temp_bytes, total;
+};
+
+BqLayout bq_layout(int64_t n_src, int64_t n_dst) {
+  BqLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t ns = (size_t)(n_src > 0 ? n_src : 1), nd = (size_t)(n_dst > 0 ? n_dst : 1);
+  l.keys = take(ns * 8);
+  l.skeys = take(ns * 8);
+  l.ids = take(ns * 4);
+  l.sids = take(ns * 4);
+  l.spts = take(ns * 16);
+  l.ranges = take(nd * 9 * 8);
+  l.counts = take(nd * 4);
+  size_t t_sort = 0, t_scan = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (const int64_t*)nullptr, (int64_t*)nullptr,
+                                     (const int32_t*)nullptr, (int32_t*)nullptr, (int)ns);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, (const int32_t*)nullptr, (int32_t*)nullptr, (int)nd);
+  l.temp_bytes = t_sort > t_scan ? t_sort : t_scan;
+  l.temp = take(l.temp_bytes);
+  l.total = off;
+  return l;
+}
+
+}  // namespace
+
+}  // namespace se3
+
+using namespace se3;
+
+extern "C" int se3_compute_keys(const float* pts, const int32_t* batch_ids, const float* aabb_min,
+                                const int32_t* num_cells, const float* cell_size, int64_t n, int64_t* keys,
+                                void* stream) {
+  if (n < 0 || (n > 0 && (!pts || !batch_ids || !aabb_min || !num_cells || !cell_size || !keys)))
+    return SE3_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SE3_OK;
+  hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, pts, batch_ids,
+                     aabb_min, num_cells, cell_size, 0.f, n, keys, (int32_t*)nullptr);
+  return check_launch();
+}
+
+extern "C" size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst) {
+  return bq_layout(n_src, n_dst).total;
+}
+
+extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                    const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                                    float radius, int64_t n_src, int64_t n_dst, void* workspace,
+                                    size_t workspace_bytes, int32_t* ends, void* stream_) {
+  if (n_src < 0 || n_dst < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_src >= (1ll << 31) || n_dst >= (1ll << 31) / 9) return SE3_ERR_UNSUPPORTED;
+  if (n_dst == 0) return SE3_OK;
+  if (!pts_dst || !batch_dst || !aabb_min || !num_cells || !workspace || !ends ||
+      (n_src > 0 && (!pts_src || !batch_src)))
+    return SE3_ERR_INVALID_ARGUMENT;
+  const BqLayout l = bq_layout(n_src, n_dst);
+  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  int64_t* keys = (int64_t*)(ws + l.keys);
+  int64_t* skeys = (int64_t*)(ws + l.skeys);
+  int32_t* ids = (int32_t*)(ws + l.ids);
+  int32_t* sids = (int32_t*)(ws + l.sids);
+  float4* spts = (float4*)(ws + l.spts);
+  int2* ranges = (int2*)(ws + l.ranges);
+  int32_t* counts = (int32_t*)(ws + l.counts);
+  size_t temp_bytes = l.temp_bytes;
+
+  if (n_src > 0) {
+    // cell size = radius in every dimension (BallQuery.py:39-40)
+    hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src, aabb_min,
+                       num_cells, (const float*)nullptr, radius, n_src, keys, ids);
+    if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n_src, 0, 64,
+                                           stream) != hipSuccess)
+      return SE3_ERR_LAUNCH;
+    hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, sids, n_src,
+                       spts);
+  }
+  hipLaunchKernelGGL(find_ranges_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
+                     aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges);
+  hipLaunchKernelGGL(scan_candidates_kernel<false>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, stream, pts_dst,
+                     1.0f / radius, spts, ranges, n_dst, counts, (const int32_t*)nullptr, (int32_t*)nullptr);
+  temp_bytes = l.temp_bytes;
+  if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
+    return SE3_ERR_LAUNCH;
+  return check_launch();
+}
+
+extern "C" int se3_ball_query_store(const float* pts_dst, const int32_t* batch_dst, float radius, int64_t n_src,
+                                    int64_t n_dst, const void* workspace, size_t workspace_bytes,
+                                    const int32_t* ends, int64_t n_edges, int32_t* neighbors, void* stream) {
+  (void)batch_dst;
+  if (n_src < 0 || n_dst < 0 || n_edges < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_dst == 0 || n_edges == 0) return SE3_OK;
+  if (!pts_dst || !workspace || !ends || !neighbors) return SE3_ERR_INVALID_ARGUMENT;
+  const BqLayout l = bq_layout(n_src, n_dst);
+  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  const char* ws = (const char*)workspace;
+  hipLaunchKernelGGL(scan_candidates_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
+                     (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors);
+  return check_launch();
+}
+
+namespace {
+struct TrLayout {
+  size_t src, smp, ssrc, temp, temp_bytes, total;
+};
+TrLayout tr_layout(int64_t e) {
+  TrLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = se3::align_up(off + bytes, 256); return o; };
+  const size_t ne = (size_t)(e > 0 ? e : 1);
+  l.src = take(ne * 4);
+  l.smp = take(ne * 4);
+  l.ssrc = take(ne * 4);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, l.temp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                     (const int32_t*)nullptr, (int32_t*)nullptr, (int)ne);
+  l.temp = take(l.temp_bytes);
+  l.total = off;
+  return l;
+}
+}  // namespace
+
+extern "C" size_t se3_csr_transpose_workspace_bytes(int64_t n_edges) { return tr_layout(n_edges).total; }
+
+extern "C" int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, void* workspace,
+                                 size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream_) {
+  if (n_edges < 0 || n_src < 0) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_edges >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  if (n_src == 0) return SE3_OK;
+  if (!t_ends || (n_edges > 0 && (!neighbors || !workspace || !t_samples))) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  const TrLayout l = tr_layout(n_edges);
+  if (n_edges > 0 && workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  int32_t* ssrc = nullptr;
+  if (n_edges > 0) {
+    int32_t* src = (int32_t*)(ws + l.src);
+    int32_t* smp = (int32_t*)(ws + l.smp);
+    ssrc = (int32_t*)(ws + l.ssrc);
+    hipLaunchKernelGGL(split_edges_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, src, smp);
+    size_t temp_bytes = l.temp_bytes;
+    // stable LSD radix sort: inside one source the samples keep their ascending input order
+    if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, src, ssrc, smp, t_samples, (int)n_edges, 0, 32,
+                                           stream) != hipSuccess)
+      return SE3_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(group_ends_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, ssrc, n_edges, n_src, t_ends);
+  return check_launch();
+}

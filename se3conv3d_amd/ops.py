@@ -1,0 +1,356 @@
+"""Tensor-level wrappers and autograd Functions over the C ABI (include/se3conv.h).
+
+PyTorch is used for device memory, the current stream and autograd bookkeeping only; every
+computation below runs in libse3conv_hip.so.  The class names / call signatures mirror the
+reference's ``point_cloud_lib.custom_ops`` (FeatBasisProj.py, BallQuery.py, ComputeKeys.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Se3Shape
+
+
+# --------------------------------------------------------------------------------------- helpers
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, device=None) -> C.c_void_p:
+    """Device pointer of a contiguous CUDA tensor of the given dtype (ValueError otherwise)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback), got {t.device}")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name}: on {t.device}, expected {device}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _as(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Contiguous copy-if-needed in ``dtype`` (what the reference wrappers do with ``.to``)."""
+    return t.detach().to(dtype).contiguous()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------- grid keys (a10, f-2)
+def compute_keys(pts, batch_ids, aabb_min, num_cells, cell_size) -> torch.Tensor:
+    """``point_cloud_lib_ops.compute_keys`` (reference ComputeKeys.py / compute_keys.cu:75-124)."""
+    lib = _lib.load()
+    pts = _as(pts, torch.float32)
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("compute_keys: only 3-D points are supported")
+    dev = pts.device
+    n = pts.shape[0]
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    b = _as(batch_ids, torch.int32)
+    mn = _as(aabb_min, torch.float32)
+    nc = _as(num_cells, torch.int32).to(dev)
+    cs = _as(cell_size, torch.float32).to(dev)
+    _lib.check(lib.se3_compute_keys(_ptr(pts, torch.float32, "pts"), _ptr(b, torch.int32, "batch_ids", dev),
+                                    _ptr(mn, torch.float32, "aabb_min", dev), _ptr(nc, torch.int32, "num_cells"),
+                                    _ptr(cs, torch.float32, "cell_size"), n, _ptr(keys, torch.int64, "keys"),
+                                    _stream()), "se3_compute_keys")
+    return keys
+
+
+class ComputeKeys(torch.autograd.Function):
+    """Drop-in for ``point_cloud_lib.custom_ops.ComputeKeys``."""
+
+    @staticmethod
+    def forward(ctx, p_pts, p_batch_ids, p_aabb_min, p_grid_size, p_cell_size):
+        return compute_keys(p_pts, p_batch_ids, p_aabb_min, p_grid_size, p_cell_size)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------- ball query (a10)
+def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float):
+    """Grid parameters exactly as BallQuery.forward builds them (BallQuery.py:34-38), on device,
+    without a host read-back."""
+    n_batches_t = batch_src.max() + 1 if batch_src.numel() else None
+    idx = batch_src.to(torch.int64)
+    # number of batches is needed for the output shape: one tiny sync, same as the reference's
+    # `torch::amax(...).item()` (ball_query.cu:46).
+    nb = int(n_batches_t.item()) if n_batches_t is not None else 1
+    mn = torch.full((nb, 3), float("inf"), dtype=torch.float32, device=pts_src.device)
+    mx = torch.full((nb, 3), float("-inf"), dtype=torch.float32, device=pts_src.device)
+    idx3 = idx[:, None].expand(-1, 3)
+    mn = mn.scatter_reduce(0, idx3, pts_src, "amin") - 1e-6
+    mx = mx.scatter_reduce(0, idx3, pts_src, "amax") - 1e-6
+    num_cells = (((mx - mn) / radius).to(torch.int32) + 1).max(dim=0)[0].to(torch.int32)
+    return mn.contiguous(), num_cells.contiguous()
+
+
+def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Radius neighbours: ``neighbors [E,2] int32`` (col0 sample, col1 source; grouped by sample)
+    and ``ends [M] int32`` (inclusive end offsets).  Two-phase C ABI, one host sync for E."""
+    lib = _lib.load()
+    pts_src = _as(pts_src, torch.float32)
+    pts_dst = _as(pts_dst, torch.float32)
+    if pts_src.dim() != 2 or pts_src.shape[1] != 3 or pts_dst.dim() != 2 or pts_dst.shape[1] != 3:
+        raise ValueError("ball_query: only [N,3] point sets are supported")
+    if not (radius > 0):
+        raise ValueError("ball_query: radius must be positive")
+    dev = pts_src.device
+    bs = _as(batch_src, torch.int32)
+    bd = _as(batch_dst, torch.int32)
+    n_src, n_dst = pts_src.shape[0], pts_dst.shape[0]
+    ends = torch.zeros(n_dst, dtype=torch.int32, device=dev)
+    if n_dst == 0 or n_src == 0:
+        return torch.zeros((0, 2), dtype=torch.int32, device=dev), ends
+    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius)
+    nbytes = lib.se3_ball_query_workspace_bytes(n_src, n_dst)
+    ws = _workspace(nbytes, dev)
+    f32, i32 = torch.float32, torch.int32
+    _lib.check(lib.se3_ball_query_count(
+        _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
+        _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius),
+        n_src, n_dst, C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(ends, i32, "ends"), _stream()),
+        "se3_ball_query_count")
+    n_edges = int(ends[-1].item())
+    neighbors = torch.empty((n_edges, 2), dtype=torch.int32, device=dev)
+    _lib.check(lib.se3_ball_query_store(
+        _ptr(pts_dst, f32, "pts_dst"), _ptr(bd, i32, "batch_dst"), float(radius), n_src, n_dst,
+        C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(ends, i32, "ends"), n_edges,
+        _ptr(neighbors, i32, "neighbors"), _stream()), "se3_ball_query_store")
+    return neighbors, ends
+
+
+class BallQuery(torch.autograd.Function):
+    """Drop-in for ``point_cloud_lib.custom_ops.BallQuery`` (BallQuery.py:11-53).  Like the
+    reference it returns ``neighbors`` as int64 (ball_query.cu:99-101 promotes through ``cat``)
+    and ``start_ids`` (inclusive ends) as int32; ``max_neighbors`` must be 0."""
+
+    @staticmethod
+    def forward(ctx, p_pt_src, p_pt_sample, p_batch_id_src, p_batch_id_sample, radius, max_neighbors):
+        if max_neighbors != 0:
+            raise NotImplementedError("max_neighbors > 0 (random sub-sampling) is not used by any model path")
+        nb, ends = ball_query(p_pt_src, p_pt_sample, p_batch_id_src, p_batch_id_sample, radius)
+        return nb.to(torch.int64), ends
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return None, None, None, None, None, None
+
+
+def csr_transpose(neighbors_i32: torch.Tensor, n_src: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Source-major copy of an edge list: ``t_samples [E]``, ``t_ends [n_src]`` (inclusive)."""
+    lib = _lib.load()
+    dev = neighbors_i32.device
+    e = neighbors_i32.shape[0]
+    t_samples = torch.empty(e, dtype=torch.int32, device=dev)
+    t_ends = torch.zeros(n_src, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.se3_csr_transpose_workspace_bytes(e), dev)
+    _lib.check(lib.se3_csr_transpose(_ptr(neighbors_i32, torch.int32, "neighbors"), e, n_src,
+                                     C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(t_samples, torch.int32, "t_samples"),
+                                     _ptr(t_ends, torch.int32, "t_ends"), _stream()), "se3_csr_transpose")
+    return t_samples, t_ends
+
+
+# ------------------------------------------------------------------- the operator's geometry bundle
+@dataclass
+class ConvGeometry:
+    """Everything the operator reads besides features and parameters (all fp32 / int32, GPU)."""
+
+    pts_in: torch.Tensor       # [N_in,3]
+    pts_out: torch.Tensor      # [N_out,3]
+    frames_in: torch.Tensor    # [N_in,F_in,9]
+    frames_out: torch.Tensor   # [N_out,F_out,9]
+    neighbors: torch.Tensor    # [E,2] int32
+    ends: torch.Tensor         # [N_out] int32
+    _transpose: Optional[Tuple[torch.Tensor, torch.Tensor]] = field(default=None, repr=False)
+
+    @staticmethod
+    def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends) -> "ConvGeometry":
+        n_out = pts_out.shape[0]
+        ends = _as(ends, torch.int32)
+        if ends.shape[0] != n_out:
+            raise ValueError(f"start_ids has {ends.shape[0]} entries, expected one per output point ({n_out})")
+        fi = _as(frames_in, torch.float32).reshape(pts_in.shape[0], -1, 9)
+        fo = _as(frames_out, torch.float32).reshape(n_out, -1, 9)
+        nb = _as(neighbors, torch.int32)
+        if nb.dim() != 2 or nb.shape[1] != 2:
+            raise ValueError("neighbors must be [E,2]")
+        return ConvGeometry(_as(pts_in, torch.float32), _as(pts_out, torch.float32), fi, fo, nb, ends)
+
+    def transpose(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._transpose is None:
+            self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0])
+        return self._transpose
+
+    def shape(self, c_in: int, c_out: int, num_basis: int) -> Se3Shape:
+        return Se3Shape(self.pts_in.shape[0], self.pts_out.shape[0], self.neighbors.shape[0],
+                        self.frames_in.shape[1], self.frames_out.shape[1], c_in, c_out, num_basis)
+
+
+def _geom_ptrs(g: ConvGeometry):
+    f32, i32 = torch.float32, torch.int32
+    dev = g.pts_out.device
+    return [_ptr(g.pts_in, f32, "pts_in", dev), _ptr(g.pts_out, f32, "pts_out", dev),
+            _ptr(g.frames_in, f32, "frames_in", dev), _ptr(g.frames_out, f32, "frames_out", dev),
+            _ptr(g.neighbors, i32, "neighbors", dev), _ptr(g.ends, i32, "ends", dev)]
+
+
+def _scalar(t, name, dev) -> torch.Tensor:
+    t = torch.as_tensor(t, dtype=torch.float32)
+    return t.detach().to(device=dev, dtype=torch.float32).reshape(()).contiguous()
+
+
+def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weights, rho, nu, save_t: bool = True):
+    """Raw forward: returns ``(out [N_out*F_out, C_out], T or None)``."""
+    lib = _lib.load()
+    f32 = torch.float32
+    dev = geom.pts_out.device
+    feat = _as(feat, f32)
+    a, b, w = _as(proj_axes, f32), _as(proj_biases, f32), _as(conv_weights, f32)
+    if a.shape[0] != 9:
+        raise ValueError(f"proj_axes_ has {a.shape[0]} rows; only the 9-D ('6D') descriptor is implemented")
+    c_in, kb, c_out = w.shape
+    if feat.shape != (geom.pts_in.shape[0] * geom.frames_in.shape[1], c_in):
+        raise ValueError(f"features are {tuple(feat.shape)}, expected "
+                         f"({geom.pts_in.shape[0] * geom.frames_in.shape[1]}, {c_in})")
+    shp = geom.shape(c_in, c_out, kb)
+    rows = geom.pts_out.shape[0] * geom.frames_out.shape[1]
+    out = torch.empty((rows, c_out), dtype=f32, device=dev)
+    t_save = torch.empty((rows, c_in, kb), dtype=f32, device=dev) if save_t else None
+    ws = _workspace(lib.se3conv_fwd_workspace_bytes(C.byref(shp), 1 if save_t else 0), dev)
+    rho_t, nu_t = _scalar(rho, "rho", dev), _scalar(nu, "nu", dev)
+    _lib.check(lib.se3conv_fwd(*_geom_ptrs(geom), _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),
+                               _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
+                               _ptr(rho_t, f32, "norm_neigh_dist_"), _ptr(nu_t, f32, "norm_num_neighs_"),
+                               C.byref(shp), _ptr(out, f32, "out"), _ptr(t_save, f32, "t_save"),
+                               C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "se3conv_fwd")
+    return out, t_save
+
+
+def se3conv_backward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weights, rho, nu, t_save, grad_out,
+                     want_feat=True, want_params=True):
+    """Raw backward: returns ``(dX, dA, dbeta, dW)`` (None where not requested)."""
+    lib = _lib.load()
+    f32, i32 = torch.float32, torch.int32
+    dev = geom.pts_out.device
+    feat = _as(feat, f32)
+    a, b, w = _as(proj_axes, f32), _as(proj_biases, f32), _as(conv_weights, f32)
+    g = _as(grad_out, f32)
+    c_in, kb, c_out = w.shape
+    shp = geom.shape(c_in, c_out, kb)
+    d_x = torch.empty_like(feat) if want_feat else None
+    d_a = torch.empty_like(a) if want_params else None
+    d_b = torch.empty_like(b) if want_params else None
+    d_w = torch.empty_like(w) if want_params else None
+    t_samples, t_ends = geom.transpose() if want_feat else (None, None)
+    ws = _workspace(lib.se3conv_bwd_workspace_bytes(C.byref(shp), int(want_feat), int(want_params),
+                                                    int(t_save is not None)), dev)
+    rho_t, nu_t = _scalar(rho, "rho", dev), _scalar(nu, "nu", dev)
+    _lib.check(lib.se3conv_bwd(*_geom_ptrs(geom), _ptr(t_samples, i32, "t_samples"), _ptr(t_ends, i32, "t_ends"),
+                               _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),
+                               _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
+                               _ptr(rho_t, f32, "rho"), _ptr(nu_t, f32, "nu"), _ptr(t_save, f32, "t_save"),
+                               _ptr(g, f32, "grad_out", dev), C.byref(shp), _ptr(d_x, f32, "grad_feat"),
+                               _ptr(d_a, f32, "grad_axes"), _ptr(d_b, f32, "grad_biases"),
+                               _ptr(d_w, f32, "grad_weights"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+               "se3conv_bwd")
+    return d_x, d_a, d_b, d_w
+
+
+class SE3ConvFunction(torch.autograd.Function):
+    """The fused operator as one autograd node (replaces the chain matmul -> GELU -> FeatBasisProj
+    -> einsum -> scalings of PNEConvLayerRotEquiv.py:199-216).  Differentiable w.r.t. features and
+    the three parameters; geometry carries no gradient (reference: built under no_grad, :67)."""
+
+    @staticmethod
+    def forward(ctx, feat, proj_axes, proj_biases, conv_weights, geom: ConvGeometry, rho, nu):
+        need_params = any(ctx.needs_input_grad[1:4])
+        out, t_save = se3conv_forward(geom, feat, proj_axes, proj_biases, conv_weights, rho, nu,
+                                      save_t=need_params)
+        ctx.geom = geom
+        ctx.in_dtype = feat.dtype
+        ctx.save_for_backward(feat, proj_axes, proj_biases, conv_weights, _scalar(rho, "rho", out.device),
+                              _scalar(nu, "nu", out.device), t_save if t_save is not None else torch.empty(0))
+        ctx.has_t = t_save is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feat, a, b, w, rho, nu, t_save = ctx.saved_tensors
+        want_feat = ctx.needs_input_grad[0]
+        want_params = any(ctx.needs_input_grad[1:4])
+        d_x, d_a, d_b, d_w = se3conv_backward(ctx.geom, feat, a, b, w, rho, nu, t_save if ctx.has_t else None,
+                                              grad_out, want_feat, want_params)
+        if d_x is not None:
+            d_x = d_x.to(ctx.in_dtype)
+        ng = ctx.needs_input_grad
+        return (d_x, d_a if ng[1] else None, d_b if ng[2] else None, d_w if ng[3] else None, None, None, None)
+
+
+# ------------------------------------------------------------------ API-parity ops (a1, a3, a4, a5)
+def rot_tensors(geom: ConvGeometry, rho):
+    """``get_rot_tenors`` materialised on the GPU: ``desc [E',9]``, ``neighbs [E',2] int32`` sorted by
+    output row, ``ends [N_out*F_out] int32``."""
+    lib = _lib.load()
+    dev = geom.pts_out.device
+    shp = geom.shape(1, 1, 32)
+    ff = shp.f_in * shp.f_out
+    e2 = geom.neighbors.shape[0] * ff
+    desc = torch.empty((e2, 9), dtype=torch.float32, device=dev)
+    fe_nb = torch.empty((e2, 2), dtype=torch.int32, device=dev)
+    fe_ends = torch.zeros(geom.pts_out.shape[0] * shp.f_out, dtype=torch.int32, device=dev)
+    rho_t = _scalar(rho, "rho", dev)
+    _lib.check(lib.se3_rot_tensors(*_geom_ptrs(geom), _ptr(rho_t, torch.float32, "rho"), C.byref(shp),
+                                   _ptr(desc, torch.float32, "desc"), _ptr(fe_nb, torch.int32, "fe_neighbors"),
+                                   _ptr(fe_ends, torch.int32, "fe_ends"), _stream()), "se3_rot_tensors")
+    return desc, fe_nb, fe_ends
+
+
+class FeatBasisProj(torch.autograd.Function):
+    """Drop-in for ``point_cloud_lib.custom_ops.FeatBasisProj`` (FeatBasisProj.py:4-65)."""
+
+    @staticmethod
+    def forward(p_ctx, p_pt_basis, p_pt_features, p_neighbors, p_start_ids):
+        lib = _lib.load()
+        f32, i32 = torch.float32, torch.int32
+        basis, feat = _as(p_pt_basis, f32), _as(p_pt_features, f32)
+        nb, ends = _as(p_neighbors, i32), _as(p_start_ids, i32)
+        p_ctx.save_for_backward(basis, feat, nb, ends)
+        p_ctx.dtypes = (p_pt_basis.dtype, p_pt_features.dtype)
+        dev = feat.device
+        rows, ch, kb = ends.shape[0], feat.shape[1], basis.shape[1]
+        out = torch.empty((rows, ch, kb), dtype=f32, device=dev)
+        _lib.check(lib.se3_feat_basis_proj(_ptr(basis, f32, "pt_basis", dev), _ptr(feat, f32, "pt_features"),
+                                           _ptr(nb, i32, "neighbors", dev), _ptr(ends, i32, "start_ids", dev),
+                                           nb.shape[0], rows, feat.shape[0], ch, kb, _ptr(out, f32, "out"),
+                                           _stream()), "se3_feat_basis_proj")
+        return out
+
+    @staticmethod
+    def backward(p_ctx, p_grads):
+        lib = _lib.load()
+        f32, i32 = torch.float32, torch.int32
+        basis, feat, nb, ends = p_ctx.saved_tensors
+        g = _as(p_grads, f32)
+        dev = feat.device
+        g_feat = torch.empty_like(feat)
+        g_basis = torch.empty_like(basis)
+        _lib.check(lib.se3_feat_basis_proj_grad(
+            _ptr(basis, f32, "pt_basis", dev), _ptr(feat, f32, "pt_features"), _ptr(nb, i32, "neighbors"),
+            _ptr(ends, i32, "start_ids"), _ptr(g, f32, "grads", dev), nb.shape[0], ends.shape[0], feat.shape[0],
+            feat.shape[1], basis.shape[1], _ptr(g_feat, f32, "g_feat"), _ptr(g_basis, f32, "g_basis"), _stream()),
+            "se3_feat_basis_proj_grad")
+        return g_basis.to(p_ctx.dtypes[0]), g_feat.to(p_ctx.dtypes[1]), None, None

@@ -1,0 +1,235 @@
+"""Geometry containers the accelerated path reads (mirror of point_cloud_lib/pc).
+
+Only what the convolution and the benchmark stack need:
+
+  * ``Pointcloud`` / ``PointcloudRotEquiv``  (pc/Pointcloud.py:5-48, pc/PointcloudRotEquiv.py:13-52):
+    ``pts_``, ``batch_ids_``, ``local_frames_ [N,F,9]``, ``n_frames_``,
+    ``batch_ids_considering_frames_``; frames sampled in the constructor -- random rotations or
+    rotations about a fixed axis (pc/RotationFunctions.py:428-508).  PCA frames (kNN + eigh) are
+    the next scope row and raise NotImplementedError here.
+  * ``Neighborhood`` / ``BQNeighborhood``    (pc/Neighborhood.py, pc/BQNeighborhood.py:13-64) on the HIP ball query.
+  * ``GridSubSample`` / ``PointHierarchy`` / ``PointHierarchyRotEquiv`` (pc/GridSubSample.py:40-93,
+    pc/Grid.py:37-57, pc/PointHierarchy.py:10-93, pc/PointHierarchyRotEquiv.py:7-44): grid-average
+    sub-sampling on the HIP key kernel + torch unique / index_reduce (plumbing), neighbourhood memo.
+"""
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------ frames
+def quaternion_to_matrix(q: torch.Tensor) -> torch.Tensor:
+    """Real-part-first quaternions -> rotation matrices (pc/RotationFunctions.py:57-88)."""
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    m = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return m.reshape(q.shape[:-1] + (3, 3))
+
+
+def sample_reference_frames(n_origins: int, n_frames: int, axis_fixed=None, dtype=None, device=None) -> torch.Tensor:
+    """Random frames ``[n_origins, n_frames, 9]`` (pc/RotationFunctions.py:428-508).  Note the
+    reference treats ``axis_fixed = 0`` as "not fixed" (``not axis_fixed``); kept."""
+    n = n_origins * n_frames
+    if axis_fixed is None or not axis_fixed:
+        o = torch.randn((n, 4), dtype=dtype, device=device)
+        s = (o * o).sum(1)
+        sign = torch.where(o[:, 0] < 0, -torch.ones_like(s), torch.ones_like(s))
+        o = o / (torch.sqrt(s) * sign)[:, None]
+        return quaternion_to_matrix(o).reshape(n_origins, n_frames, 9)
+    ang = torch.rand(n, device=device) * 2 * math.pi
+    c, s, z, o = torch.cos(ang), torch.sin(ang), torch.zeros_like(ang), torch.ones_like(ang)
+    if axis_fixed == 1:
+        rows = (c, z, s, z, o, z, -s, z, c)
+    elif axis_fixed == 2:
+        rows = (c, -s, z, s, c, z, z, z, o)
+    else:
+        raise ValueError(f"axis_fixed = {axis_fixed}")
+    return torch.stack(rows, -1).reshape(n_origins, n_frames, 9)
+
+
+# ------------------------------------------------------------------------------------------ clouds
+class Pointcloud(object):
+    def __init__(self, p_pts, p_batch_ids, **kwargs):
+        self.pts_with_grads_ = bool(kwargs.pop("requires_grad", False))
+        self.pts_ = torch.as_tensor(p_pts, **kwargs)
+        self.batch_ids_ = torch.as_tensor(p_batch_ids, **kwargs)
+        self.batch_size_ = torch.max(self.batch_ids_) + 1
+        if self.pts_with_grads_:
+            self.pts_.requires_grad = True
+
+    def to_device(self, p_device):
+        self.pts_ = self.pts_.to(p_device)
+        self.batch_ids_ = self.batch_ids_.to(p_device)
+        self.batch_size_ = self.batch_size_.to(p_device)
+
+
+class PointcloudRotEquiv(Pointcloud):
+    """Point cloud with ``n_frames`` SO(3) reference frames per point."""
+
+    def __init__(self, p_pts, p_batch_ids, p_ref_frames_config, ref_frames_pts=None, standard_knn=False, **kwargs):
+        super().__init__(p_pts, p_batch_ids, **kwargs)
+        self.local_frames_config_ = p_ref_frames_config
+        self.ref_frames_pts = ref_frames_pts
+        frames = self.get_local_ref_frames()
+        self.n_frames_ = frames.shape[1]
+        self.local_frames_ = torch.as_tensor(frames, **kwargs)
+        self.batch_ids_considering_frames_ = self.batch_ids_.repeat_interleave(self.n_frames_)
+
+    def get_local_ref_frames(self):
+        cfg = self.local_frames_config_
+        if cfg.get("pca", False):
+            raise NotImplementedError("PCA reference frames (kNN + eigh) are scope row f-1; pass frames explicitly "
+                                      "via from_frames() or use pca: False")
+        return sample_reference_frames(self.pts_.shape[0], cfg["n_frames"], axis_fixed=cfg.get("fixed_axis"),
+                                       device=self.pts_.device)
+
+    @classmethod
+    def from_frames(cls, p_pts, p_batch_ids, p_frames, p_ref_frames_config=None):
+        """Cloud with externally supplied frames ``[N,F,9]`` (e.g. PCA frames computed upstream)."""
+        self = cls.__new__(cls)
+        Pointcloud.__init__(self, p_pts, p_batch_ids)
+        self.local_frames_ = torch.as_tensor(p_frames).reshape(self.pts_.shape[0], -1, 9)
+        self.n_frames_ = self.local_frames_.shape[1]
+        self.local_frames_config_ = p_ref_frames_config or {"pca": False, "n_frames": self.n_frames_,
+                                                            "fixed_axis": False}
+        self.ref_frames_pts = None
+        self.batch_ids_considering_frames_ = self.batch_ids_.repeat_interleave(self.n_frames_)
+        return self
+
+    def to_device(self, p_device):
+        super().to_device(p_device)
+        self.local_frames_ = self.local_frames_.to(p_device)
+        self.batch_ids_considering_frames_ = self.batch_ids_considering_frames_.to(p_device)
+
+    def feature_pooling(self, p_in_tensor, p_pooling_method="avg"):
+        """Pool the F per-frame feature rows of every point (pc/PointcloudRotEquiv.py:224-251)."""
+        x = p_in_tensor.reshape(self.pts_.shape[0], self.n_frames_, -1)
+        if p_pooling_method == "avg":
+            return x.mean(1)
+        if p_pooling_method == "max":
+            return x.max(1)[0]
+        if p_pooling_method == "min":
+            return x.min(1)[0]
+        if p_pooling_method == "sum":
+            return x.sum(1)
+        raise ValueError(p_pooling_method)
+
+
+# ----------------------------------------------------------------------------------- neighbourhoods
+class Neighborhood(ABC):
+    def __init__(self, p_pc_src, p_samples):
+        self.pc_src_ = p_pc_src
+        self.samples_ = p_samples
+        self.neighbors_ = None
+        self.start_ids_ = None
+        self.__compute_neighborhood__()
+
+    @abstractmethod
+    def __compute_neighborhood__(self):
+        pass
+
+
+class BQNeighborhood(Neighborhood):
+    """Ball-query neighbourhood: ``neighbors_ [E,2]`` (col0 sample, col1 source) int64 like the
+    reference, ``start_ids_ [M]`` = inclusive end offsets, ``radius_``."""
+
+    def __init__(self, p_pc_src, p_samples, p_radius, p_max_neighbors=0):
+        self.radius_ = p_radius
+        self.max_neighbors_ = p_max_neighbors
+        super().__init__(p_pc_src, p_samples)
+
+    def __compute_neighborhood__(self):
+        self.neighbors_, self.start_ids_ = ops.BallQuery.apply(
+            self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_, self.samples_.batch_ids_,
+            self.radius_, self.max_neighbors_)
+
+
+# --------------------------------------------------------------------------------------- hierarchy
+class GridSubSample(object):
+    """Grid-average sub-sampling (pc/GridSubSample.py, pc/Grid.py, pc/BoundingBox.py)."""
+
+    def __init__(self, p_pc_src, p_cell_size):
+        self.pc_src_ = p_pc_src
+        self.cell_size_ = p_cell_size
+        pts, bid = p_pc_src.pts_, p_pc_src.batch_ids_.to(torch.int64)
+        nb = int(p_pc_src.batch_size_)
+        idx3 = bid[:, None].expand(-1, 3)
+        mn = torch.full((nb, 3), float("inf"), dtype=pts.dtype, device=pts.device).scatter_reduce(0, idx3, pts, "amin") - 1e-6
+        mx = torch.full((nb, 3), float("-inf"), dtype=pts.dtype, device=pts.device).scatter_reduce(0, idx3, pts, "amax") + 1e-6
+        self.num_cells_ = (((mx - mn) / p_cell_size).to(torch.int32) + 1).max(dim=0)[0]
+        keys = ops.ComputeKeys.apply(pts, p_pc_src.batch_ids_, mn, self.num_cells_,
+                                     torch.full((3,), p_cell_size, dtype=torch.float32, device=pts.device))
+        _, self.cell_ids_ = torch.unique(keys, return_inverse=True)
+        self.num_out_ = int(self.cell_ids_.max().item()) + 1 if keys.numel() else 0
+
+    def __subsample_tensor__(self, p_tensor, p_method="avg"):
+        idx = self.cell_ids_
+        if p_tensor.dim() > 1:
+            idx = idx.reshape((-1,) + (1,) * (p_tensor.dim() - 1)).expand_as(p_tensor)
+        out = torch.zeros((self.num_out_,) + tuple(p_tensor.shape[1:]), dtype=p_tensor.dtype, device=p_tensor.device)
+        if p_method == "avg":
+            return out.scatter_reduce(0, idx, p_tensor, "mean", include_self=False)
+        if p_method == "max":
+            return out.scatter_reduce(0, idx, p_tensor, "amax", include_self=False)
+        raise ValueError(p_method)
+
+    def __upsample_tensor__(self, p_tensor):
+        return p_tensor[self.cell_ids_]
+
+
+class PointHierarchy(object):
+    def __init__(self, p_point_cloud, p_num_sub_samples, p_subsample_method="grid_avg", **kwargs):
+        if p_subsample_method != "grid_avg":
+            raise NotImplementedError("only grid_avg sub-sampling is implemented (the *_rot task scripts use it)")
+        self.sub_sampled_objs_ = []
+        self.pcs_ = [p_point_cloud]
+        cur = p_point_cloud
+        for i in range(p_num_sub_samples):
+            new_pc, samp = self.__create_sub_sample__(cur, p_subsample_method, i, **kwargs)
+            self.sub_sampled_objs_.append(samp)
+            self.pcs_.append(new_pc)
+            cur = new_pc
+        self.neigh_cache_ = {}
+
+    def __create_sub_sample__(self, p_point_cloud, p_samp_method, p_id, **kwargs):
+        samp = GridSubSample(p_point_cloud, kwargs["grid_radii"][p_id])
+        new_pts = samp.__subsample_tensor__(p_point_cloud.pts_, "avg")
+        new_bid = samp.__subsample_tensor__(p_point_cloud.batch_ids_, "max")
+        return Pointcloud(new_pts, new_bid), samp
+
+    def create_neighborhood(self, p_pc_src_id, p_pc_dest_id, p_neigh_method, **kwargs):
+        if p_neigh_method != "ball_query":
+            raise NotImplementedError("only ball_query neighbourhoods are on the accelerated path")
+        key = f"{p_pc_src_id}_{p_pc_dest_id}_{p_neigh_method}{kwargs['bq_radius']}"
+        if key not in self.neigh_cache_:
+            self.neigh_cache_[key] = BQNeighborhood(self.pcs_[p_pc_src_id], self.pcs_[p_pc_dest_id],
+                                                    kwargs["bq_radius"])
+        return self.neigh_cache_[key]
+
+    def clear_neigh_cache(self):
+        self.neigh_cache_ = {}
+
+    def pool_tensor(self, p_tensor, p_pc_src_id, p_pc_dest_id, p_pool_method):
+        assert p_pc_dest_id - p_pc_src_id == 1
+        return self.sub_sampled_objs_[p_pc_src_id].__subsample_tensor__(p_tensor, p_pool_method)
+
+    def upsample_tensor(self, p_tensor, p_pc_src_id, p_pc_dest_id):
+        assert p_pc_src_id - p_pc_dest_id == 1
+        return self.sub_sampled_objs_[p_pc_dest_id].__upsample_tensor__(p_tensor)
+
+
+class PointHierarchyRotEquiv(PointHierarchy):
+    """Every level gets its own freshly sampled frames (pc/PointHierarchyRotEquiv.py:31-44)."""
+
+    def __create_sub_sample__(self, p_point_cloud, p_samp_method, p_id, **kwargs):
+        samp = GridSubSample(p_point_cloud, kwargs["grid_radii"][p_id])
+        new_pts = samp.__subsample_tensor__(p_point_cloud.pts_, "avg")
+        new_bid = samp.__subsample_tensor__(p_point_cloud.batch_ids_, "max")
+        return PointcloudRotEquiv(new_pts, new_bid, p_point_cloud.local_frames_config_), samp

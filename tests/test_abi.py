@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/se3conv.h declares.
+No compute entry point is called here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "se3conv.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(se3\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    for must in ["se3conv_fwd", "se3conv_bwd", "se3_ball_query_count", "se3_ball_query_store", "se3_feat_basis_proj",
+                 "se3_feat_basis_proj_grad", "se3_compute_keys", "se3_rot_tensors", "se3_csr_transpose"]:
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    from se3conv3d_amd import _lib
+
+    lib = C.CDLL(built_library)
+    syms = declared_symbols()
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in se3conv.h but not exported"
+    assert _lib.load().se3_abi_version() == 1
+
+
+def test_host_side_argument_checks(built_library):
+    from se3conv3d_amd import _lib
+
+    lib = _lib.load()
+    null = C.c_void_p(0)
+    assert lib.se3_compute_keys(null, null, null, null, null, -1, null, null) == -1
+    assert lib.se3_compute_keys(null, null, null, null, null, 4, null, null) == -1
+    assert lib.se3_ball_query_count(null, null, null, null, null, null, 0.0, 1, 1, null, 0, null, null) == -1
+    bad = _lib.Se3Shape(10, 10, 10, 0, 1, 8, 8, 32)  # f_in = 0
+    assert lib.se3conv_fwd_workspace_bytes(C.byref(bad), 1) == 0
+    k16 = _lib.Se3Shape(10, 10, 10, 1, 1, 8, 8, 16)  # K != 32 -> unsupported by the MFMA kernels
+    args = [null] * 12 + [C.byref(k16), null, null, null, 0, null]
+    assert lib.se3conv_fwd(*args) == -2
+    assert lib.se3_feat_basis_proj(null, null, null, null, 0, 0, 0, 8, 12, null, null) == -2
+    assert b"workspace" in lib.se3_error_string(-3)
+    ok = _lib.Se3Shape(1000, 1000, 16000, 2, 2, 64, 64, 32)
+    assert lib.se3conv_fwd_workspace_bytes(C.byref(ok), 0) > 1000 * 2 * 64 * 32 * 4
+    assert lib.se3conv_bwd_workspace_bytes(C.byref(ok), 1, 1, 1) > 0
+    assert lib.se3_ball_query_workspace_bytes(1000, 1000) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from se3conv3d_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.Se3LibraryError):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected(built_library):
+    """The product path has no CPU fallback: CPU tensors raise instead of being computed elsewhere."""
+    import torch
+
+    from se3conv3d_amd import ops
+
+    pts = torch.rand(8, 3)
+    bid = torch.zeros(8, dtype=torch.int32)
+    with pytest.raises(ValueError):
+        ops.ball_query(pts, pts, bid, bid, 0.5)
+
+
+def test_no_product_import_of_oracle():
+    """Nothing under se3conv3d_amd/ may import the oracle (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, "se3conv3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("CPU oracle", ""), f

@@ -1,0 +1,328 @@
+"""GPU: the HIP path (through the C ABI / module interface) against the oracle and the golden fixtures.
+
+Tolerances (||d||_2 / ||ref||_2 per tensor): the north star allows 1e-4; the fp32-MFMA path is exact
+fp32 arithmetic with a different summation order, so the tests hold it to 2e-5.
+Integer results (edges, ends, keys, transposed lists) are compared bit-exactly (as sets per sample
+where the reference leaves the order undefined).
+"""
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, canon_edges, golden_layer_files, load_npz, rel_err
+from oracle import se3conv_oracle as O
+
+pytestmark = pytest.mark.gpu
+FILES = golden_layer_files()
+TOL = 2e-5
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def amd(built_library):
+    import se3conv3d_amd
+
+    return se3conv3d_amd
+
+
+def clouds_from(d, amd):
+    pc_in = amd.pc.PointcloudRotEquiv.from_frames(d["pts_in"].to(DEV), d["batch_in"].to(DEV), d["frames_in"].to(DEV))
+    same = d["pts_in"].shape == d["pts_out"].shape and torch.equal(d["pts_in"], d["pts_out"]) \
+        and torch.equal(d["frames_in"], d["frames_out"])
+    pc_out = pc_in if same else amd.pc.PointcloudRotEquiv.from_frames(
+        d["pts_out"].to(DEV), d["batch_out"].to(DEV), d["frames_out"].to(DEV))
+    return pc_in, pc_out
+
+
+def layer_from(d, amd):
+    c_in, kb, c_out = d["conv_weights"].shape
+    conv = amd.PNEConvLayerRotEquivFactory(9, kb, "mlp_gelu").create_conv_layer(c_in, c_out)
+    conv.load_state_dict({"proj_axes_": d["proj_axes"], "proj_biases_": d["proj_biases"],
+                          "conv_weights_": d["conv_weights"], "norm_neigh_dist_": d["rho"],
+                          "norm_num_neighs_": d["nu"]})
+    return conv.to(DEV)
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_ball_query_matches_golden(path, amd):
+    d = load_npz(path)
+    pc_in, pc_out = clouds_from(d, amd)
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, float(d["radius"]))
+    assert nbh.neighbors_.dtype == torch.int64 and nbh.start_ids_.dtype == torch.int32
+    assert torch.equal(nbh.start_ids_.cpu(), d["ends"])
+    assert torch.equal(canon_edges(nbh.neighbors_), canon_edges(d["neighbors"]))
+    # grouped by sample
+    assert bool((nbh.neighbors_[1:, 0] >= nbh.neighbors_[:-1, 0]).all())
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_layer_forward_backward_matches_golden(path, amd):
+    d = load_npz(path)
+    pc_in, pc_out = clouds_from(d, amd)
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, float(d["radius"]))
+    conv = layer_from(d, amd)
+    x = d["x"].to(DEV).requires_grad_(True)
+    amd.PNEConvLayerRotEquiv.empty_rot_tenors_cache()
+    out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=nbh)
+    assert out.shape == d["out"].shape and out.dtype == torch.float32 and out.is_cuda
+    out.backward(d["grad_out"].to(DEV))
+    assert rel_err(out, d["out"]) < TOL
+    assert rel_err(x.grad, d["dx"]) < TOL
+    assert rel_err(conv.proj_axes_.grad, d["dA"]) < TOL
+    assert rel_err(conv.proj_biases_.grad, d["dbeta"]) < TOL
+    assert rel_err(conv.conv_weights_.grad, d["dW"]) < TOL
+
+
+@pytest.mark.parametrize("path", FILES[:4], ids=[os.path.basename(f) for f in FILES[:4]])
+def test_rot_tensors_and_feat_basis_proj_api(path, amd):
+    """API-parity ops: get_rot_tenors materialised + FeatBasisProj fwd/bwd reproduce the layer."""
+    d = load_npz(path)
+    pc_in, pc_out = clouds_from(d, amd)
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, float(d["radius"]))
+    rt = amd.PNEConvLayerRotEquiv.get_rot_tenors(pc_in, pc_out, nbh, d["rho"].to(DEV))
+    assert torch.equal(rt["neighbs_start_ids"].cpu(), d["rt_ends"])
+    ref_nb, nb = d["rt_neighbs"].long(), rt["neighbs"].cpu()
+    big = int(max(ref_nb[:, 1].max(), nb[:, 1].max())) + 1
+    o_ref, o_new = torch.argsort(ref_nb[:, 0] * big + ref_nb[:, 1]), torch.argsort(nb[:, 0] * big + nb[:, 1])
+    assert torch.equal(ref_nb[o_ref], nb[o_new])
+    assert rel_err(rt["rel_pts_rel_orient"].cpu()[o_new], d["rt_desc"][o_ref]) < TOL
+
+    a, b, w = d["proj_axes"].to(DEV), d["proj_biases"].to(DEV), d["conv_weights"].to(DEV)
+    phi = torch.nn.functional.gelu(rt["rel_pts_rel_orient"] @ a + b).requires_grad_(True)
+    x = d["x"].to(DEV).requires_grad_(True)
+    t = amd.FeatBasisProj.apply(phi, x, rt["neighbs"], rt["neighbs_start_ids"])
+    out = torch.einsum("nik,iko->no", t, w) / pc_in.n_frames_ * d["nu"].to(DEV)
+    assert rel_err(out, d["out"]) < TOL
+    out.backward(d["grad_out"].to(DEV))
+    assert rel_err(x.grad, d["dx"]) < TOL
+    # gBasis against the oracle's restatement of feat_basis_proj_grads.cu
+    g_t = torch.einsum("no,iko->nik", d["grad_out"], d["conv_weights"]) / pc_in.n_frames_ * d["nu"]
+    _, g_basis = O.feat_basis_proj_grad(phi.detach().cpu(), d["x"], rt["neighbs"].cpu(), rt["neighbs_start_ids"].cpu(), g_t)
+    assert rel_err(phi.grad, g_basis) < TOL
+
+
+def random_case(seed, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches=1):
+    g = torch.Generator().manual_seed(seed)
+    pts_in = torch.rand(n_in, 3, generator=g)
+    bid_in = torch.sort(torch.randint(0, batches, (n_in,), generator=g, dtype=torch.int32)).values
+    if n_out is None:
+        pts_out, bid_out = pts_in, bid_in
+    else:
+        pts_out = torch.rand(n_out, 3, generator=g)
+        bid_out = torch.sort(torch.randint(0, batches, (n_out,), generator=g, dtype=torch.int32)).values
+    fi = O.random_frames(n_in, f_in, g)
+    fo = fi if (n_out is None and f_in == f_out) else O.random_frames(pts_out.shape[0], f_out, g)
+    r = O.radius_for_degree(n_in / batches, k_deg)
+    a, b, w = O.init_parameters(9, c_in, c_out, 32, g)
+    b = (torch.rand(32, generator=g) - 0.5)
+    x = torch.randn(n_in * f_in, c_in, generator=g)
+    go = torch.randn(pts_out.shape[0] * f_out, c_out, generator=g)
+    return dict(pts_in=pts_in, pts_out=pts_out, bid_in=bid_in, bid_out=bid_out, fi=fi, fo=fo, r=r, a=a, b=b, w=w, x=x, go=go)
+
+
+CASES = [
+    # seed n_in  n_out F_in F_out C_in C_out k   batches     what it stresses
+    (11, 700, None, 2, 2, 64, 64, 40, 1),     # degree > 32: several 32-edge chunks per row
+    (12, 600, 300, 1, 4, 32, 96, 20, 3),      # F_in != F_out, 3 batches, C_out = 96 (not a multiple of 64)
+    (13, 500, 250, 4, 1, 128, 32, 10, 2),     # C_in = 128 (float4 gather), F_out = 1
+    (14, 400, None, 2, 2, 96, 48, 16, 1),     # C_in = 96: three passes of the 32-channel tile
+    (15, 300, 500, 2, 2, 3, 13, 6, 1),        # odd channel counts (ScanNet colours -> classes)
+    (16, 256, None, 3, 3, 32, 32, 8, 1),      # F = 3 (not a power of two)
+    (17, 2000, None, 2, 2, 64, 64, 70, 1),    # very dense: ~70 neighbours, 5 chunks
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"seed{c[0]}" for c in CASES])
+def test_random_shapes_against_oracle(case, amd):
+    seed, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches = case
+    c = random_case(seed, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches)
+    nb_ref, ends_ref = O.ball_query(c["pts_in"], c["pts_out"], c["bid_in"], c["bid_out"], c["r"])
+    nb, ends = amd.ops.ball_query(c["pts_in"].to(DEV), c["pts_out"].to(DEV), c["bid_in"].to(DEV), c["bid_out"].to(DEV), c["r"])
+    assert torch.equal(ends.cpu(), ends_ref)
+    assert torch.equal(canon_edges(nb), canon_edges(nb_ref))
+
+    rho, nu = torch.tensor(1.0 / c["r"]), torch.tensor(ends_ref.shape[0] / max(nb_ref.shape[0], 1))
+    out_r, dx_r, da_r, db_r, dw_r = O.conv_forward_backward(c["pts_in"], c["pts_out"], c["fi"], c["fo"], nb_ref, c["x"],
+                                                           c["a"], c["b"], c["w"], rho, nu, c["go"])
+    geom = amd.ops.ConvGeometry.build(c["pts_in"].to(DEV), c["pts_out"].to(DEV), c["fi"].to(DEV), c["fo"].to(DEV), nb, ends)
+    x = c["x"].to(DEV).requires_grad_(True)
+    a, b, w = (c[k].to(DEV).requires_grad_(True) for k in ("a", "b", "w"))
+    out = amd.SE3ConvFunction.apply(x, a, b, w, geom, rho, nu)
+    out.backward(c["go"].to(DEV))
+    assert rel_err(out, out_r) < TOL
+    assert rel_err(x.grad, dx_r) < TOL
+    assert rel_err(a.grad, da_r) < TOL
+    assert rel_err(b.grad, db_r) < TOL
+    assert rel_err(w.grad, dw_r) < TOL
+
+    # the source-major edge list is a permutation of the edges, grouped by source, samples ascending
+    ts, te = geom.transpose()
+    ts, te = ts.cpu().long(), te.cpu().long()
+    deg_in = torch.bincount(nb_ref[:, 1], minlength=c["pts_in"].shape[0])
+    assert torch.equal(te, torch.cumsum(deg_in, 0))
+    srcs = torch.repeat_interleave(torch.arange(c["pts_in"].shape[0]), deg_in)
+    assert torch.equal(canon_edges(torch.stack((ts, srcs), 1)), canon_edges(nb_ref))
+
+
+def test_features_only_backward_and_frozen_params(amd):
+    """needs_input_grad combinations: only dX (frozen layer) and only parameter grads."""
+    c = random_case(21, 300, None, 2, 2, 32, 32, 12)
+    nb, ends = amd.ops.ball_query(c["pts_in"].to(DEV), c["pts_out"].to(DEV), c["bid_in"].to(DEV), c["bid_out"].to(DEV), c["r"])
+    rho, nu = torch.tensor(1.0 / c["r"]), torch.tensor(0.07)
+    out_r, dx_r, da_r, db_r, dw_r = O.conv_forward_backward(c["pts_in"], c["pts_out"], c["fi"], c["fo"], nb.cpu().long(),
+                                                           c["x"], c["a"], c["b"], c["w"], rho, nu, c["go"])
+    geom = amd.ops.ConvGeometry.build(c["pts_in"].to(DEV), c["pts_out"].to(DEV), c["fi"].to(DEV), c["fo"].to(DEV), nb, ends)
+    x = c["x"].to(DEV).requires_grad_(True)
+    out = amd.SE3ConvFunction.apply(x, c["a"].to(DEV), c["b"].to(DEV), c["w"].to(DEV), geom, rho, nu)
+    out.backward(c["go"].to(DEV))
+    assert rel_err(x.grad, dx_r) < TOL
+    w = c["w"].to(DEV).requires_grad_(True)
+    out = amd.SE3ConvFunction.apply(c["x"].to(DEV), c["a"].to(DEV), c["b"].to(DEV), w, geom, rho, nu)
+    out.backward(c["go"].to(DEV))
+    assert rel_err(w.grad, dw_r) < TOL
+
+
+def test_empty_rows_and_empty_graph(amd):
+    """Samples without any neighbour give zero rows (and the output keeps N_out*F_out rows: the
+    reference would drop trailing ones, PNEConvLayerRotEquiv.py:111-114)."""
+    g = torch.Generator().manual_seed(3)
+    pts_in = torch.rand(64, 3, generator=g)
+    pts_out = torch.cat((torch.rand(30, 3, generator=g), torch.full((3, 3), 7.0)))
+    z_in, z_out = torch.zeros(64, dtype=torch.int32), torch.zeros(33, dtype=torch.int32)
+    fi, fo = O.random_frames(64, 2, g), O.random_frames(33, 2, g)
+    a, b, w = O.init_parameters(9, 32, 32, 32, g)
+    x = torch.randn(128, 32, generator=g)
+    nb, ends = amd.ops.ball_query(pts_in.to(DEV), pts_out.to(DEV), z_in.to(DEV), z_out.to(DEV), 0.3)
+    nb_r, ends_r = O.ball_query(pts_in, pts_out, z_in, z_out, 0.3)
+    assert torch.equal(ends.cpu(), ends_r) and int(ends_r[-1]) == int(ends_r[-4])
+    geom = amd.ops.ConvGeometry.build(pts_in.to(DEV), pts_out.to(DEV), fi.to(DEV), fo.to(DEV), nb, ends)
+    out, _ = amd.ops.se3conv_forward(geom, x.to(DEV), a.to(DEV), b.to(DEV), w.to(DEV), 3.0, 0.1)
+    ref = O.conv_forward(pts_in, pts_out, fi, fo, nb_r, x, a, b, w, torch.tensor(3.0), torch.tensor(0.1))
+    assert out.shape == (66, 32) and float(out[-6:].abs().max()) == 0.0
+    assert rel_err(out, ref) < TOL
+    # radius so small that only self-edges exist for a different output cloud: E = 0
+    nb0, ends0 = amd.ops.ball_query(pts_in.to(DEV), pts_out.to(DEV), z_in.to(DEV), z_out.to(DEV), 1e-4)
+    assert nb0.shape == (0, 2) and int(ends0.sum()) == 0
+    geom0 = amd.ops.ConvGeometry.build(pts_in.to(DEV), pts_out.to(DEV), fi.to(DEV), fo.to(DEV), nb0, ends0)
+    out0, _ = amd.ops.se3conv_forward(geom0, x.to(DEV), a.to(DEV), b.to(DEV), w.to(DEV), 3.0, 0.1)
+    assert float(out0.abs().max()) == 0.0
+
+
+def test_compute_keys_bit_exact(amd):
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(5000, 3, generator=g) * torch.tensor([2.0, 1.0, 0.5])
+    bid = torch.sort(torch.randint(0, 4, (5000,), generator=g, dtype=torch.int32)).values
+    mn, nc = O.ball_query_grid_params(pts, bid, 0.07)
+    cs = torch.full((3,), 0.07)
+    ref = O.compute_keys(pts, bid, mn, nc, cs)
+    got = amd.ops.compute_keys(pts.to(DEV), bid.to(DEV), mn.to(DEV), nc.to(DEV), cs.to(DEV))
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref)
+
+
+def test_ema_preprocess_matches_golden(amd):
+    d = load_npz(os.path.join(GOLDEN, "layer_n256_f2_c64.npz"))
+    pc_in, pc_out = clouds_from(d, amd)
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, float(d["radius"]))
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(64, 64).to(DEV)
+    conv.start_pre_process()
+    with torch.no_grad():
+        for step in range(d["ema"].shape[0]):
+            conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=d["x"].to(DEV), p_neighborhood=nbh)
+            assert math.isclose(float(conv.norm_neigh_dist_), float(d["ema"][step, 0]), rel_tol=1e-6)
+            assert math.isclose(float(conv.norm_num_neighs_), float(d["ema"][step, 1]), rel_tol=1e-6)
+    conv.end_pre_process()
+    assert not conv.pre_process_
+
+
+# ---- full-size, size-independent properties (BASELINE.json headline shape: N=64k, k=32, F=2, C=64) ----
+@pytest.fixture(scope="module")
+def headline(amd):
+    torch.manual_seed(0)
+    n, f, c = 65536, 2, 64
+    pts = torch.rand(n, 3, device=DEV)
+    bid = torch.zeros(n, dtype=torch.int32, device=DEV)
+    pc = amd.pc.PointcloudRotEquiv(pts, bid, {"pca": False, "n_frames": f, "fixed_axis": False})
+    r = O.radius_for_degree(n, 32)
+    nbh = amd.pc.BQNeighborhood(pc, pc, r)
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c, c).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r)
+    conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / nbh.neighbors_.shape[0])
+    with torch.no_grad():
+        conv.proj_biases_.uniform_(-0.5, 0.5)
+    x = torch.randn(n * f, c, device=DEV)
+    return pc, nbh, conv, x, r
+
+
+def test_headline_graph_properties(headline, amd):
+    pc, nbh, conv, x, r = headline
+    nb, ends = nbh.neighbors_, nbh.start_ids_.long()
+    n = pc.pts_.shape[0]
+    assert int(ends[-1]) == nb.shape[0] and bool((ends[1:] >= ends[:-1]).all())
+    mean_deg = nb.shape[0] / n
+    assert 24 < mean_deg < 33  # interior estimate 32, boundary effects lower it
+    # every edge satisfies the predicate, every point is its own neighbour, graph is symmetric
+    d = (pc.pts_[nb[:, 0]] - pc.pts_[nb[:, 1]]) * (1.0 / r)
+    assert bool(((d * d).sum(1).sqrt() < 1.0 + 1e-6).all())
+    assert int((nb[:, 0] == nb[:, 1]).sum()) == n
+    fwd = nb[:, 0] * n + nb[:, 1]
+    bwd = nb[:, 1] * n + nb[:, 0]
+    assert torch.equal(torch.sort(fwd).values, torch.sort(bwd).values)
+    assert torch.equal(torch.bincount(nb[:, 0], minlength=n).cumsum(0), ends)
+    # a random subset of samples against brute force on the GPU (exact edge sets)
+    idx = torch.randperm(n, device=DEV)[:512]
+    dd = (pc.pts_[idx][:, None, :] - pc.pts_[None, :, :]) * torch.tensor(1.0 / r, dtype=torch.float32)
+    hit = (dd[..., 0] * dd[..., 0] + dd[..., 1] * dd[..., 1] + dd[..., 2] * dd[..., 2]).sqrt() < 1.0
+    cnt = hit.sum(1)
+    start = torch.cat((ends.new_zeros(1), ends[:-1]))
+    assert torch.equal(cnt, (ends - start)[idx])
+
+
+def test_headline_rotation_invariance_and_linearity(headline, amd):
+    """Joint rotation of points and frames leaves the output unchanged (SE(3) equivariance with
+    frame-relative features, cf. random_rotate in pc/RotationFunctions.py:412-425); the operator is
+    linear in the features and gradients are consistent with that linearity."""
+    pc, nbh, conv, x, r = headline
+    with torch.no_grad():
+        out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
+        assert out.shape == (x.shape[0], 64) and bool(torch.isfinite(out).all())
+        rot = O.quaternion_to_matrix(torch.nn.functional.normalize(torch.randn(4), dim=0)).to(DEV)
+        pts_r = pc.pts_ @ rot.t()
+        frames_r = torch.einsum("nm,ijml->ijnl", rot, pc.local_frames_.reshape(-1, 2, 3, 3)).reshape(-1, 2, 9)
+        pc_r = amd.pc.PointcloudRotEquiv.from_frames(pts_r, pc.batch_ids_, frames_r)
+        nbh_r = amd.pc.BQNeighborhood.__new__(amd.pc.BQNeighborhood)  # same graph: distances are preserved
+        nbh_r.neighbors_, nbh_r.start_ids_, nbh_r.radius_ = nbh.neighbors_, nbh.start_ids_, nbh.radius_
+        out_r = conv(p_pc_in=pc_r, p_pc_out=pc_r, p_in_features=x, p_neighborhood=nbh_r)
+        assert rel_err(out_r, out) < 2e-5
+        x2 = torch.randn_like(x)
+        lin = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=2.0 * x - 0.5 * x2, p_neighborhood=nbh)
+        out2 = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x2, p_neighborhood=nbh)
+        assert rel_err(lin, 2.0 * out - 0.5 * out2) < 2e-5
+    # adjoint identity <conv(x), g> == <x, conv^T(g)> ties backward to forward at full size
+    xg = x.clone().requires_grad_(True)
+    o = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=xg, p_neighborhood=nbh)
+    g = torch.randn_like(o)
+    o.backward(g)
+    lhs = float((o.detach().double() * g.double()).sum())
+    rhs = float((x.double() * xg.grad.double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
+    # Euler identity for the weights: out is linear in W  =>  <W, dW> == <out, g>
+    wdot = float((conv.conv_weights_.detach().double() * conv.conv_weights_.grad.double()).sum())
+    assert abs(wdot - lhs) <= 2e-5 * max(abs(lhs), 1.0)
+
+
+def test_headline_subset_against_oracle(headline, amd):
+    """Rows of the full-size output against the oracle evaluated on those rows' neighbourhoods."""
+    pc, nbh, conv, x, r = headline
+    with torch.no_grad():
+        out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
+    ends = nbh.start_ids_.long().cpu()
+    sel = torch.arange(1000, 1064)
+    e0, e1 = int(ends[sel[0] - 1]), int(ends[sel[-1]])
+    nb = nbh.neighbors_[e0:e1].cpu().clone()
+    nb[:, 0] -= int(sel[0])
+    ref = O.conv_forward(pc.pts_.cpu(), pc.pts_[sel].cpu(), pc.local_frames_.cpu(), pc.local_frames_[sel].cpu(), nb,
+                         x.cpu(), conv.proj_axes_.detach().cpu(), conv.proj_biases_.detach().cpu(),
+                         conv.conv_weights_.detach().cpu(), conv.norm_neigh_dist_.cpu(), conv.norm_num_neighs_.cpu())
+    assert rel_err(out[int(sel[0]) * 2:(int(sel[-1]) + 1) * 2], ref) < TOL

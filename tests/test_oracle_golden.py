@@ -1,0 +1,131 @@
+"""CPU: the oracle against the fixtures generated from the reference's Python (tools/gen_golden.py)."""
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, canon_edges, golden_layer_files, load_npz, rel_err
+from oracle import se3conv_oracle as O
+
+FILES = golden_layer_files()
+TOL = 2e-6  # fp32 CPU restatement vs reference Python, ||d||/||ref||
+
+
+def test_fixtures_present():
+    assert len(FILES) >= 7
+    assert os.path.exists(os.path.join(GOLDEN, "rotation_fns.npz"))
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_layer_forward_backward_matches_reference(path):
+    d = load_npz(path)
+    out, dx, da, db, dw = O.conv_forward_backward(
+        d["pts_in"], d["pts_out"], d["frames_in"], d["frames_out"], d["neighbors"].long(), d["x"],
+        d["proj_axes"], d["proj_biases"], d["conv_weights"], d["rho"], d["nu"], d["grad_out"])
+    assert out.shape == d["out"].shape
+    assert rel_err(out, d["out"]) < TOL
+    assert rel_err(dx, d["dx"]) < TOL
+    assert rel_err(da, d["dA"]) < TOL
+    assert rel_err(db, d["dbeta"]) < TOL
+    assert rel_err(dw, d["dW"]) < TOL
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_fp64_oracle_agrees(path):
+    """The fp64 evaluation of the same formula bounds the fp32 reference's own rounding."""
+    d = load_npz(path)
+    out, dx, da, db, dw = O.conv_forward_backward(
+        d["pts_in"], d["pts_out"], d["frames_in"], d["frames_out"], d["neighbors"].long(), d["x"],
+        d["proj_axes"], d["proj_biases"], d["conv_weights"], d["rho"], d["nu"], d["grad_out"], dtype=torch.float64)
+    assert rel_err(d["out"], out) < TOL and rel_err(d["dx"], dx) < TOL and rel_err(d["dW"], dw) < TOL
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_rot_tensors_match_reference(path):
+    d = load_npz(path)
+    rt = O.get_rot_tensors(d["pts_in"], d["pts_out"], d["frames_in"], d["frames_out"], d["neighbors"].long(), d["rho"])
+    assert torch.equal(rt["neighbs_start_ids"], d["rt_ends"])
+    # the reference's sort is unstable: compare per output row as multisets keyed by the source row
+    ref_nb, nb = d["rt_neighbs"].long(), rt["neighbs"]
+    assert torch.equal(ref_nb[:, 0], nb[:, 0])
+    big = int(max(ref_nb[:, 1].max(), nb[:, 1].max())) + 1
+    o_ref = torch.argsort(ref_nb[:, 0] * big + ref_nb[:, 1])
+    o_new = torch.argsort(nb[:, 0] * big + nb[:, 1])
+    assert torch.equal(ref_nb[o_ref], nb[o_new])
+    assert rel_err(rt["rel_pts_rel_orient"][o_new], d["rt_desc"][o_ref]) < TOL
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_ball_query_matches_reference_edges(path):
+    d = load_npz(path)
+    nb, ends = O.ball_query(d["pts_in"], d["pts_out"], d["batch_in"], d["batch_out"], float(d["radius"]))
+    assert torch.equal(ends, d["ends"])
+    assert torch.equal(canon_edges(nb), canon_edges(d["neighbors"]))
+
+
+@pytest.mark.parametrize("name", ["layer_down_n512_n128_f2.npz", "layer_sparse_n200_f2.npz", "layer_n256_f2_c64.npz"])
+def test_grid_search_loses_no_neighbour(name):
+    """The reference's grid windows (3x3 pencils x [z-1,z+1]) give the brute-force edge set."""
+    d = load_npz(os.path.join(GOLDEN, name))
+    nb_g, ends_g = O.ball_query_grid(d["pts_in"], d["pts_out"], d["batch_in"], d["batch_out"], float(d["radius"]))
+    assert torch.equal(ends_g, d["ends"])
+    assert torch.equal(canon_edges(nb_g), canon_edges(d["neighbors"]))
+
+
+@pytest.mark.parametrize("path", FILES[:3], ids=[os.path.basename(f) for f in FILES[:3]])
+def test_feat_basis_proj_and_grad(path):
+    """feat_basis_proj / _grad restatements against autograd of the dense formula."""
+    d = load_npz(path)
+    rt = O.get_rot_tensors(d["pts_in"], d["pts_out"], d["frames_in"], d["frames_out"], d["neighbors"].long(), d["rho"])
+    phi = O.kernel_mlp(rt["rel_pts_rel_orient"], d["proj_axes"], d["proj_biases"]).requires_grad_(True)
+    x = d["x"].clone().requires_grad_(True)
+    t = O.feat_basis_proj(phi, x, rt["neighbs"], rt["neighbs_start_ids"])
+    out = torch.einsum("nik,iko->no", t, d["conv_weights"]) / d["frames_in"].shape[1] * d["nu"]
+    assert rel_err(out, d["out"]) < TOL
+    g = torch.randn_like(t)
+    t.backward(g)
+    g_feat, g_basis = O.feat_basis_proj_grad(phi.detach(), x.detach(), rt["neighbs"], rt["neighbs_start_ids"], g)
+    assert rel_err(g_feat, x.grad) < TOL and rel_err(g_basis, phi.grad) < TOL
+
+
+def test_ema_trajectory():
+    for path in FILES:
+        d = load_npz(path)
+        rho, nu = torch.tensor(0.0), torch.tensor(0.0)
+        for step in range(d["ema"].shape[0]):
+            rho, nu = O.ema_update(rho, nu, float(d["radius"]), d["ends"].shape[0], d["neighbors"].shape[0])
+            assert abs(float(rho) - float(d["ema"][step, 0])) <= 1e-6 * abs(float(d["ema"][step, 0]))
+            assert abs(float(nu) - float(d["ema"][step, 1])) <= 1e-6 * abs(float(d["ema"][step, 1]))
+
+
+def test_rotation_functions():
+    d = load_npz(os.path.join(GOLDEN, "rotation_fns.npz"))
+    fa, fb = d["frames_a"], d["frames_b"]
+    nb = torch.stack((torch.arange(5), torch.arange(5)), 1)
+    desc = O.edge_descriptors(torch.zeros(5, 3) + d["dirs"], torch.zeros(5, 3), fb, fa, nb, torch.tensor(1.0))
+    # descriptor = [dirs @ R_a, rows 0,1 of R_a^T R_b] in pair order a*F_b + b
+    local = d["local"][:, :, None, :].expand(-1, -1, 4, -1).reshape(5, 8, 3)
+    assert rel_err(desc[..., :3], local) < TOL
+    assert rel_err(desc[..., 3:], d["rel6"]) < TOL
+    assert rel_err(d["relmat"][..., :6], d["rel6"]) == 0.0
+    combos = torch.tensor([(a, b) for a in range(2) for b in range(4)])
+    assert torch.equal(combos, d["combos"])
+
+
+def test_dropped_rows_quirk():
+    """pad_rows=False reproduces the reference quirk: trailing output rows without edges vanish."""
+    g = torch.Generator().manual_seed(0)
+    pts_in = torch.rand(50, 3, generator=g)
+    pts_out = torch.cat((torch.rand(20, 3, generator=g), torch.full((2, 3), 9.0)))  # last 2 samples isolated
+    fi, fo = O.random_frames(50, 2, g), O.random_frames(22, 2, g)
+    z = torch.zeros(50, dtype=torch.int32), torch.zeros(22, dtype=torch.int32)
+    nb, ends = O.ball_query(pts_in, pts_out, z[0], z[1], 0.4)
+    a, b, w = O.init_parameters(9, 8, 8, 32, g)
+    x = torch.randn(100, 8, generator=g)
+    full = O.conv_forward(pts_in, pts_out, fi, fo, nb, x, a, b, w, torch.tensor(2.5), torch.tensor(0.1))
+    ref_like = O.conv_forward(pts_in, pts_out, fi, fo, nb, x, a, b, w, torch.tensor(2.5), torch.tensor(0.1), pad_rows=False)
+    assert full.shape[0] == 44 and ref_like.shape[0] < 44
+    assert torch.equal(full[: ref_like.shape[0]], ref_like)
+    assert float(full[ref_like.shape[0]:].abs().max()) == 0.0
+    lean = O.conv_forward_edgewise(pts_in, pts_out, fi, fo, nb, x, a, b, w, torch.tensor(2.5), torch.tensor(0.1))
+    assert rel_err(lean, full) < TOL
