@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the PNEConvLayerRotEquiv hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU; scenes are sharded by rank, the
+     data path has no collective -- only the timing barrier and a MAX all-reduce of the wall time.)
+
+Workload (BASELINE.json metric "Mpoints/sec fwd+bwd PNEConvLayerRotEquiv (N=64k,k=32,F=2)"):
+one synthetic cloud per rank, N0 = 65 536 points ~ U[0,1)^3, F = 2 random frames per point,
+C = 64 -> 64 channels, K = 32 basis functions, radius for mean degree k = 32; a 4-level stack = one
+same-level convolution per level of a grid-subsampled hierarchy (cell doubling, radius = 2 x cell
+like tasks/SemSeg/seg_models.py:29-33).  One step = forward + backward (dX, dA, dbeta, dW) of all
+four levels, neighbourhoods prebuilt ("conv-only").  value = N0 * n_gpus /
+step time.  The JSON line also carries the single full-resolution layer rate, the roofline of the
+dominant kernel (HIP events inside the library, on the launch stream) and a CPU baseline (the
+oracle, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N0, K_DEG, FRAMES, CH, KB = 65536, 32, 2, 64, 32
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec
+
+
+def build_stack(amd, O, device, seed):
+    torch.manual_seed(seed)
+    cfg = {"pca": False, "n_frames": FRAMES, "fixed_axis": False}
+    r0 = O.radius_for_degree(N0, K_DEG)
+    pts = torch.rand(N0, 3, device=device)
+    bid = torch.zeros(N0, dtype=torch.int32, device=device)
+    pc0 = amd.pc.PointcloudRotEquiv(pts, bid, cfg)
+    hier = amd.pc.PointHierarchyRotEquiv(pc0, 3, "grid_avg", grid_radii=[r0, 2 * r0, 4 * r0])
+    radii = [r0, 2 * r0, 4 * r0, 8 * r0]  # radius = 2 x the cell that produced the level
+    factory = amd.PNEConvLayerRotEquivFactory(9, KB, "mlp_gelu")
+    levels = []
+    for lvl, (pc, r) in enumerate(zip(hier.pcs_, radii)):
+        nbh = hier.create_neighborhood(lvl, lvl, "ball_query", bq_radius=r)
+        conv = factory.create_conv_layer(CH, CH).to(device)
+        conv.norm_neigh_dist_.fill_(1.0 / r)
+        conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.neighbors_.shape[0], 1))
+        n = pc.pts_.shape[0]
+        x = torch.randn(n * FRAMES, CH, device=device, requires_grad=True)
+        g = torch.randn(n * FRAMES, CH, device=device)
+        levels.append(dict(pc=pc, nbh=nbh, conv=conv, x=x, g=g, n=n, e=nbh.neighbors_.shape[0], r=r))
+    return levels
+
+
+def step(levels):
+    for lv in levels:
+        lv["x"].grad = None
+        for p in lv["conv"].parameters():
+            p.grad = None
+        out = lv["conv"](p_pc_in=lv["pc"], p_pc_out=lv["pc"], p_in_features=lv["x"], p_neighborhood=lv["nbh"])
+        out.backward(lv["g"])
+
+
+def layer_flops(n, e):
+    """Algorithmic FLOPs per stage of one layer (MLP counted with its bias row)."""
+    ep = e * FRAMES * FRAMES
+    rows = n * FRAMES
+    dense = rows * 2 * CH * KB * CH
+    edge = ep * (2 * 10 * KB + 2 * CH * KB)
+    return {"edge_t_fwd": edge, "gemm_out": dense, "gemm_gradT": dense, "gemm_gradW": dense, "gemm_gradX": dense,
+            "edge_t_transposed": edge, "edge_param_grad": ep * (2 * 10 * KB + 2 * CH * KB + 2 * 10 * KB)}
+
+
+def layer_bytes(n, e):
+    """Algorithmic HBM bytes of one layer fwd+bwd (uncached-gather model of SURVEY.md section 8d:
+    every point-edge touches its neighbour's F_in*C_in block once per pass; no T, nothing E'-sized)."""
+    rows = n * FRAMES
+    geom = 8 * e + 4 * n + 12 * 2 * n + 36 * 2 * rows
+    params = 4 * (10 * KB + CH * KB * CH)
+    fwd = geom + 4 * e * FRAMES * CH + 4 * rows * CH + params
+    bwd = geom + 2 * 4 * e * FRAMES * CH + 4 * rows * CH + 4 * rows * CH + 2 * params
+    return fwd + bwd
+
+
+def profile_level0(lib, lv, reps):
+    lib.se3_profile_reset()
+    lib.se3_profile_enable(1)
+    for _ in range(reps):
+        step([lv])
+    torch.cuda.synchronize()
+    lib.se3_profile_enable(0)
+    buf = C.create_string_buffer(4096)
+    lib.se3_profile_tags(buf, 4096)
+    stages = {}
+    for tag in buf.value.decode().split(","):
+        if not tag:
+            continue
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        lib.se3_profile_read(tag.encode(), C.byref(ms), C.byref(cnt))
+        stages[tag] = (ms.value / max(cnt.value, 1), cnt.value)
+    lib.se3_profile_reset()
+    return stages
+
+
+def cpu_baseline(O):
+    """The oracle (a port of the reference's Python path) on this box's host cores, bounded sample:
+    one layer, same k / F / C / K, N = 4096 points."""
+    n = 4096
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand(n, 3, generator=g)
+    bid = torch.zeros(n, dtype=torch.int32)
+    fr = O.random_frames(n, FRAMES, g)
+    r = O.radius_for_degree(n, K_DEG)
+    nb, ends = O.ball_query(pts, pts, bid, bid, r)
+    a, b, w = O.init_parameters(9, CH, CH, KB, g)
+    x = torch.randn(n * FRAMES, CH, generator=g)
+    go = torch.randn(n * FRAMES, CH, generator=g)
+    rho, nu = torch.tensor(1.0 / r), torch.tensor(n / nb.shape[0])
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.conv_forward_backward(pts, pts, fr, fr, nb, x, a, b, w, rho, nu, go)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": n / best / 1e6, "unit": "Mpoints/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch CPU) single layer fwd+bwd, N={n}, k~{nb.shape[0] / n:.1f}, F={FRAMES}, "
+                      f"C={CH}, K={KB}; best of 2 after 1 warm-up ({best:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import se3conv3d_amd as amd
+    from oracle import se3conv_oracle as O  # cpu_baseline leg + radius helper only
+    from se3conv3d_amd import _lib
+
+    lib = _lib.load()
+    levels = build_stack(amd, O, device, seed=rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt_stack = timed(lambda: step(levels), args.steps, args.warmup)
+    dt_layer = timed(lambda: step(levels[:1]), args.steps, max(1, args.warmup // 2))
+    ms_step = dt_stack / args.steps * 1e3
+    ms_layer = dt_layer / args.steps * 1e3
+
+    stages = profile_level0(lib, levels[0], reps=5)
+    fl = layer_flops(levels[0]["n"], levels[0]["e"])
+    dom = max(stages, key=lambda t: stages[t][0]) if stages else None
+    roofline = None
+    if dom is not None:
+        ach = fl.get(dom, 0) / (stages[dom][0] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(stages[dom][0], 4), "launches": stages[dom][1],
+                    "algorithmic_flops_per_launch": fl.get(dom, 0),
+                    "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}}
+    lb = layer_bytes(levels[0]["n"], levels[0]["e"])
+    hbm = {"algorithmic_bytes_per_layer": lb, "achieved": round(lb / (ms_layer * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS,
+           "unit": "GB/s", "frac": round(lb / (ms_layer * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
+
+    result = {
+        "metric": "Mpoints/sec fwd+bwd PNEConvLayerRotEquiv (N=64k,k=32,F=2)",
+        "value": round(N0 * world / (ms_step * 1e-3) / 1e6, 3),
+        "unit": "Mpoints/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "4-level PNEConvLayerRotEquiv stack, conv-only fwd+bwd (dX,dA,dbeta,dW), one cloud per GPU",
+                   "n_points": N0, "k": K_DEG, "frames": FRAMES, "channels": CH, "num_basis": KB,
+                   "level_points": [lv["n"] for lv in levels], "level_edges": [lv["e"] for lv in levels],
+                   "mean_degree_level0": round(levels[0]["e"] / levels[0]["n"], 2), "sharding": "one scene per rank, no data-path collective"},
+        "single_layer": {"ms_per_step": round(ms_layer, 4), "value": round(N0 * world / (ms_layer * 1e-3) / 1e6, 3),
+                         "unit": "Mpoints/s", "hbm_roofline": hbm},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(O)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -170,6 +170,19 @@ int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_i
                 float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
                 void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optional per-kernel timing for bench.py's roofline line (no reference counterpart: the reference
+ * only prints wall-clock per batch, tasks/SemSeg/train_dfaust_rot.py:239-296).  When enabled, every
+ * kernel launch of the fused operator is bracketed by hipEvents on its own launch stream; read
+ * accumulates milliseconds and launch counts per stage tag ("edge_t_fwd", "gemm_out", "gemm_gradT",
+ * "edge_param_grad", "gemm_gradW", "edge_t_transposed", "gemm_gradX", "edge_t_recompute").
+ * Off by default; this switch is the library's only process-wide state.
+ * ------------------------------------------------------------------------------------------- */
+int se3_profile_enable(int on);
+int se3_profile_reset(void);
+int se3_profile_read(const char* tag, double* total_ms, int64_t* launches);
+int se3_profile_tags(char* buf, size_t len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,10 @@ SIGNATURES = {
     "se3conv_fwd": (C.c_int, [_P] * 12 + [_SHP, _P, _P, _P, _SZ, _P]),
     "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
     "se3conv_bwd": (C.c_int, [_P] * 16 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
+    "se3_profile_enable": (C.c_int, [C.c_int]),
+    "se3_profile_reset": (C.c_int, []),
+    "se3_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "se3_profile_tags": (C.c_int, [C.c_char_p, _SZ]),
 }
 
 _lib = None

@@ -1,4 +1,6 @@
 // extern "C" entry points of the fused operator + the API-parity ops (see include/se3conv.h).
+#include <cstring>
+
 #include "common.h"
 
 namespace se3 {
@@ -318,9 +320,9 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
 
   hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
   const EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
-  if (int rc = launch_edge_t(g, feat, s->c_in, axes_ext, rho, t, stream)) return rc;
+  if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, axes_ext, rho, t, stream)) return rc;
   // einsum('nik,iko->no') :210, /F_in :213, *norm_num_neighs_ :216
-  return launch_gemm_nn(t, conv_weights, out, s->n_out * s->f_out, s->c_out, s->c_in * s->num_basis, nu,
+  return launch_gemm_nn("gemm_out", t, conv_weights, out, s->n_out * s->f_out, s->c_out, s->c_in * s->num_basis, nu,
                         1.0f / (float)s->f_in, stream);
 }
 
@@ -364,10 +366,10 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     float* wt = (float*)(ws + l.wt);
     hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream, conv_weights, wt,
                        ck, s->c_out);
-    if (int rc = launch_gemm_nn(grad_out, wt, big, rows_out, ck, s->c_out, nu, inv_fin, stream)) return rc;
+    if (int rc = launch_gemm_nn("gemm_gradT", grad_out, wt, big, rows_out, ck, s->c_out, nu, inv_fin, stream)) return rc;
     if (grad_axes || grad_biases) {
       float* partials = (float*)(ws + l.param_partials);
-      if (int rc = launch_edge_param_grad(g, feat, s->c_in, axes_ext, rho, big, partials, l.n_param_partials, stream))
+      if (int rc = launch_edge_param_grad("edge_param_grad", g, feat, s->c_in, axes_ext, rho, big, partials, l.n_param_partials, stream))
         return rc;
       hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(2), dim3(256), 0, stream, partials, l.n_param_partials,
                          grad_axes, grad_biases);
@@ -376,11 +378,11 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       const float* t = t_save;
       if (!t) {
         float* tt = (float*)(ws + l.t);
-        if (int rc = launch_edge_t(g, feat, s->c_in, axes_ext, rho, tt, stream)) return rc;
+        if (int rc = launch_edge_t("edge_t_recompute", g, feat, s->c_in, axes_ext, rho, tt, stream)) return rc;
         t = tt;
       }
       // dW[(i,k),o] = alpha * sum_m T[m,(i,k)] g[m,o]
-      if (int rc = launch_gemm_tn(t, grad_out, grad_weights, (float*)(ws + l.tn_partials), l.tn_splits, rows_out, ck,
+      if (int rc = launch_gemm_tn("gemm_gradW", t, grad_out, grad_weights, (float*)(ws + l.tn_partials), l.tn_splits, rows_out, ck,
                                   s->c_out, nu, inv_fin, stream))
         return rc;
     }
@@ -393,11 +395,95 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     gt.ctr_pts = pts_in, gt.ctr_frames = frames_in, gt.nb_pts = pts_out, gt.nb_frames = frames_out;
     gt.nbr = t_samples, gt.nbr_stride = 1, gt.nbr_offset = 0, gt.ends = t_ends;
     gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.transposed = 1;
-    if (int rc = launch_edge_t(gt, grad_out, s->c_out, axes_ext, rho, big, stream)) return rc;
+    if (int rc = launch_edge_t("edge_t_transposed", gt, grad_out, s->c_out, axes_ext, rho, big, stream)) return rc;
     float* w2 = (float*)(ws + l.w2);
     hipLaunchKernelGGL(permute_weights_oki_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream,
                        conv_weights, w2, s->c_in, kb, s->c_out);
-    if (int rc = launch_gemm_nn(big, w2, grad_feat, rows_in, s->c_in, s->c_out * kb, nu, inv_fin, stream)) return rc;
+    if (int rc = launch_gemm_nn("gemm_gradX", big, w2, grad_feat, rows_in, s->c_in, s->c_out * kb, nu, inv_fin, stream)) return rc;
   }
   return check_launch();
+}
+
+// ---- optional per-kernel timing ------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace se3 {
+namespace {
+struct ProfRec { std::string tag; hipEvent_t start, stop; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::map<std::string, std::pair<double, int64_t>> g_prof_acc;
+ProfRec* g_prof_open = nullptr;
+
+void prof_drain_locked() {
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      auto& a = g_prof_acc[r.tag];
+      a.first += ms;
+      a.second += 1;
+    }
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  g_prof_recs.clear();
+}
+}  // namespace
+
+void prof_begin(const char* tag, hipStream_t stream) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.tag = tag;
+  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  (void)hipEventRecord(r.start, stream);
+  g_prof_recs.push_back(r);
+  g_prof_open = &g_prof_recs.back();
+}
+
+void prof_end(hipStream_t stream) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_open) (void)hipEventRecord(g_prof_open->stop, stream);
+  g_prof_open = nullptr;
+}
+}  // namespace se3
+
+extern "C" int se3_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(se3::g_prof_mu);
+  if (!on) se3::prof_drain_locked();
+  se3::g_prof_on = on != 0;
+  return SE3_OK;
+}
+
+extern "C" int se3_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(se3::g_prof_mu);
+  se3::prof_drain_locked();
+  se3::g_prof_acc.clear();
+  return SE3_OK;
+}
+
+extern "C" int se3_profile_read(const char* tag, double* total_ms, int64_t* launches) {
+  if (!tag || !total_ms || !launches) return SE3_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(se3::g_prof_mu);
+  se3::prof_drain_locked();
+  auto it = se3::g_prof_acc.find(tag);
+  *total_ms = it == se3::g_prof_acc.end() ? 0.0 : it->second.first;
+  *launches = it == se3::g_prof_acc.end() ? 0 : it->second.second;
+  return SE3_OK;
+}
+
+extern "C" int se3_profile_tags(char* buf, size_t len) {
+  if (!buf || len == 0) return SE3_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(se3::g_prof_mu);
+  se3::prof_drain_locked();
+  std::string all;
+  for (auto& kv : se3::g_prof_acc) all += (all.empty() ? "" : ",") + kv.first;
+  if (all.size() + 1 > len) return SE3_ERR_WORKSPACE;
+  std::memcpy(buf, all.c_str(), all.size() + 1);
+  return SE3_OK;
 }

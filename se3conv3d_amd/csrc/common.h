@@ -68,6 +68,16 @@ inline int check_launch() {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Optional per-kernel timing (se3_profile_* in se3conv.h): when enabled every launcher brackets its
+// kernel with hipEvents on the launch stream.  Off by default; the only process-wide state.
+void prof_begin(const char* tag, hipStream_t stream);
+void prof_end(hipStream_t stream);
+struct ProfScope {
+  hipStream_t s;
+  ProfScope(const char* tag, hipStream_t stream) : s(stream) { prof_begin(tag, s); }
+  ~ProfScope() { prof_end(s); }
+};
+
 // ---- kernels implemented in the other translation units (host launchers) ----------------------
 struct EdgeGeom {            // one side-agnostic view of the geometry for the edge kernels
   const float* ctr_pts;      // [Nc,3]   points the rows are centred on
@@ -82,17 +92,17 @@ struct EdgeGeom {            // one side-agnostic view of the geometry for the e
   int transposed;            // 0: centre = output point (descriptor "out" side); 1: centre = input point
 };
 
-int launch_edge_t(const EdgeGeom& g, const float* feat, int channels, const float* axes_ext,
+int launch_edge_t(const char* tag, const EdgeGeom& g, const float* feat, int channels, const float* axes_ext,
                   const float* rho, float* t_out, hipStream_t stream);
-int launch_edge_param_grad(const EdgeGeom& g, const float* feat, int channels, const float* axes_ext,
-                           const float* rho, const float* grad_t, float* partials, int n_partials,
-                           hipStream_t stream);
+int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat, int channels,
+                           const float* axes_ext, const float* rho, const float* grad_t, float* partials,
+                           int n_partials, hipStream_t stream);
 int edge_param_grad_blocks(int64_t rows);
 
-int launch_gemm_nn(const float* a, const float* b, float* c, int64_t m, int n, int k, const float* alpha_num,
-                   float alpha_scale, hipStream_t stream);
-int launch_gemm_tn(const float* a, const float* b, float* c, float* partials, int splits, int64_t m, int ka,
-                   int n, const float* alpha_num, float alpha_scale, hipStream_t stream);
+int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, int64_t m, int n, int k,
+                   const float* alpha_num, float alpha_scale, hipStream_t stream);
+int launch_gemm_tn(const char* tag, const float* a, const float* b, float* c, float* partials, int splits, int64_t m,
+                   int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream);
 int gemm_tn_splits(int64_t m, int ka, int n);
 
 }  // namespace se3

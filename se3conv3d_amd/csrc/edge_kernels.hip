@@ -265,10 +265,11 @@ __global__ __launch_bounds__(256) void edge_param_grad_kernel(EdgeGeom g, const 
 
 }  // namespace
 
-int launch_edge_t(const EdgeGeom& g, const float* feat, int channels, const float* axes_ext, const float* rho,
-                  float* t_out, hipStream_t stream) {
+int launch_edge_t(const char* tag, const EdgeGeom& g, const float* feat, int channels, const float* axes_ext,
+                  const float* rho, float* t_out, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (rows == 0) return SE3_OK;
+  ProfScope prof(tag, stream);
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (channels % 128 == 0)
     hipLaunchKernelGGL(edge_t_kernel<4>, grid, block, 0, stream, g, feat, channels, axes_ext, rho, t_out, rows);
@@ -284,10 +285,11 @@ int edge_param_grad_blocks(int64_t rows) {
   return (int)(want < 2048 ? (want > 0 ? want : 1) : 2048);
 }
 
-int launch_edge_param_grad(const EdgeGeom& g, const float* feat, int channels, const float* axes_ext,
-                           const float* rho, const float* grad_t, float* partials, int n_partials,
-                           hipStream_t stream) {
+int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat, int channels,
+                           const float* axes_ext, const float* rho, const float* grad_t, float* partials,
+                           int n_partials, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
+  ProfScope prof(tag, stream);
   hipLaunchKernelGGL(edge_param_grad_kernel, dim3(n_partials), dim3(256), 0, stream, g, feat, channels, axes_ext,
                      rho, grad_t, partials, rows);
   return check_launch();

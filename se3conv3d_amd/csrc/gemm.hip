@@ -155,9 +155,10 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, float
 
 }  // namespace
 
-int launch_gemm_nn(const float* a, const float* b, float* c, int64_t m, int n, int k, const float* alpha_num,
-                   float alpha_scale, hipStream_t stream) {
+int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, int64_t m, int n, int k,
+                   const float* alpha_num, float alpha_scale, hipStream_t stream) {
   if (m == 0 || n == 0) return SE3_OK;
+  ProfScope prof(tag, stream);
   const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN - 1) / BN));
   hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, a, b, c, m, n, k, alpha_num, alpha_scale);
   return check_launch();
@@ -172,9 +173,10 @@ int gemm_tn_splits(int64_t m, int ka, int n) {
   return (int)s;
 }
 
-int launch_gemm_tn(const float* a, const float* b, float* c, float* partials, int splits, int64_t m, int ka, int n,
-                   const float* alpha_num, float alpha_scale, hipStream_t stream) {
+int launch_gemm_tn(const char* tag, const float* a, const float* b, float* c, float* partials, int splits, int64_t m,
+                   int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream) {
   if (ka == 0 || n == 0) return SE3_OK;
+  ProfScope prof(tag, stream);
   int64_t chunk = (m + splits - 1) / splits;
   chunk += chunk & 1;  // keep every split's first row even so the (m, m+1) pairing never straddles splits
   if (chunk == 0) chunk = 2;
