@@ -28,7 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N0, K_DEG, FRAMES, CH, KB = 65536, 32, 2, 64, 32
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+# MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate; bf16 dense MFMA ~2.5 PF.
+# In "bf16x3" every multiply costs 3 bf16 MFMA products, so frac <= 1/3 by construction there.
+PEAK_MFMA_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec
 
 
@@ -72,6 +74,21 @@ def layer_flops(n, e):
     edge = ep * (2 * 10 * KB + 2 * CH * KB)
     return {"edge_t_fwd": edge, "gemm_out": dense, "gemm_gradT": dense, "gemm_gradW": dense, "gemm_gradX": dense,
             "edge_t_transposed": edge, "edge_param_grad": ep * (2 * 10 * KB + 2 * CH * KB + 2 * 10 * KB)}
+
+
+def stage_bytes(n, e):
+    """HBM bytes each kernel of the (unfused) pipeline has to move at least: its gathered rows counted
+    once per edge (uncached-gather model), its dense operands and results once."""
+    ep_pt = e * FRAMES            # (edge, neighbour frame) pairs: one C-row gather each per centre frame pass
+    rows = n * FRAMES
+    t_bytes = 4 * rows * CH * KB  # T / grad_T / U: [rows, C, K] words
+    geom = 8 * e + 4 * n + 12 * 2 * n + 36 * 2 * rows
+    w = 4 * CH * KB * CH
+    edge = geom + 4 * ep_pt * CH * FRAMES + t_bytes
+    return {"edge_t_fwd": edge, "edge_t_transposed": edge, "edge_param_grad": edge,
+            "gemm_out": t_bytes + w + 4 * rows * CH, "gemm_gradT": t_bytes + w + 4 * rows * CH,
+            "gemm_gradX": t_bytes + w + 4 * rows * CH, "gemm_gradW": t_bytes + 4 * rows * CH + w,
+            "split_pack": 8 * rows * CH}
 
 
 def layer_bytes(n, e):
@@ -136,6 +153,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("SE3CONV_PRECISION", "bf16x3"), choices=["bf16x3", "fp32"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +175,7 @@ def main():
     from se3conv3d_amd import _lib
 
     lib = _lib.load()
+    amd.set_precision(args.precision)
     levels = build_stack(amd, O, device, seed=rank)
 
     def barrier():
@@ -187,15 +206,25 @@ def main():
 
     stages = profile_level0(lib, levels[0], reps=5)
     fl = layer_flops(levels[0]["n"], levels[0]["e"])
+    sb = stage_bytes(levels[0]["n"], levels[0]["e"])
+    peak_tf = PEAK_MFMA_TFLOPS[args.precision]
     dom = max(stages, key=lambda t: stages[t][0]) if stages else None
     roofline = None
     if dom is not None:
-        ach = fl.get(dom, 0) / (stages[dom][0] * 1e-3) / 1e12
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(stages[dom][0], 4), "launches": stages[dom][1],
-                    "algorithmic_flops_per_launch": fl.get(dom, 0),
-                    "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}}
+        sec = stages[dom][0] * 1e-3
+        tf = fl.get(dom, 0) / sec / 1e12
+        gbs = sb.get(dom, 0) / sec / 1e9
+        frac_mfma, frac_hbm = tf / peak_tf, gbs / PEAK_HBM_GBPS
+        if frac_hbm >= frac_mfma:
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(frac_hbm, 4), "traffic": None, "algorithmic_bytes_per_launch": sb.get(dom, 0),
+                        "mfma_frac": round(frac_mfma, 4)}
+        else:
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                        "frac": round(frac_mfma, 4), "traffic": None, "algorithmic_flops_per_launch": fl.get(dom, 0),
+                        "hbm_frac": round(frac_hbm, 4)}
+        roofline.update({"avg_launch_ms": round(stages[dom][0], 4), "launches": stages[dom][1],
+                         "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}})
     lb = layer_bytes(levels[0]["n"], levels[0]["e"])
     hbm = {"algorithmic_bytes_per_layer": lb, "achieved": round(lb / (ms_layer * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS,
            "unit": "GB/s", "frac": round(lb / (ms_layer * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
@@ -211,7 +240,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": "4-level PNEConvLayerRotEquiv stack, conv-only fwd+bwd (dX,dA,dbeta,dW), one cloud per GPU",
                    "n_points": N0, "k": K_DEG, "frames": FRAMES, "channels": CH, "num_basis": KB,

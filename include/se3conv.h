@@ -49,7 +49,19 @@ typedef struct se3conv_shape {
   int32_t c_in;    /* input feature channels                                */
   int32_t c_out;   /* output feature channels                               */
   int32_t num_basis; /* K = p_num_basis; the MFMA kernels implement K == 32 */
+  int32_t precision; /* SE3_PRECISION_*: arithmetic of the contractions (inputs/outputs are fp32)  */
 } se3conv_shape;
+
+/* Arithmetic of the three contractions (kernel MLP, basis (x) feature aggregate, C_in*K -> C_out):
+ *   FP32   : v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulate (reference numerics up to
+ *            summation order; ~1e-6 relative to the oracle).
+ *   BF16X3 : every fp32 operand x is split into hi = bf16(x), lo = bf16(x - hi) and every product is
+ *            evaluated as hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_bf16 with fp32 accumulate
+ *            (~1e-5 relative to the oracle; the north-star tolerance is 1e-4; 16x the MFMA rate at
+ *            3 products).  `t_save` is then an opaque buffer of the same size (packed hi/lo words)
+ *            and must be passed back to se3conv_bwd with the same precision. */
+#define SE3_PRECISION_FP32 0
+#define SE3_PRECISION_BF16X3 1
 
 /* Library / build identification. */
 int se3_abi_version(void);

@@ -13,7 +13,8 @@ not been built (``python -m se3conv3d_amd.build``).
 from . import layers, ops, pc  # noqa: F401
 from .layers import (IConvLayer, IConvLayerFactory, PNEConvLayerRotEquiv,  # noqa: F401
                      PNEConvLayerRotEquivFactory, PreProcessModule)
-from .ops import BallQuery, ComputeKeys, FeatBasisProj, SE3ConvFunction  # noqa: F401
+from .ops import (BallQuery, ComputeKeys, FeatBasisProj, SE3ConvFunction, get_precision,  # noqa: F401
+                  set_precision)
 from .pc import (BQNeighborhood, Pointcloud, PointcloudRotEquiv, PointHierarchy,  # noqa: F401
                  PointHierarchyRotEquiv)
 

@@ -11,6 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libse3conv_hip.so")
 
 SE3_OK = 0
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
 
 
 class Se3Shape(C.Structure):
@@ -19,7 +20,7 @@ class Se3Shape(C.Structure):
     _fields_ = [
         ("n_in", C.c_int64), ("n_out", C.c_int64), ("n_edges", C.c_int64),
         ("f_in", C.c_int32), ("f_out", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32),
-        ("num_basis", C.c_int32),
+        ("num_basis", C.c_int32), ("precision", C.c_int32),
     ]
 
 

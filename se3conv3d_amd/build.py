@@ -17,7 +17,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libse3conv_hip.so")
-SOURCES = ["geometry.hip", "edge_kernels.hip", "gemm.hip", "api.hip"]
+SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "gemm.hip", "gemm_bf16.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "se3conv.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         subprocess.run(cmd, check=True)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])

@@ -37,16 +37,26 @@ __global__ void permute_weights_oki_kernel(const float* __restrict__ w, float* _
   }
 }
 
-__global__ void reduce_param_partials_kernel(const float* __restrict__ partials, int n_partials,
-                                             float* __restrict__ grad_axes, float* __restrict__ grad_biases) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= kDescExt * kBasis) return;
+// one block per output element: 256 threads stride over the per-block partials, then tree-reduce
+__global__ __launch_bounds__(256) void reduce_param_partials_kernel(const float* __restrict__ partials, int n_partials,
+                                                                    float* __restrict__ grad_axes,
+                                                                    float* __restrict__ grad_biases) {
+  __shared__ float red[256];
+  const int i = blockIdx.x;
   float s = 0.f;
-  for (int p = 0; p < n_partials; ++p) s += partials[(int64_t)p * kDescExt * kBasis + i];
-  if (i < SE3_DESC_DIMS * kBasis) {
-    if (grad_axes) grad_axes[i] = s;
-  } else if (grad_biases) {
-    grad_biases[i - SE3_DESC_DIMS * kBasis] = s;
+  for (int p = threadIdx.x; p < n_partials; p += 256) s += partials[(int64_t)p * kDescExt * kBasis + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (i < SE3_DESC_DIMS * kBasis) {
+      if (grad_axes) grad_axes[i] = red[0];
+    } else if (grad_biases) {
+      grad_biases[i - SE3_DESC_DIMS * kBasis] = red[0];
+    }
   }
 }
 
@@ -167,7 +177,8 @@ inline unsigned grid_for(int64_t n) {
 
 bool shape_ok(const se3conv_shape* s) {
   return s && s->n_in >= 0 && s->n_out >= 0 && s->n_edges >= 0 && s->f_in >= 1 && s->f_out >= 1 && s->c_in >= 1 &&
-         s->c_out >= 1 && s->num_basis >= 1;
+         s->c_out >= 1 && s->num_basis >= 1 &&
+         (s->precision == SE3_PRECISION_FP32 || s->precision == SE3_PRECISION_BF16X3);
 }
 int shape_supported(const se3conv_shape* s) {
   if (s->num_basis != kBasis) return SE3_ERR_UNSUPPORTED;  // every shipped config uses K = 32
@@ -177,18 +188,28 @@ int shape_supported(const se3conv_shape* s) {
   return SE3_OK;
 }
 
-struct FwdLayout { size_t axes_ext, t, total; };
+struct FwdLayout { size_t axes_ext, t, featpk, bt_hi, bt_lo, total; };
 FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
   FwdLayout l{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t kb = s->num_basis;
   l.axes_ext = take(kDescExt * kBasis * 4);
-  l.t = save_t ? 0 : take((size_t)s->n_out * s->f_out * s->c_in * s->num_basis * 4);
+  l.t = save_t ? 0 : take((size_t)s->n_out * s->f_out * s->c_in * kb * 4);
+  if (s->precision == SE3_PRECISION_BF16X3) {
+    l.featpk = take((size_t)s->n_in * s->f_in * s->c_in * 4);
+    const size_t plane = (size_t)s->c_out * align_up((size_t)s->c_in * kb, 32) * 2;
+    l.bt_hi = take(plane);
+    l.bt_lo = take(plane);
+  }
   l.total = off;
   return l;
 }
 
-struct BwdLayout { size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, total; int n_param_partials, tn_splits; };
+struct BwdLayout {
+  size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, total;
+  int n_param_partials, tn_splits;
+};
 BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
   BwdLayout l{};
   size_t off = 0;
@@ -196,9 +217,21 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   const size_t kb = s->num_basis;
   const size_t rows_out = (size_t)s->n_out * s->f_out, rows_in = (size_t)s->n_in * s->f_in;
   const size_t wsz = (size_t)s->c_in * kb * s->c_out * 4;
+  const bool fast = s->precision == SE3_PRECISION_BF16X3;
   l.axes_ext = take(kDescExt * kBasis * 4);
-  l.wt = want_params ? take(wsz) : 0;
-  l.w2 = want_feat ? take(wsz) : 0;
+  if (!fast) {
+    l.wt = want_params ? take(wsz) : 0;
+    l.w2 = want_feat ? take(wsz) : 0;
+  } else {
+    // the largest of the three pre-split weight layouts (see prep_weights_kernel)
+    size_t plane = (size_t)s->c_in * kb * align_up((size_t)s->c_out, 32) * 2;
+    const size_t p2 = (size_t)s->c_in * align_up((size_t)s->c_out * kb, 32) * 2;
+    if (p2 > plane) plane = p2;
+    l.bt_hi = take(plane);
+    l.bt_lo = take(plane);
+    l.featpk = want_params ? take(rows_in * s->c_in * 4) : 0;
+    l.gpk = take(rows_out * s->c_out * 4);
+  }
   size_t big = 0;
   if (want_params) big = rows_out * s->c_in * kb * 4;
   if (want_feat && rows_in * s->c_out * kb * 4 > big) big = rows_in * s->c_out * kb * 4;
@@ -320,10 +353,22 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
 
   hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
   const EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
-  if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, axes_ext, rho, t, stream)) return rc;
-  // einsum('nik,iko->no') :210, /F_in :213, *norm_num_neighs_ :216
-  return launch_gemm_nn("gemm_out", t, conv_weights, out, s->n_out * s->f_out, s->c_out, s->c_in * s->num_basis, nu,
-                        1.0f / (float)s->f_in, stream);
+  const int64_t rows_out = s->n_out * s->f_out;
+  const int ck = s->c_in * s->num_basis;
+  const float inv_fin = 1.0f / (float)s->f_in;
+  // einsum('nik,iko->no') :210, /F_in :213, *norm_num_neighs_ :216 are the GEMM + its alpha
+  if (s->precision == SE3_PRECISION_FP32) {
+    if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, axes_ext, rho, t, stream)) return rc;
+    return launch_gemm_nn("gemm_out", t, conv_weights, out, rows_out, s->c_out, ck, nu, inv_fin, stream);
+  }
+  uint32_t* featpk = (uint32_t*)(ws + l.featpk);
+  uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
+  uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
+  if (int rc = launch_split_pack(feat, featpk, s->n_in * s->f_in * s->c_in, stream)) return rc;
+  if (int rc = launch_prep_weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, stream)) return rc;
+  if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, axes_ext, rho, t, true, stream)) return rc;
+  return launch_gemm_nn_bf16("gemm_out", (const uint32_t*)t, bt_hi, bt_lo, out, false, rows_out, s->c_out, ck, nu,
+                             inv_fin, stream);
 }
 
 extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
@@ -360,46 +405,92 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
 
   hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
   const EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
+  // transposed graph: centre = input point, edges lead to output points (feature gradient)
+  EdgeGeom gt{};
+  gt.ctr_pts = pts_in, gt.ctr_frames = frames_in, gt.nb_pts = pts_out, gt.nb_frames = frames_out;
+  gt.nbr = t_samples, gt.nbr_stride = 1, gt.nbr_offset = 0, gt.ends = t_ends;
+  gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.transposed = 1;
+  float* partials = (float*)(ws + l.param_partials);
+  float* tn_partials = (float*)(ws + l.tn_partials);
 
-  if (want_params) {
-    // gT[m,(i,k)] = alpha * sum_o g[m,o] W[i,k,o]
-    float* wt = (float*)(ws + l.wt);
-    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream, conv_weights, wt,
-                       ck, s->c_out);
-    if (int rc = launch_gemm_nn("gemm_gradT", grad_out, wt, big, rows_out, ck, s->c_out, nu, inv_fin, stream)) return rc;
-    if (grad_axes || grad_biases) {
-      float* partials = (float*)(ws + l.param_partials);
-      if (int rc = launch_edge_param_grad("edge_param_grad", g, feat, s->c_in, axes_ext, rho, big, partials, l.n_param_partials, stream))
+  if (s->precision == SE3_PRECISION_FP32) {
+    if (want_params) {
+      // gT[m,(i,k)] = alpha * sum_o g[m,o] W[i,k,o]
+      float* wt = (float*)(ws + l.wt);
+      hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream, conv_weights,
+                         wt, ck, s->c_out);
+      if (int rc = launch_gemm_nn("gemm_gradT", grad_out, wt, big, rows_out, ck, s->c_out, nu, inv_fin, stream)) return rc;
+      if (grad_axes || grad_biases) {
+        if (int rc = launch_edge_param_grad("edge_param_grad", g, feat, s->c_in, axes_ext, rho, big, partials,
+                                            l.n_param_partials, stream))
+          return rc;
+        hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
+                           l.n_param_partials, grad_axes, grad_biases);
+      }
+      if (grad_weights) {
+        const float* t = t_save;
+        if (!t) {
+          float* tt = (float*)(ws + l.t);
+          if (int rc = launch_edge_t("edge_t_recompute", g, feat, s->c_in, axes_ext, rho, tt, stream)) return rc;
+          t = tt;
+        }
+        // dW[(i,k),o] = alpha * sum_m T[m,(i,k)] g[m,o]
+        if (int rc = launch_gemm_tn("gemm_gradW", t, grad_out, grad_weights, tn_partials, l.tn_splits, rows_out, ck,
+                                    s->c_out, nu, inv_fin, stream))
+          return rc;
+      }
+    }
+    if (want_feat && rows_in > 0) {
+      // Transposed convolution instead of scatter atomics:
+      //   U[(p,b),o,k] = sum_{edges into p} sum_a phi(s,a,p,b)[k] g[(s,a),o];  dX[(p,b),i] = alpha * sum_{o,k} U W[i,k,o]
+      if (int rc = launch_edge_t("edge_t_transposed", gt, grad_out, s->c_out, axes_ext, rho, big, stream)) return rc;
+      float* w2 = (float*)(ws + l.w2);
+      hipLaunchKernelGGL(permute_weights_oki_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream,
+                         conv_weights, w2, s->c_in, kb, s->c_out);
+      if (int rc = launch_gemm_nn("gemm_gradX", big, w2, grad_feat, rows_in, s->c_in, s->c_out * kb, nu, inv_fin, stream))
         return rc;
-      hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(2), dim3(256), 0, stream, partials, l.n_param_partials,
-                         grad_axes, grad_biases);
+    }
+    return check_launch();
+  }
+
+  // ---- split-bf16 path: same stages, operands as packed words -----------------------------------------
+  uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
+  uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
+  uint32_t* gpk = (uint32_t*)(ws + l.gpk);
+  uint32_t* bigw = (uint32_t*)big;
+  if (int rc = launch_split_pack(grad_out, gpk, rows_out * s->c_out, stream)) return rc;
+  if (want_params) {
+    uint32_t* featpk = (uint32_t*)(ws + l.featpk);
+    if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
+    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, stream)) return rc;
+    if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out, nu, inv_fin,
+                                     stream))
+      return rc;
+    if (grad_axes || grad_biases) {
+      if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, axes_ext, rho, bigw, partials,
+                                               l.n_param_partials, stream))
+        return rc;
+      hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
+                         l.n_param_partials, grad_axes, grad_biases);
     }
     if (grad_weights) {
-      const float* t = t_save;
+      const uint32_t* t = (const uint32_t*)t_save;
       if (!t) {
-        float* tt = (float*)(ws + l.t);
-        if (int rc = launch_edge_t("edge_t_recompute", g, feat, s->c_in, axes_ext, rho, tt, stream)) return rc;
+        uint32_t* tt = (uint32_t*)(ws + l.t);
+        if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, axes_ext, rho, tt, true, stream)) return rc;
         t = tt;
       }
-      // dW[(i,k),o] = alpha * sum_m T[m,(i,k)] g[m,o]
-      if (int rc = launch_gemm_tn("gemm_gradW", t, grad_out, grad_weights, (float*)(ws + l.tn_partials), l.tn_splits, rows_out, ck,
-                                  s->c_out, nu, inv_fin, stream))
+      if (int rc = launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck,
+                                       s->c_out, nu, inv_fin, stream))
         return rc;
     }
   }
-
   if (want_feat && rows_in > 0) {
-    // Transposed convolution instead of scatter atomics:
-    //   U[(p,b),o,k] = sum_{edges into p} sum_a phi(s,a,p,b)[k] g[(s,a),o];  dX[(p,b),i] = alpha * sum_{o,k} U W[i,k,o]
-    EdgeGeom gt{};
-    gt.ctr_pts = pts_in, gt.ctr_frames = frames_in, gt.nb_pts = pts_out, gt.nb_frames = frames_out;
-    gt.nbr = t_samples, gt.nbr_stride = 1, gt.nbr_offset = 0, gt.ends = t_ends;
-    gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.transposed = 1;
-    if (int rc = launch_edge_t("edge_t_transposed", gt, grad_out, s->c_out, axes_ext, rho, big, stream)) return rc;
-    float* w2 = (float*)(ws + l.w2);
-    hipLaunchKernelGGL(permute_weights_oki_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream,
-                       conv_weights, w2, s->c_in, kb, s->c_out);
-    if (int rc = launch_gemm_nn("gemm_gradX", big, w2, grad_feat, rows_in, s->c_in, s->c_out * kb, nu, inv_fin, stream)) return rc;
+    if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, axes_ext, rho, bigw, true, stream)) return rc;
+    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, bt_hi, bt_lo, stream)) return rc;
+    if (int rc = launch_gemm_nn_bf16("gemm_gradX", bigw, bt_hi, bt_lo, grad_feat, false, rows_in, s->c_in,
+                                     s->c_out * kb, nu, inv_fin, stream))
+      return rc;
   }
   return check_launch();
 }

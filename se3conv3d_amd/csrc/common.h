@@ -24,6 +24,61 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- split-bf16 ("bf16x3") arithmetic ------------------------------------------------------------
+// An fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi) (16 significant bits together); a
+// product a*b is evaluated as a_hi*b_hi + a_lo*b_hi + a_hi*b_lo on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation (relative error ~2^-17 per product, vs 2^-24 for the fp32 MFMA at 1/16 the rate).
+// In memory such operands are "packed words": (hi << 16) | lo, the same 4 bytes as the fp32 value.
+using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using bf16x2 = __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16;
+using f32x2 = __attribute__((__vector_size__(2 * sizeof(float)))) float;
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t;
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// c += a*b with both operands split
+__device__ __forceinline__ f32x16 mfma_bf16x3(u32x4 a_hi, u32x4 a_lo, u32x4 b_hi, u32x4 b_lo, f32x16 c) {
+  c = mfma_bf16(a_lo, b_hi, c);
+  c = mfma_bf16(a_hi, b_lo, c);
+  return mfma_bf16(a_hi, b_hi, c);
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float x0, float x1) {  // low half = bf16(x0), high half = bf16(x1)
+  f32x2 v = {x0, x1};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// two values -> packed pair of their hi parts and packed pair of their lo parts
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  lo = cvt_pk_bf16(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+// one value -> packed word (hi << 16) | lo
+__device__ __forceinline__ uint32_t split_pack(float x) {
+  const uint32_t h = cvt_pk_bf16(x, 0.f) << 16;
+  return h | (cvt_pk_bf16(x - __uint_as_float(h), 0.f) & 0xffffu);
+}
+// packed words w0, w1 -> packed pair of hi parts / of lo parts (element 0 = w0)
+__device__ __forceinline__ uint32_t pair_hi(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x07060302u); }
+__device__ __forceinline__ uint32_t pair_lo(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x05040100u); }
+// 8 packed words -> the two 8 x bf16 MFMA fragments
+__device__ __forceinline__ void frags_from_words(const uint32_t w[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = pair_hi(w[2 * i], w[2 * i + 1]);
+    lo[i] = pair_lo(w[2 * i], w[2 * i + 1]);
+  }
+}
+// 8 fp32 values -> the two fragments
+__device__ __forceinline__ void frags_from_floats(const float v[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t a, b;
+    split2(v[2 * i], v[2 * i + 1], a, b);
+    hi[i] = a;
+    lo[i] = b;
+  }
+}
+
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -32,14 +87,27 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // Exact-erf GELU (torch.nn.GELU() default; reference PNEConvLayer.py:94-95) and its derivative.
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
+// erfc through Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 on erf, i.e. <= 7.5e-8 on the normal
+// CDF -- fp32 rounding level), evaluated on |x| so the negative tail keeps its relative accuracy:
+//   Phi(-|x|) = 0.5 * erfc(|x|/sqrt2) = 0.5 * t*(a1 + t*(a2 + ...)) * exp(-x^2/2),  t = 1/(1 + p|x|/sqrt2)
+// 11 full-rate VALU ops + v_rcp_f32 + v_exp_f32; the same exponential gives the density for GELU'.
 __device__ __forceinline__ void gelu_erf_grad(float x, float& y, float& dy) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);  // exp(-x^2/2)
+  const float q = 0.5f * p * t * e;                                            // Phi(-|x|)
+  const float cdf = x >= 0.f ? 1.0f - q : q;
   y = x * cdf;
-  dy = cdf + x * pdf;
+  dy = fmaf(x * e, 0.39894228040143267794f, cdf);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float y, dy;
+  gelu_erf_grad(x, y, dy);
+  return y;
 }
 
 // 9-D edge descriptor (reference PNEConvLayerRotEquiv.py:68-90):
@@ -104,5 +172,22 @@ int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, in
 int launch_gemm_tn(const char* tag, const float* a, const float* b, float* c, float* partials, int splits, int64_t m,
                    int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream);
 int gemm_tn_splits(int64_t m, int ka, int n);
+int launch_reduce_partials(const float* partials, float* out, int64_t count, int splits, const float* alpha_num,
+                           float alpha_scale, hipStream_t stream);
+
+// split-bf16 path (edge_bf16.hip, gemm_bf16.hip)
+int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream);
+int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, const float* axes_ext,
+                       const float* rho, void* t_out, bool out_packed, hipStream_t stream);
+int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
+                                const float* axes_ext, const float* rho, const uint32_t* grad_t, float* partials,
+                                int n_partials, hipStream_t stream);
+int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
+                        hipStream_t stream);
+int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
+                        bool out_packed, int64_t m, int n, int k, const float* alpha_num, float alpha_scale,
+                        hipStream_t stream);
+int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream);
 
 }  // namespace se3

@@ -1,0 +1,325 @@
+// Split-bf16 ("bf16x3") versions of the edge kernels: same decomposition as edge_kernels.hip (one
+// wavefront per output row, 32 frame-edges per chunk, kernel-MLP output used in place as the MFMA
+// B operand) on v_mfma_f32_32x32x16_bf16 -- 16x the fp32-MFMA rate at 3 products per multiply.
+//
+// k-dimension bookkeeping (16 per MFMA): lane half h owns k-slots 8h..8h+7.  For the aggregate
+// T += feat^T phi, k-step s (0,1) of a chunk covers the frame-edges held in accumulator registers
+// 8s..8s+7 of the MLP result, i.e. slot (h, j) <-> frame-edge acc_row(8s + j, h); the A operand
+// (gathered features) is loaded in exactly that order, so no lane ever moves data.
+//
+// Gathered operands (features, grad_out) are read as packed words (hi << 16 | lo) prepared by
+// split_pack_kernel; intermediates (T, grad_T, U) are written as packed words too.
+#include "common.h"
+
+namespace se3 {
+
+namespace {
+
+struct RowInfo {
+  int64_t ctr;
+  int start, n_total;
+};
+
+__device__ __forceinline__ RowInfo row_info(const EdgeGeom& g, int64_t m) {
+  RowInfo r;
+  r.ctr = m / g.f_ctr;
+  r.start = r.ctr > 0 ? g.ends[r.ctr - 1] : 0;
+  r.n_total = (g.ends[r.ctr] - r.start) * g.f_nb;
+  return r;
+}
+
+__device__ __forceinline__ void lane_descriptor(const EdgeGeom& g, const RowInfo& ri, int fe, const float yc[3],
+                                                const float rc[9], float rho, float d[kDescExt], int& q) {
+  const int e = ri.start + fe / g.f_nb;
+  const int fn = fe % g.f_nb;
+  const int nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+  q = nb * g.f_nb + fn;
+  float xn[3], rn[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+  if (!g.transposed)
+    edge_descriptor(xn, rn, yc, rc, rho, d);
+  else
+    edge_descriptor(yc, rc, xn, rn, rho, d);
+  d[9] = 1.0f;
+}
+
+// B operand of the kernel MLP: [A; beta; 0...] as a 16 x 32 matrix, lane (kcol, h) holds rows 8h..8h+7.
+__device__ __forceinline__ void load_mlp_weights(const float* __restrict__ axes_ext, int kcol, int h, u32x4& b_hi,
+                                                 u32x4& b_lo) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * h + j;
+    v[j] = k < kDescExt ? axes_ext[k * kBasis + kcol] : 0.f;
+  }
+  frags_from_floats(v, b_hi, b_lo);
+}
+
+// pre[n, k] for the 32 frame-edges of the chunk (lane n = lane & 31 supplies its descriptor).
+__device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], int h, u32x4 b_hi, u32x4 b_lo) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = h ? (j < 2 ? d[8 + j] : 0.f) : d[j];
+  u32x4 a_hi, a_lo;
+  frags_from_floats(v, a_hi, a_lo);
+  return mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, zero16());
+}
+
+// ------------------------------------------------------------------------------------------------
+// T[m, c, k] = sum_n feat[q(n), c] * GELU(desc(n) . A + beta)[k];   feat and T are packed words
+// (OUT_PACKED) or T is plain fp32.
+// ------------------------------------------------------------------------------------------------
+template <int VW, bool OUT_PACKED>
+__global__ __launch_bounds__(256) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
+                                                          const float* __restrict__ axes_ext,
+                                                          const float* __restrict__ rho_p, void* __restrict__ t_out,
+                                                          int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int kcol = lane & 31, h = lane >> 5;
+  const float rho = *rho_p;
+  u32x4 w_hi, w_lo;
+  load_mlp_weights(axes_ext, kcol, h, w_hi, w_lo);
+
+  const RowInfo ri = row_info(g, m);
+  float yc[3], rc[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ri.ctr * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[m * 9 + i];
+
+  for (int cbase = 0; cbase < channels; cbase += 32 * VW) {
+    const int cb = cbase + VW * kcol;
+    const bool ch_ok = cb < channels;  // channels % VW == 0 => the whole vector is valid or not
+    const int cb_ld = ch_ok ? cb : 0;
+    f32x16 acc[VW];
+#pragma unroll
+    for (int t = 0; t < VW; ++t) acc[t] = zero16();
+
+    for (int c0 = 0; c0 < ri.n_total; c0 += 32) {
+      const int cnt = min(32, ri.n_total - c0);
+      const int fe = c0 + min(kcol, cnt - 1);
+      float d[kDescExt];
+      int q;
+      lane_descriptor(g, ri, fe, yc, rc, rho, d, q);
+      f32x16 phi = mlp_preactivation(d, h, w_hi, w_lo);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) phi[r] = acc_row(r, h) < cnt ? gelu_erf(phi[r]) : 0.f;
+
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s * 16 < cnt) {  // wave-uniform
+          uint32_t w[VW][8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * s + j;
+            const int q_lo = __builtin_amdgcn_readlane(q, acc_row(r, 0));
+            const int q_hi = __builtin_amdgcn_readlane(q, acc_row(r, 1));
+            const uint32_t* src = feat + (int64_t)(h ? q_hi : q_lo) * channels + cb_ld;
+            if constexpr (VW == 4) {
+              const uint4 v = *reinterpret_cast<const uint4*>(src);
+              w[0][j] = v.x, w[1][j] = v.y, w[2][j] = v.z, w[3][j] = v.w;
+            } else if constexpr (VW == 2) {
+              const uint2 v = *reinterpret_cast<const uint2*>(src);
+              w[0][j] = v.x, w[1][j] = v.y;
+            } else {
+              w[0][j] = *src;
+            }
+          }
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = phi[8 * s + j];
+          u32x4 b_hi, b_lo;
+          frags_from_floats(pv, b_hi, b_lo);
+#pragma unroll
+          for (int t = 0; t < VW; ++t) {
+            u32x4 a_hi, a_lo;
+            frags_from_words(w[t], a_hi, a_lo);
+            if (!ch_ok) a_hi = a_lo = u32x4{0u, 0u, 0u, 0u};
+            acc[t] = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc[t]);
+          }
+        }
+      }
+    }
+    // acc[t] register r, lane (kcol, h) = T[m][cbase + VW*acc_row(r,h) + t][kcol]
+#pragma unroll
+    for (int t = 0; t < VW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = cbase + VW * acc_row(r, h) + t;
+        if (ch < channels) {
+          const int64_t o = (m * channels + ch) * kBasis + kcol;
+          if constexpr (OUT_PACKED)
+            static_cast<uint32_t*>(t_out)[o] = split_pack(acc[t][r]);
+          else
+            static_cast<float*>(t_out)[o] = acc[t][r];
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradient of the kernel-MLP parameters (cf. edge_param_grad_kernel in edge_kernels.hip):
+//   gphi[n,k] = sum_i feat[q(n), i] * gT[m][i,k]   rows n, cols k, k-dim = channels, 16 per MFMA:
+//               A: lane (n,h) reads words feat[q(n)][i0 + 8h .. +7]  (32 contiguous bytes)
+//               B: lane (k,h) reads words gT[m][i0 + 8h + j][k], j = 0..7
+//   gpre = gphi * GELU'(pre);  d[A;beta][j,k] += desc_ext[n,j] * gpre[n,k]   (fp32 VALU)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+                                                                   int channels, const float* __restrict__ axes_ext,
+                                                                   const float* __restrict__ rho_p,
+                                                                   const uint32_t* __restrict__ grad_t,
+                                                                   float* __restrict__ partials, int64_t rows) {
+  __shared__ __attribute__((aligned(16))) float lds_desc[4][32][12];
+  __shared__ float lds_red[4][kDescExt][kBasis];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kcol = lane & 31, h = lane >> 5;
+  const float rho = *rho_p;
+  u32x4 w_hi, w_lo;
+  load_mlp_weights(axes_ext, kcol, h, w_hi, w_lo);
+  float dacc[kDescExt];
+#pragma unroll
+  for (int j = 0; j < kDescExt; ++j) dacc[j] = 0.f;
+  const bool vec_ok = (channels % 16) == 0;
+
+  for (int64_t m = (int64_t)blockIdx.x * 4 + wave; m < rows; m += (int64_t)gridDim.x * 4) {
+    const RowInfo ri = row_info(g, m);
+    if (ri.n_total == 0) continue;
+    float yc[3], rc[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ri.ctr * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[m * 9 + i];
+    const uint32_t* gt_row = grad_t + m * (int64_t)channels * kBasis;
+
+    for (int c0 = 0; c0 < ri.n_total; c0 += 32) {
+      const int cnt = min(32, ri.n_total - c0);
+      const int fe = c0 + min(kcol, cnt - 1);
+      float d[kDescExt];
+      int q;
+      lane_descriptor(g, ri, fe, yc, rc, rho, d, q);
+      const f32x16 pre = mlp_preactivation(d, h, w_hi, w_lo);
+      if (h == 0) {
+        float4* dst = reinterpret_cast<float4*>(&lds_desc[wave][kcol][0]);
+        dst[0] = make_float4(d[0], d[1], d[2], d[3]);
+        dst[1] = make_float4(d[4], d[5], d[6], d[7]);
+        dst[2] = make_float4(d[8], d[9], 0.f, 0.f);
+      }
+
+      f32x16 gphi = zero16();
+      const uint32_t* f_row = feat + (int64_t)q * channels;
+      for (int i0 = 0; i0 < channels; i0 += 16) {
+        const int my0 = i0 + 8 * h;
+        uint32_t wa[8], wb[8];
+        if (vec_ok) {
+          const uint4 v0 = *reinterpret_cast<const uint4*>(f_row + my0);
+          const uint4 v1 = *reinterpret_cast<const uint4*>(f_row + my0 + 4);
+          wa[0] = v0.x, wa[1] = v0.y, wa[2] = v0.z, wa[3] = v0.w, wa[4] = v1.x, wa[5] = v1.y, wa[6] = v1.z, wa[7] = v1.w;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wb[j] = gt_row[(int64_t)(my0 + j) * kBasis + kcol];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool ok = my0 + j < channels;
+            wa[j] = ok ? f_row[my0 + j] : 0u;
+            wb[j] = ok ? gt_row[(int64_t)(my0 + j) * kBasis + kcol] : 0u;
+          }
+        }
+        u32x4 a_hi, a_lo, b_hi, b_lo;
+        frags_from_words(wa, a_hi, a_lo);
+        frags_from_words(wb, b_hi, b_lo);
+        gphi = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, gphi);
+      }
+
+      // wave-private LDS hand-off of the descriptors (LDS ops of one wave complete in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = acc_row(r, h);
+        float y, dy;
+        gelu_erf_grad(pre[r], y, dy);
+        const float gp = n < cnt ? gphi[r] * dy : 0.f;
+        const float4* src = reinterpret_cast<const float4*>(&lds_desc[wave][n][0]);
+        const float4 d0 = src[0], d1 = src[1];
+        const float2 d2 = *reinterpret_cast<const float2*>(&lds_desc[wave][n][8]);
+        dacc[0] += d0.x * gp, dacc[1] += d0.y * gp, dacc[2] += d0.z * gp, dacc[3] += d0.w * gp;
+        dacc[4] += d1.x * gp, dacc[5] += d1.y * gp, dacc[6] += d1.z * gp, dacc[7] += d1.w * gp;
+        dacc[8] += d2.x * gp, dacc[9] += d2.y * gp;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < kDescExt; ++j) {
+    const float v = dacc[j] + __shfl_xor(dacc[j], 32);
+    if (h == 0) lds_red[wave][j][kcol] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kDescExt * kBasis; i += blockDim.x) {
+    const int j = i / kBasis, k = i % kBasis;
+    partials[(int64_t)blockIdx.x * kDescExt * kBasis + i] =
+        lds_red[0][j][k] + lds_red[1][j][k] + lds_red[2][j][k] + lds_red[3][j][k];
+  }
+}
+
+__global__ void split_pack_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i4);
+    *reinterpret_cast<uint4*>(dst + i4) = make_uint4(split_pack(v.x), split_pack(v.y), split_pack(v.z), split_pack(v.w));
+  } else {
+    for (int64_t i = i4; i < n; ++i) dst[i] = split_pack(src[i]);
+  }
+}
+
+}  // namespace
+
+int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream) {
+  if (n == 0) return SE3_OK;
+  ProfScope prof("split_pack", stream);
+  const int64_t blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n);
+  return check_launch();
+}
+
+int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, const float* axes_ext,
+                       const float* rho, void* t_out, bool out_packed, hipStream_t stream) {
+  const int64_t rows = g.n_ctr * g.f_ctr;
+  if (rows == 0) return SE3_OK;
+  ProfScope prof(tag, stream);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define SE3_LAUNCH(VW)                                                                                              \
+  do {                                                                                                              \
+    if (out_packed)                                                                                                 \
+      hipLaunchKernelGGL((edge_t_bf16_kernel<VW, true>), grid, block, 0, stream, g, feat, channels, axes_ext, rho,  \
+                         t_out, rows);                                                                              \
+    else                                                                                                            \
+      hipLaunchKernelGGL((edge_t_bf16_kernel<VW, false>), grid, block, 0, stream, g, feat, channels, axes_ext, rho, \
+                         t_out, rows);                                                                              \
+  } while (0)
+  if (channels % 128 == 0) SE3_LAUNCH(4);
+  else if (channels % 64 == 0) SE3_LAUNCH(2);
+  else SE3_LAUNCH(1);
+#undef SE3_LAUNCH
+  return check_launch();
+}
+
+int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
+                                const float* axes_ext, const float* rho, const uint32_t* grad_t, float* partials,
+                                int n_partials, hipStream_t stream) {
+  const int64_t rows = g.n_ctr * g.f_ctr;
+  ProfScope prof(tag, stream);
+  hipLaunchKernelGGL(edge_param_grad_bf16_kernel, dim3(n_partials), dim3(256), 0, stream, g, feat, channels, axes_ext,
+                     rho, grad_t, partials, rows);
+  return check_launch();
+}
+
+}  // namespace se3

@@ -182,9 +182,13 @@ int launch_gemm_tn(const char* tag, const float* a, const float* b, float* c, fl
   if (chunk == 0) chunk = 2;
   const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
-  const int64_t count = (int64_t)ka * n;
+  return launch_reduce_partials(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, stream);
+}
+
+int launch_reduce_partials(const float* partials, float* out, int64_t count, int splits, const float* alpha_num,
+                           float alpha_scale, hipStream_t stream) {
   const int rb = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, stream, partials, c, count, splits, alpha_num,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, stream, partials, out, count, splits, alpha_num,
                      alpha_scale);
   return check_launch();
 }

@@ -1,0 +1,264 @@
+// Split-bf16 GEMMs (v_mfma_f32_32x32x16_bf16, 3 products per multiply, fp32 accumulate).
+//
+//   gemm_nn_bf16 : C[M,N]  = alpha * A[M,K] @ B[K,N]     A = packed words (hi<<16|lo), row-major;
+//                  B = the layer's weights, pre-split by prep_weights_kernel into two bf16 planes
+//                  stored transposed, Bt[N][Kp] (Kp = K rounded up to 32, zero padded), so that an
+//                  MFMA B fragment (8 consecutive k of one column) is one 16-byte LDS read.
+//   gemm_tn_bf16 : C[Ka,N] = alpha * A[M,Ka]^T @ B[M,N]  both packed words; reduction over the rows
+//                  (weight gradient).  The k-strided operands go through LDS and are read by column.
+//
+// These are streaming kernels: A (1 GB at the headline shape) is read once, so they are HBM-bound
+// as long as the MFMA side reaches ~1/3 of its peak.
+#include "common.h"
+
+namespace se3 {
+
+namespace {
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int A_LD = BK + 4;   // words; 144-byte pitch keeps 16-byte alignment and spreads ds_read_b128 over all banks
+constexpr int B_LD = BK + 8;   // bf16;  80-byte pitch, same properties
+
+__device__ __forceinline__ uint4 ld4_words(const uint32_t* p, int64_t avail, bool vec) {
+  if (avail >= 4 && vec) return *reinterpret_cast<const uint4*>(p);
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (avail > 0) v.x = p[0];
+  if (avail > 1) v.y = p[1];
+  if (avail > 2) v.z = p[2];
+  if (avail > 3) v.w = p[3];
+  return v;
+}
+
+template <bool OUT_PACKED>
+__global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __restrict__ a,
+                                                           const uint16_t* __restrict__ bt_hi,
+                                                           const uint16_t* __restrict__ bt_lo, void* __restrict__ c,
+                                                           int64_t m, int n, int k, int kp,
+                                                           const float* __restrict__ alpha_num, float alpha_scale) {
+  __shared__ __attribute__((aligned(16))) uint32_t as[2][BM][A_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BN][B_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BN][B_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const bool a_vec = (k % 4) == 0;
+
+  uint4 ra[4], rbh, rbl;
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 32 + (tid >> 3), kq = (tid & 7) * 4;
+      const int64_t gr = m0 + row;
+      ra[p] = gr < m ? ld4_words(a + gr * k + k0 + kq, k - (k0 + kq), a_vec) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int nl = tid >> 2, kq8 = (tid & 3) * 8;
+    if (n0 + nl < n) {
+      rbh = *reinterpret_cast<const uint4*>(bt_hi + (int64_t)(n0 + nl) * kp + k0 + kq8);
+      rbl = *reinterpret_cast<const uint4*>(bt_lo + (int64_t)(n0 + nl) * kp + k0 + kq8);
+    } else {
+      rbh = rbl = make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 32 + (tid >> 3), kq = (tid & 7) * 4;
+      *reinterpret_cast<uint4*>(&as[buf][row][kq]) = ra[p];
+    }
+    const int nl = tid >> 2, kq8 = (tid & 3) * 8;
+    *reinterpret_cast<uint4*>(&bsh[buf][nl][kq8]) = rbh;
+    *reinterpret_cast<uint4*>(&bsl[buf][nl][kq8]) = rbl;
+  };
+
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  const int nk = kp / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kk = 16 * s + 8 * h;
+      const uint4 w0 = *reinterpret_cast<const uint4*>(&as[buf][wave * 32 + rl][kk]);
+      const uint4 w1 = *reinterpret_cast<const uint4*>(&as[buf][wave * 32 + rl][kk + 4]);
+      const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      u32x4 a_hi, a_lo;
+      frags_from_words(w, a_hi, a_lo);
+      const u32x4 b0h = *reinterpret_cast<const u32x4*>(&bsh[buf][rl][kk]);
+      const u32x4 b0l = *reinterpret_cast<const u32x4*>(&bsl[buf][rl][kk]);
+      const u32x4 b1h = *reinterpret_cast<const u32x4*>(&bsh[buf][32 + rl][kk]);
+      const u32x4 b1l = *reinterpret_cast<const u32x4*>(&bsl[buf][32 + rl][kk]);
+      acc0 = mfma_bf16x3(a_hi, a_lo, b0h, b0l, acc0);
+      acc1 = mfma_bf16x3(a_hi, a_lo, b1h, b1l, acc1);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t gr = m0 + wave * 32 + acc_row(r, h);
+    if (gr < m) {
+      const int gc = n0 + rl;
+      if constexpr (OUT_PACKED) {
+        uint32_t* out = static_cast<uint32_t*>(c);
+        if (gc < n) out[gr * n + gc] = split_pack(alpha * acc0[r]);
+        if (gc + 32 < n) out[gr * n + gc + 32] = split_pack(alpha * acc1[r]);
+      } else {
+        float* out = static_cast<float*>(c);
+        if (gc < n) out[gr * n + gc] = alpha * acc0[r];
+        if (gc + 32 < n) out[gr * n + gc + 32] = alpha * acc1[r];
+      }
+    }
+  }
+}
+
+// One block: 128 (ka) x 64 (n) outputs over rows [split*chunk, (split+1)*chunk) in stages of 32 rows.
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __restrict__ a,
+                                                           const uint32_t* __restrict__ b,
+                                                           float* __restrict__ partials, int64_t m, int ka, int n,
+                                                           int64_t chunk) {
+  __shared__ __attribute__((aligned(16))) uint32_t at[2][BK][128];
+  __shared__ __attribute__((aligned(16))) uint32_t bt[2][BK][BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = lane & 31, h = lane >> 5;
+  const int ka0 = blockIdx.x * 128;
+  const int n0 = blockIdx.y * BN;
+  const int64_t mb = (int64_t)blockIdx.z * chunk;
+  const int64_t me = min(m, mb + chunk);
+  const bool b_vec = (n % 4) == 0;
+
+  uint4 ra[4], rb[2];
+  auto load_tile = [&](int64_t mm) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 8 + (tid >> 5), cq = (tid & 31) * 4;
+      const int64_t gr = mm + row;
+      ra[p] = gr < me ? ld4_words(a + gr * ka + ka0 + cq, ka - (ka0 + cq), true) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = p * 16 + (tid >> 4), cq = (tid & 15) * 4;
+      const int64_t gr = mm + row;
+      rb[p] = gr < me ? ld4_words(b + gr * n + n0 + cq, n - (n0 + cq), b_vec) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&at[buf][p * 8 + (tid >> 5)][(tid & 31) * 4]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(&bt[buf][p * 16 + (tid >> 4)][(tid & 15) * 4]) = rb[p];
+  };
+
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  const int64_t nst = me > mb ? (me - mb + BK - 1) / BK : 0;
+  if (nst > 0) {
+    load_tile(mb);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int64_t st = 0; st < nst; ++st) {
+    const int buf = (int)(st & 1);
+    if (st + 1 < nst) load_tile(mb + (st + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint32_t wa[8], wb0[8], wb1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = 16 * s + 8 * h + j;
+        wa[j] = at[buf][row][wave * 32 + rl];
+        wb0[j] = bt[buf][row][rl];
+        wb1[j] = bt[buf][row][32 + rl];
+      }
+      u32x4 a_hi, a_lo, b_hi, b_lo;
+      frags_from_words(wa, a_hi, a_lo);
+      frags_from_words(wb0, b_hi, b_lo);
+      acc0 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc0);
+      frags_from_words(wb1, b_hi, b_lo);
+      acc1 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc1);
+    }
+    if (st + 1 < nst) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  float* out = partials + (int64_t)blockIdx.z * ka * n;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ka0 + wave * 32 + acc_row(r, h);
+    if (row < ka) {
+      if (n0 + rl < n) out[(int64_t)row * n + n0 + rl] = acc0[r];
+      if (n0 + 32 + rl < n) out[(int64_t)row * n + n0 + 32 + rl] = acc1[r];
+    }
+  }
+}
+
+// Bt[nn][kk] (two bf16 planes, pitch kp) from the layer weights W[C_in, K, C_out]:
+//   mode 0 (out = T W)      : nn = o,          kk = i*K + k     value W[i,k,o]
+//   mode 1 (gT = g W^T)     : nn = i*K + k,    kk = o           value W[i,k,o]
+//   mode 2 (dX = U W')      : nn = i,          kk = o*K + k     value W[i,k,o]
+__global__ void prep_weights_kernel(const float* __restrict__ w, int c_in, int kb, int c_out, int mode, int n, int k,
+                                    int kp, uint16_t* __restrict__ bt_hi, uint16_t* __restrict__ bt_lo) {
+  const int64_t total = (int64_t)n * kp;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int nn = (int)(idx / kp), kk = (int)(idx % kp);
+    float v = 0.f;
+    if (kk < k) {
+      if (mode == 0) v = w[(int64_t)kk * c_out + nn];
+      else if (mode == 1) v = w[(int64_t)nn * c_out + kk];
+      else v = w[((int64_t)nn * kb + (kk % kb)) * c_out + kk / kb];
+    }
+    const uint32_t pk = split_pack(v);
+    bt_hi[idx] = (uint16_t)(pk >> 16);
+    bt_lo[idx] = (uint16_t)(pk & 0xffffu);
+  }
+}
+
+}  // namespace
+
+int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
+                        hipStream_t stream) {
+  int n, k;
+  if (mode == 0) n = c_out, k = c_in * kb;
+  else if (mode == 1) n = c_in * kb, k = c_out;
+  else n = c_in, k = c_out * kb;
+  const int kp = (k + 31) / 32 * 32;
+  const int64_t total = (int64_t)n * kp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, c_in, kb, c_out, mode, n, k, kp, bt_hi,
+                     bt_lo);
+  return check_launch();
+}
+
+int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
+                        bool out_packed, int64_t m, int n, int k, const float* alpha_num, float alpha_scale,
+                        hipStream_t stream) {
+  if (m == 0 || n == 0) return SE3_OK;
+  ProfScope prof(tag, stream);
+  const int kp = (k + 31) / 32 * 32;
+  const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN - 1) / BN));
+  if (out_packed)
+    hipLaunchKernelGGL(gemm_nn_bf16_kernel<true>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp, alpha_num,
+                       alpha_scale);
+  else
+    hipLaunchKernelGGL(gemm_nn_bf16_kernel<false>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp,
+                       alpha_num, alpha_scale);
+  return check_launch();
+}
+
+int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream) {
+  if (ka == 0 || n == 0) return SE3_OK;
+  ProfScope prof(tag, stream);
+  int64_t chunk = (m + splits - 1) / splits;
+  chunk = (chunk + BK - 1) / BK * BK;
+  if (chunk == 0) chunk = BK;
+  const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  return launch_reduce_partials(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, stream);
+}
+
+}  // namespace se3

@@ -16,6 +16,27 @@ from . import _lib
 from ._lib import Se3Shape
 
 
+# ------------------------------------------------------------------------------------- precision
+# Arithmetic of the operator's contractions (include/se3conv.h, SE3_PRECISION_*): "bf16x3" = split-bf16
+# MFMA with fp32 accumulate (~1e-5 rel. to the fp32 reference, the default), "fp32" = exact-fp32 MFMA.
+import os as _os
+
+_precision = _os.environ.get("SE3CONV_PRECISION", "bf16x3")
+if _precision not in _lib.PRECISIONS:
+    raise ValueError(f"SE3CONV_PRECISION={_precision!r}; expected one of {sorted(_lib.PRECISIONS)}")
+
+
+def set_precision(name: str) -> None:
+    global _precision
+    if name not in _lib.PRECISIONS:
+        raise ValueError(f"precision {name!r}; expected one of {sorted(_lib.PRECISIONS)}")
+    _precision = name
+
+
+def get_precision() -> str:
+    return _precision
+
+
 # --------------------------------------------------------------------------------------- helpers
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -195,9 +216,10 @@ class ConvGeometry:
             self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0])
         return self._transpose
 
-    def shape(self, c_in: int, c_out: int, num_basis: int) -> Se3Shape:
+    def shape(self, c_in: int, c_out: int, num_basis: int, precision: Optional[str] = None) -> Se3Shape:
         return Se3Shape(self.pts_in.shape[0], self.pts_out.shape[0], self.neighbors.shape[0],
-                        self.frames_in.shape[1], self.frames_out.shape[1], c_in, c_out, num_basis)
+                        self.frames_in.shape[1], self.frames_out.shape[1], c_in, c_out, num_basis,
+                        _lib.PRECISIONS[precision or _precision])
 
 
 def _geom_ptrs(g: ConvGeometry):
@@ -213,8 +235,10 @@ def _scalar(t, name, dev) -> torch.Tensor:
     return t.detach().to(device=dev, dtype=torch.float32).reshape(()).contiguous()
 
 
-def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weights, rho, nu, save_t: bool = True):
-    """Raw forward: returns ``(out [N_out*F_out, C_out], T or None)``."""
+def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weights, rho, nu, save_t: bool = True,
+                    precision: Optional[str] = None):
+    """Raw forward: returns ``(out [N_out*F_out, C_out], T or None)``.  ``T`` is fp32 in "fp32" precision
+    and an opaque same-size buffer of packed hi/lo words in "bf16x3" (pass it back with the same precision)."""
     lib = _lib.load()
     f32 = torch.float32
     dev = geom.pts_out.device
@@ -226,7 +250,7 @@ def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weigh
     if feat.shape != (geom.pts_in.shape[0] * geom.frames_in.shape[1], c_in):
         raise ValueError(f"features are {tuple(feat.shape)}, expected "
                          f"({geom.pts_in.shape[0] * geom.frames_in.shape[1]}, {c_in})")
-    shp = geom.shape(c_in, c_out, kb)
+    shp = geom.shape(c_in, c_out, kb, precision)
     rows = geom.pts_out.shape[0] * geom.frames_out.shape[1]
     out = torch.empty((rows, c_out), dtype=f32, device=dev)
     t_save = torch.empty((rows, c_in, kb), dtype=f32, device=dev) if save_t else None
@@ -241,7 +265,7 @@ def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weigh
 
 
 def se3conv_backward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weights, rho, nu, t_save, grad_out,
-                     want_feat=True, want_params=True):
+                     want_feat=True, want_params=True, precision: Optional[str] = None):
     """Raw backward: returns ``(dX, dA, dbeta, dW)`` (None where not requested)."""
     lib = _lib.load()
     f32, i32 = torch.float32, torch.int32
@@ -250,7 +274,7 @@ def se3conv_backward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weig
     a, b, w = _as(proj_axes, f32), _as(proj_biases, f32), _as(conv_weights, f32)
     g = _as(grad_out, f32)
     c_in, kb, c_out = w.shape
-    shp = geom.shape(c_in, c_out, kb)
+    shp = geom.shape(c_in, c_out, kb, precision)
     d_x = torch.empty_like(feat) if want_feat else None
     d_a = torch.empty_like(a) if want_params else None
     d_b = torch.empty_like(b) if want_params else None
@@ -278,8 +302,9 @@ class SE3ConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, proj_axes, proj_biases, conv_weights, geom: ConvGeometry, rho, nu):
         need_params = any(ctx.needs_input_grad[1:4])
+        ctx.precision = _precision
         out, t_save = se3conv_forward(geom, feat, proj_axes, proj_biases, conv_weights, rho, nu,
-                                      save_t=need_params)
+                                      save_t=need_params, precision=ctx.precision)
         ctx.geom = geom
         ctx.in_dtype = feat.dtype
         ctx.save_for_backward(feat, proj_axes, proj_biases, conv_weights, _scalar(rho, "rho", out.device),
@@ -293,7 +318,7 @@ class SE3ConvFunction(torch.autograd.Function):
         want_feat = ctx.needs_input_grad[0]
         want_params = any(ctx.needs_input_grad[1:4])
         d_x, d_a, d_b, d_w = se3conv_backward(ctx.geom, feat, a, b, w, rho, nu, t_save if ctx.has_t else None,
-                                              grad_out, want_feat, want_params)
+                                              grad_out, want_feat, want_params, precision=ctx.precision)
         if d_x is not None:
             d_x = d_x.to(ctx.in_dtype)
         ng = ctx.needs_input_grad

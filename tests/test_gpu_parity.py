@@ -16,15 +16,25 @@ from oracle import se3conv_oracle as O
 
 pytestmark = pytest.mark.gpu
 FILES = golden_layer_files()
-TOL = 2e-5
 DEV = "cuda:0"
+# ||d||/||ref|| bounds per arithmetic mode.  The north star allows 1e-4.  "fp32" (exact-fp32 MFMA) only
+# differs from the oracle by summation order; "bf16x3" (split-bf16 MFMA, the default) carries 16
+# significant bits per operand: measured ~1e-5, held to 5e-5 here.
+TOLS = {"fp32": 2e-5, "bf16x3": 5e-5}
+TOL = 2e-5  # tests of the fp32-only ops (FeatBasisProj, rot tensors)
 
 
-@pytest.fixture(scope="module")
-def amd(built_library):
+@pytest.fixture(scope="module", params=["bf16x3", "fp32"])
+def amd(built_library, request):
     import se3conv3d_amd
 
-    return se3conv3d_amd
+    se3conv3d_amd.set_precision(request.param)
+    yield se3conv3d_amd
+    se3conv3d_amd.set_precision("bf16x3")
+
+
+def tol(amd):
+    return TOLS[amd.get_precision()]
 
 
 def clouds_from(d, amd):
@@ -68,11 +78,11 @@ def test_layer_forward_backward_matches_golden(path, amd):
     out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=nbh)
     assert out.shape == d["out"].shape and out.dtype == torch.float32 and out.is_cuda
     out.backward(d["grad_out"].to(DEV))
-    assert rel_err(out, d["out"]) < TOL
-    assert rel_err(x.grad, d["dx"]) < TOL
-    assert rel_err(conv.proj_axes_.grad, d["dA"]) < TOL
-    assert rel_err(conv.proj_biases_.grad, d["dbeta"]) < TOL
-    assert rel_err(conv.conv_weights_.grad, d["dW"]) < TOL
+    assert rel_err(out, d["out"]) < tol(amd)
+    assert rel_err(x.grad, d["dx"]) < tol(amd)
+    assert rel_err(conv.proj_axes_.grad, d["dA"]) < tol(amd)
+    assert rel_err(conv.proj_biases_.grad, d["dbeta"]) < tol(amd)
+    assert rel_err(conv.conv_weights_.grad, d["dW"]) < tol(amd)
 
 
 @pytest.mark.parametrize("path", FILES[:4], ids=[os.path.basename(f) for f in FILES[:4]])
@@ -151,11 +161,11 @@ def test_random_shapes_against_oracle(case, amd):
     a, b, w = (c[k].to(DEV).requires_grad_(True) for k in ("a", "b", "w"))
     out = amd.SE3ConvFunction.apply(x, a, b, w, geom, rho, nu)
     out.backward(c["go"].to(DEV))
-    assert rel_err(out, out_r) < TOL
-    assert rel_err(x.grad, dx_r) < TOL
-    assert rel_err(a.grad, da_r) < TOL
-    assert rel_err(b.grad, db_r) < TOL
-    assert rel_err(w.grad, dw_r) < TOL
+    assert rel_err(out, out_r) < tol(amd)
+    assert rel_err(x.grad, dx_r) < tol(amd)
+    assert rel_err(a.grad, da_r) < tol(amd)
+    assert rel_err(b.grad, db_r) < tol(amd)
+    assert rel_err(w.grad, dw_r) < tol(amd)
 
     # the source-major edge list is a permutation of the edges, grouped by source, samples ascending
     ts, te = geom.transpose()
@@ -177,11 +187,11 @@ def test_features_only_backward_and_frozen_params(amd):
     x = c["x"].to(DEV).requires_grad_(True)
     out = amd.SE3ConvFunction.apply(x, c["a"].to(DEV), c["b"].to(DEV), c["w"].to(DEV), geom, rho, nu)
     out.backward(c["go"].to(DEV))
-    assert rel_err(x.grad, dx_r) < TOL
+    assert rel_err(x.grad, dx_r) < tol(amd)
     w = c["w"].to(DEV).requires_grad_(True)
     out = amd.SE3ConvFunction.apply(c["x"].to(DEV), c["a"].to(DEV), c["b"].to(DEV), w, geom, rho, nu)
     out.backward(c["go"].to(DEV))
-    assert rel_err(w.grad, dw_r) < TOL
+    assert rel_err(w.grad, dw_r) < tol(amd)
 
 
 def test_empty_rows_and_empty_graph(amd):
@@ -201,7 +211,7 @@ def test_empty_rows_and_empty_graph(amd):
     out, _ = amd.ops.se3conv_forward(geom, x.to(DEV), a.to(DEV), b.to(DEV), w.to(DEV), 3.0, 0.1)
     ref = O.conv_forward(pts_in, pts_out, fi, fo, nb_r, x, a, b, w, torch.tensor(3.0), torch.tensor(0.1))
     assert out.shape == (66, 32) and float(out[-6:].abs().max()) == 0.0
-    assert rel_err(out, ref) < TOL
+    assert rel_err(out, ref) < tol(amd)
     # radius so small that only self-edges exist for a different output cloud: E = 0
     nb0, ends0 = amd.ops.ball_query(pts_in.to(DEV), pts_out.to(DEV), z_in.to(DEV), z_out.to(DEV), 1e-4)
     assert nb0.shape == (0, 2) and int(ends0.sum()) == 0
@@ -294,11 +304,11 @@ def test_headline_rotation_invariance_and_linearity(headline, amd):
         nbh_r = amd.pc.BQNeighborhood.__new__(amd.pc.BQNeighborhood)  # same graph: distances are preserved
         nbh_r.neighbors_, nbh_r.start_ids_, nbh_r.radius_ = nbh.neighbors_, nbh.start_ids_, nbh.radius_
         out_r = conv(p_pc_in=pc_r, p_pc_out=pc_r, p_in_features=x, p_neighborhood=nbh_r)
-        assert rel_err(out_r, out) < 2e-5
+        assert rel_err(out_r, out) < tol(amd)
         x2 = torch.randn_like(x)
         lin = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=2.0 * x - 0.5 * x2, p_neighborhood=nbh)
         out2 = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x2, p_neighborhood=nbh)
-        assert rel_err(lin, 2.0 * out - 0.5 * out2) < 2e-5
+        assert rel_err(lin, 2.0 * out - 0.5 * out2) < tol(amd)
     # adjoint identity <conv(x), g> == <x, conv^T(g)> ties backward to forward at full size
     xg = x.clone().requires_grad_(True)
     o = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=xg, p_neighborhood=nbh)
@@ -306,10 +316,10 @@ def test_headline_rotation_invariance_and_linearity(headline, amd):
     o.backward(g)
     lhs = float((o.detach().double() * g.double()).sum())
     rhs = float((x.double() * xg.grad.double()).sum())
-    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
+    assert abs(lhs - rhs) <= tol(amd) * max(abs(lhs), abs(rhs), 1.0)
     # Euler identity for the weights: out is linear in W  =>  <W, dW> == <out, g>
     wdot = float((conv.conv_weights_.detach().double() * conv.conv_weights_.grad.double()).sum())
-    assert abs(wdot - lhs) <= 2e-5 * max(abs(lhs), 1.0)
+    assert abs(wdot - lhs) <= tol(amd) * max(abs(lhs), 1.0)
 
 
 def test_headline_subset_against_oracle(headline, amd):
@@ -325,4 +335,4 @@ def test_headline_subset_against_oracle(headline, amd):
     ref = O.conv_forward(pc.pts_.cpu(), pc.pts_[sel].cpu(), pc.local_frames_.cpu(), pc.local_frames_[sel].cpu(), nb,
                          x.cpu(), conv.proj_axes_.detach().cpu(), conv.proj_biases_.detach().cpu(),
                          conv.conv_weights_.detach().cpu(), conv.norm_neigh_dist_.cpu(), conv.norm_num_neighs_.cpu())
-    assert rel_err(out[int(sel[0]) * 2:(int(sel[-1]) + 1) * 2], ref) < TOL
+    assert rel_err(out[int(sel[0]) * 2:(int(sel[-1]) + 1) * 2], ref) < tol(amd)
