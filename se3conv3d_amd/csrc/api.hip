@@ -185,6 +185,9 @@ int shape_supported(const se3conv_shape* s) {
   if (s->n_in * s->f_in >= (1ll << 31) || s->n_out * s->f_out >= (1ll << 31) ||
       s->n_edges * s->f_in * s->f_out >= (1ll << 31))
     return SE3_ERR_UNSUPPORTED;  // row / frame-edge ids are int32 inside the kernels
+  if (s->precision == SE3_PRECISION_BF16X3 &&
+      (s->n_in * s->f_in * s->c_in >= (1ll << 30) || s->n_out * s->f_out * s->c_out >= (1ll << 30)))
+    return SE3_ERR_UNSUPPORTED;  // gathered operands are addressed with 32-bit byte offsets
   return SE3_OK;
 }
 
@@ -366,7 +369,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   if (int rc = launch_split_pack(feat, featpk, s->n_in * s->f_in * s->c_in, stream)) return rc;
   if (int rc = launch_prep_weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, stream)) return rc;
-  if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, axes_ext, rho, t, true, stream)) return rc;
+  if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream)) return rc;
   return launch_gemm_nn_bf16("gemm_out", (const uint32_t*)t, bt_hi, bt_lo, out, false, rows_out, s->c_out, ck, nu,
                              inv_fin, stream);
 }
@@ -477,7 +480,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       const uint32_t* t = (const uint32_t*)t_save;
       if (!t) {
         uint32_t* tt = (uint32_t*)(ws + l.t);
-        if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, axes_ext, rho, tt, true, stream)) return rc;
+        if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, rows_in, axes_ext, rho, tt, stream)) return rc;
         t = tt;
       }
       if (int rc = launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck,
@@ -486,7 +489,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     }
   }
   if (want_feat && rows_in > 0) {
-    if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, axes_ext, rho, bigw, true, stream)) return rc;
+    if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, bigw, stream)) return rc;
     if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, bt_hi, bt_lo, stream)) return rc;
     if (int rc = launch_gemm_nn_bf16("gemm_gradX", bigw, bt_hi, bt_lo, grad_feat, false, rows_in, s->c_in,
                                      s->c_out * kb, nu, inv_fin, stream))

@@ -177,8 +177,8 @@ int launch_reduce_partials(const float* partials, float* out, int64_t count, int
 
 // split-bf16 path (edge_bf16.hip, gemm_bf16.hip)
 int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream);
-int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, const float* axes_ext,
-                       const float* rho, void* t_out, bool out_packed, hipStream_t stream);
+int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
+                       const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 const float* axes_ext, const float* rho, const uint32_t* grad_t, float* partials,
                                 int n_partials, hipStream_t stream);

@@ -69,96 +69,190 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], int
 }
 
 // ------------------------------------------------------------------------------------------------
-// T[m, c, k] = sum_n feat[q(n), c] * GELU(desc(n) . A + beta)[k];   feat and T are packed words
-// (OUT_PACKED) or T is plain fp32.
+// T[m, c, k] = sum_n feat[q(n), c] * GELU(desc(n) . A + beta)[k];   feat and T are packed words.
+//
+// One wavefront owns FC (1 or 2) frames of one centre point, i.e. FC output rows that share their
+// neighbour list: the gather of the neighbours' geometry, the source-row lookups and the gathered
+// feature fragments (the MFMA A operand) are done once and used for both rows.  With FC = 2 lane
+// half h computes the descriptor against centre frame a0 + h, so no descriptor is computed twice:
+// for row a the half h == a supplies descriptor dims 0..7 of the MLP's k-dimension and the other
+// half supplies dims 8, 9 (the bias slot), its dim-8 value arriving through one v_permlane32_swap;
+// the MLP weights are held in both arrangements.
+// VALU is the bound of this kernel (MFMA ~15 % busy), so everything here is about instruction count:
+// 32-bit buffer addressing, ds_bpermute for the per-row source offsets, branch-free GELU.
 // ------------------------------------------------------------------------------------------------
-template <int VW, bool OUT_PACKED>
-__global__ __launch_bounds__(256) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
-                                                          const float* __restrict__ axes_ext,
-                                                          const float* __restrict__ rho_p, void* __restrict__ t_out,
-                                                          int64_t rows) {
-  const int lane = threadIdx.x & 63;
-  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= rows) return;
-  const int kcol = lane & 31, h = lane >> 5;
-  const float rho = *rho_p;
-  u32x4 w_hi, w_lo;
-  load_mlp_weights(axes_ext, kcol, h, w_hi, w_lo);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, int64_t bytes) {
+  const uint32_t n = bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)n, 0x00020000);
+}
 
-  const RowInfo ri = row_info(g, m);
+template <int VW, int FC, bool FULL>
+__global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
+                                                          int64_t feat_rows, const float* __restrict__ axes_ext,
+                                                          const float* __restrict__ rho_p,
+                                                          uint32_t* __restrict__ t_out, int64_t n_items,
+                                                          int fnb_shift) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (item >= n_items) return;
+  const int kcol = lane & 31, h = lane >> 5;
+  const int groups = g.f_ctr / FC;
+  const int64_t ctr = item / groups;
+  const int a0 = (int)(item - ctr * groups) * FC;
+  const float rho = *rho_p;
+
+  // MLP weights [A; beta] as the MFMA B operand: arrangement `lo_first` has dims 0..7 in half 0.
+  u32x4 wb_hi[FC], wb_lo[FC];
+  {
+    float v07[8], v89[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v07[j] = axes_ext[j * kBasis + kcol];
+      v89[j] = j < 2 ? axes_ext[(8 + j) * kBasis + kcol] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+      const bool dims07 = FC == 1 ? h == 0 : h == a;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = dims07 ? v07[j] : v89[j];
+      frags_from_floats(v, wb_hi[a], wb_lo[a]);
+    }
+  }
+
+  const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
+  const int n_total = (g.ends[ctr] - start) * g.f_nb;
   float yc[3], rc[9];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ri.ctr * 3 + i];
+  for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
+  {
+    const int64_t fr = ctr * g.f_ctr + a0 + (FC == 2 ? h : 0);  // the centre frame this lane builds descriptors for
 #pragma unroll
-  for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[m * 9 + i];
+    for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[fr * 9 + i];
+  }
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * channels * 4);
+  const int row_bytes = channels * 4;
+  const int hb = 16 * h;  // ds_bpermute byte address of lane 4h
 
   for (int cbase = 0; cbase < channels; cbase += 32 * VW) {
     const int cb = cbase + VW * kcol;
-    const bool ch_ok = cb < channels;  // channels % VW == 0 => the whole vector is valid or not
-    const int cb_ld = ch_ok ? cb : 0;
-    f32x16 acc[VW];
+    const bool ch_ok = FULL || cb < channels;
+    const int cb4 = (ch_ok ? cb : 0) * 4;
+    f32x16 acc[FC][VW];
 #pragma unroll
-    for (int t = 0; t < VW; ++t) acc[t] = zero16();
+    for (int a = 0; a < FC; ++a)
+#pragma unroll
+      for (int t = 0; t < VW; ++t) acc[a][t] = zero16();
 
-    for (int c0 = 0; c0 < ri.n_total; c0 += 32) {
-      const int cnt = min(32, ri.n_total - c0);
+    for (int c0 = 0; c0 < n_total; c0 += 32) {
+      const int cnt = min(32, n_total - c0);
       const int fe = c0 + min(kcol, cnt - 1);
-      float d[kDescExt];
-      int q;
-      lane_descriptor(g, ri, fe, yc, rc, rho, d, q);
-      f32x16 phi = mlp_preactivation(d, h, w_hi, w_lo);
+      int e, fn;
+      if (fnb_shift >= 0) {
+        e = start + (fe >> fnb_shift);
+        fn = fe & ((1 << fnb_shift) - 1);
+      } else {
+        e = start + fe / g.f_nb;
+        fn = fe % g.f_nb;
+      }
+      const int nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+      const int q = nb * g.f_nb + fn;
+      const int qoff = q * row_bytes;
+      float xn[3], rn[9], d[9];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) phi[r] = acc_row(r, h) < cnt ? gelu_erf(phi[r]) : 0.f;
+      for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+      if (!g.transposed)
+        edge_descriptor(xn, rn, yc, rc, rho, d);
+      else
+        edge_descriptor(yc, rc, xn, rn, rho, d);
 
+      // MLP A operand pieces of this lane: its own dims 0..7, and {dim 8 of the row it serves as "other" half, 1}
+      u32x4 own_hi, own_lo, oth_hi, oth_lo;
+      frags_from_floats(d, own_hi, own_lo);
+      {
+        float d8 = d[8];
+        if constexpr (FC == 2) {
+          // lanes of half h hold the descriptor against frame a0+h; row a's dims 8,9 live in half 1-a
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
+          d8 = __uint_as_float(h ? sw[0] : sw[1]);
+        }
+        uint32_t p_hi, p_lo;
+        split2(d8, 1.0f, p_hi, p_lo);
+        oth_hi = u32x4{p_hi, 0u, 0u, 0u};
+        oth_lo = u32x4{p_lo, 0u, 0u, 0u};
+      }
+
+      // gathered feature fragments of the chunk's two k-steps (shared by the FC rows)
+      u32x4 fa_hi[2][VW], fa_lo[2][VW];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s * 16 < cnt) {  // wave-uniform
           uint32_t w[VW][8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const int r = 8 * s + j;
-            const int q_lo = __builtin_amdgcn_readlane(q, acc_row(r, 0));
-            const int q_hi = __builtin_amdgcn_readlane(q, acc_row(r, 1));
-            const uint32_t* src = feat + (int64_t)(h ? q_hi : q_lo) * channels + cb_ld;
+            // byte offset of the source row of frame-edge acc_row(8s+j, h), fetched from the lane that owns it
+            const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+            const int voff = src_off + cb4;
             if constexpr (VW == 4) {
-              const uint4 v = *reinterpret_cast<const uint4*>(src);
-              w[0][j] = v.x, w[1][j] = v.y, w[2][j] = v.z, w[3][j] = v.w;
+              const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
+              w[0][j] = v[0], w[1][j] = v[1], w[2][j] = v[2], w[3][j] = v[3];
             } else if constexpr (VW == 2) {
-              const uint2 v = *reinterpret_cast<const uint2*>(src);
-              w[0][j] = v.x, w[1][j] = v.y;
+              const auto v = __builtin_amdgcn_raw_buffer_load_b64(feat_rs, voff, 0, 0);
+              w[0][j] = v[0], w[1][j] = v[1];
             } else {
-              w[0][j] = *src;
+              w[0][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, voff, 0, 0);
             }
           }
-          float pv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pv[j] = phi[8 * s + j];
-          u32x4 b_hi, b_lo;
-          frags_from_floats(pv, b_hi, b_lo);
 #pragma unroll
           for (int t = 0; t < VW; ++t) {
-            u32x4 a_hi, a_lo;
-            frags_from_words(w[t], a_hi, a_lo);
-            if (!ch_ok) a_hi = a_lo = u32x4{0u, 0u, 0u, 0u};
-            acc[t] = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc[t]);
+            frags_from_words(w[t], fa_hi[s][t], fa_lo[s][t]);
+            if (!ch_ok) fa_hi[s][t] = fa_lo[s][t] = u32x4{0u, 0u, 0u, 0u};
+          }
+        }
+      }
+
+#pragma unroll
+      for (int a = 0; a < FC; ++a) {
+        const bool dims07 = FC == 1 ? h == 0 : h == a;
+        u32x4 a_hi, a_lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
+          a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
+        }
+        f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi[a], wb_lo[a], zero16());
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s * 16 < cnt) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float y = gelu_erf(phi[8 * s + j]);
+              asm volatile("" : "+v"(y));  // keep the GELU unconditional (no exec-masked branch per register)
+              pv[j] = acc_row(8 * s + j, h) < cnt ? y : 0.f;
+            }
+            u32x4 b_hi, b_lo;
+            frags_from_floats(pv, b_hi, b_lo);
+#pragma unroll
+            for (int t = 0; t < VW; ++t) acc[a][t] = mfma_bf16x3(fa_hi[s][t], fa_lo[s][t], b_hi, b_lo, acc[a][t]);
           }
         }
       }
     }
-    // acc[t] register r, lane (kcol, h) = T[m][cbase + VW*acc_row(r,h) + t][kcol]
+    // acc[a][t] register r, lane (kcol, h) = T[row a][cbase + VW*acc_row(r,h) + t][kcol]
 #pragma unroll
-    for (int t = 0; t < VW; ++t)
+    for (int a = 0; a < FC; ++a) {
+      uint32_t* t_row = t_out + ((ctr * g.f_ctr + a0 + a) * (int64_t)channels) * kBasis;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = cbase + VW * acc_row(r, h) + t;
-        if (ch < channels) {
-          const int64_t o = (m * channels + ch) * kBasis + kcol;
-          if constexpr (OUT_PACKED)
-            static_cast<uint32_t*>(t_out)[o] = split_pack(acc[t][r]);
-          else
-            static_cast<float*>(t_out)[o] = acc[t][r];
+      for (int t = 0; t < VW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = cbase + VW * acc_row(r, h) + t;
+          if (FULL || ch < channels) t_row[ch * kBasis + kcol] = split_pack(acc[a][t][r]);
         }
-      }
+    }
   }
 }
 
@@ -290,24 +384,30 @@ int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t st
   return check_launch();
 }
 
-int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, const float* axes_ext,
-                       const float* rho, void* t_out, bool out_packed, hipStream_t stream) {
+int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
+                       const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (rows == 0) return SE3_OK;
   ProfScope prof(tag, stream);
-  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define SE3_LAUNCH(VW)                                                                                              \
-  do {                                                                                                              \
-    if (out_packed)                                                                                                 \
-      hipLaunchKernelGGL((edge_t_bf16_kernel<VW, true>), grid, block, 0, stream, g, feat, channels, axes_ext, rho,  \
-                         t_out, rows);                                                                              \
-    else                                                                                                            \
-      hipLaunchKernelGGL((edge_t_bf16_kernel<VW, false>), grid, block, 0, stream, g, feat, channels, axes_ext, rho, \
-                         t_out, rows);                                                                              \
-  } while (0)
-  if (channels % 128 == 0) SE3_LAUNCH(4);
-  else if (channels % 64 == 0) SE3_LAUNCH(2);
-  else SE3_LAUNCH(1);
+  // two frames per wavefront share the gather; with 4 channel tiles per frame that would spill, so VW = 4 stays at 1
+  const int fc = (g.f_ctr % 2 == 0 && channels % 128 != 0) ? 2 : 1;
+  const int64_t items = rows / fc;
+  int shift = -1;
+  for (int sft = 0; sft < 8; ++sft)
+    if ((1 << sft) == g.f_nb) shift = sft;
+  const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+#define SE3_LAUNCH(VW, FC, FULL)                                                                                      \
+  hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL>), grid, block, 0, stream, g, feat, channels, feat_rows,          \
+                     axes_ext, rho, t_out, items, shift)
+  if (channels % 128 == 0) {
+    SE3_LAUNCH(4, 1, true);
+  } else if (channels % 64 == 0) {
+    if (fc == 2) SE3_LAUNCH(2, 2, true); else SE3_LAUNCH(2, 1, true);
+  } else if (channels % 32 == 0) {
+    if (fc == 2) SE3_LAUNCH(1, 2, true); else SE3_LAUNCH(1, 1, true);
+  } else {
+    if (fc == 2) SE3_LAUNCH(1, 2, false); else SE3_LAUNCH(1, 1, false);
+  }
 #undef SE3_LAUNCH
   return check_launch();
 }
