@@ -191,7 +191,7 @@ int shape_supported(const se3conv_shape* s) {
   return SE3_OK;
 }
 
-struct FwdLayout { size_t axes_ext, t, featpk, bt_hi, bt_lo, total; };
+struct FwdLayout { size_t axes_ext, t, featpk, bt_hi, bt_lo, split, total; };
 FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
   FwdLayout l{};
   size_t off = 0;
@@ -204,13 +204,14 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
     const size_t plane = (size_t)s->c_out * align_up((size_t)s->c_in * kb, 32) * 2;
     l.bt_hi = take(plane);
     l.bt_lo = take(plane);
+    l.split = take(gemm_nn_bf16_split_bytes((int64_t)s->n_out * s->f_out, s->c_out, s->c_in * (int)kb));
   }
   l.total = off;
   return l;
 }
 
 struct BwdLayout {
-  size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, total;
+  size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, split, total;
   int n_param_partials, tn_splits;
 };
 BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
@@ -234,6 +235,10 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     l.bt_lo = take(plane);
     l.featpk = want_params ? take(rows_in * s->c_in * 4) : 0;
     l.gpk = take(rows_out * s->c_out * 4);
+    size_t sp = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_out, s->c_in * (int)kb, s->c_out) : 0;
+    const size_t sp2 = want_feat ? gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb) : 0;
+    if (sp2 > sp) sp = sp2;
+    l.split = take(sp);
   }
   size_t big = 0;
   if (want_params) big = rows_out * s->c_in * kb * 4;
@@ -370,8 +375,8 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   if (int rc = launch_split_pack(feat, featpk, s->n_in * s->f_in * s->c_in, stream)) return rc;
   if (int rc = launch_prep_weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, stream)) return rc;
   if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream)) return rc;
-  return launch_gemm_nn_bf16("gemm_out", (const uint32_t*)t, bt_hi, bt_lo, out, false, rows_out, s->c_out, ck, nu,
-                             inv_fin, stream);
+  return launch_gemm_nn_bf16("gemm_out", (const uint32_t*)t, bt_hi, bt_lo, out, false, rows_out, s->c_out, ck,
+                             (float*)(ws + l.split), nu, inv_fin, stream);
 }
 
 extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
@@ -466,8 +471,8 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     uint32_t* featpk = (uint32_t*)(ws + l.featpk);
     if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
     if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, stream)) return rc;
-    if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out, nu, inv_fin,
-                                     stream))
+    if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
+                                     (float*)(ws + l.split), nu, inv_fin, stream))
       return rc;
     if (grad_axes || grad_biases) {
       if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, axes_ext, rho, bigw, partials,
@@ -492,7 +497,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, bigw, stream)) return rc;
     if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, bt_hi, bt_lo, stream)) return rc;
     if (int rc = launch_gemm_nn_bf16("gemm_gradX", bigw, bt_hi, bt_lo, grad_feat, false, rows_in, s->c_in,
-                                     s->c_out * kb, nu, inv_fin, stream))
+                                     s->c_out * kb, (float*)(ws + l.split), nu, inv_fin, stream))
       return rc;
   }
   return check_launch();

@@ -60,6 +60,13 @@ __device__ __forceinline__ uint32_t split_pack(float x) {
 // packed words w0, w1 -> packed pair of hi parts / of lo parts (element 0 = w0)
 __device__ __forceinline__ uint32_t pair_hi(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x07060302u); }
 __device__ __forceinline__ uint32_t pair_lo(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x05040100u); }
+// two values -> their two packed words, sharing the conversions (4 VALU per value instead of 7)
+__device__ __forceinline__ void split_pack2(float x0, float x1, uint32_t& w0, uint32_t& w1) {
+  uint32_t hi, lo;
+  split2(x0, x1, hi, lo);
+  w0 = pair_lo(lo, hi);
+  w1 = pair_hi(lo, hi);
+}
 // 8 packed words -> the two 8 x bf16 MFMA fragments
 __device__ __forceinline__ void frags_from_words(const uint32_t w[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
@@ -185,8 +192,9 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream);
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
-                        bool out_packed, int64_t m, int n, int k, const float* alpha_num, float alpha_scale,
-                        hipStream_t stream);
+                        bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
+                        float alpha_scale, hipStream_t stream);
+size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k);
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
                         int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream);
 

@@ -92,18 +92,12 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
                                                           const float* __restrict__ rho_p,
                                                           uint32_t* __restrict__ t_out, int64_t n_items,
                                                           int fnb_shift) {
+  // MLP weights [A; beta] as MFMA B fragments, kept in LDS (16 VGPRs otherwise): arrangement a has
+  // descriptor dims 0..7 in the lane half that builds row a's descriptors.
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
   const int lane = threadIdx.x & 63;
-  const int64_t item = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (item >= n_items) return;
   const int kcol = lane & 31, h = lane >> 5;
-  const int groups = g.f_ctr / FC;
-  const int64_t ctr = item / groups;
-  const int a0 = (int)(item - ctr * groups) * FC;
-  const float rho = *rho_p;
-
-  // MLP weights [A; beta] as the MFMA B operand: arrangement `lo_first` has dims 0..7 in half 0.
-  u32x4 wb_hi[FC], wb_lo[FC];
-  {
+  if (threadIdx.x < 64) {
     float v07[8], v89[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -116,9 +110,19 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = dims07 ? v07[j] : v89[j];
-      frags_from_floats(v, wb_hi[a], wb_lo[a]);
+      u32x4 w_hi, w_lo;
+      frags_from_floats(v, w_hi, w_lo);
+      *reinterpret_cast<u32x4*>(&lds_w[a][0][lane][0]) = w_hi;
+      *reinterpret_cast<u32x4*>(&lds_w[a][1][lane][0]) = w_lo;
     }
   }
+  __syncthreads();
+  const int64_t item = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (item >= n_items) return;
+  const int groups = g.f_ctr / FC;
+  const int64_t ctr = item / groups;
+  const int a0 = (int)(item - ctr * groups) * FC;
+  const float rho = *rho_p;
 
   const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
   const int n_total = (g.ends[ctr] - start) * g.f_nb;
@@ -144,9 +148,9 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
 #pragma unroll
       for (int t = 0; t < VW; ++t) acc[a][t] = zero16();
 
-    for (int c0 = 0; c0 < n_total; c0 += 32) {
-      const int cnt = min(32, n_total - c0);
-      const int fe = c0 + min(kcol, cnt - 1);
+    // frame-edge -> (neighbour id, source row): lane n of both halves handles frame-edge c0 + n
+    auto edge_of = [&](int c0, int& nb, int& q) {
+      const int fe = min(c0 + kcol, n_total - 1);
       int e, fn;
       if (fnb_shift >= 0) {
         e = start + (fe >> fnb_shift);
@@ -155,14 +159,33 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
         e = start + fe / g.f_nb;
         fn = fe % g.f_nb;
       }
-      const int nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-      const int q = nb * g.f_nb + fn;
-      const int qoff = q * row_bytes;
-      float xn[3], rn[9], d[9];
+      nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+      q = nb * g.f_nb + fn;
+    };
+    auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
 #pragma unroll
       for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+    };
+    // software pipeline: the neighbour ids and geometry of chunk c0+32 are fetched while chunk c0 computes
+    int nb_nx = 0, q_nx = 0;
+    float xn_nx[3], rn_nx[9];
+    if (n_total > 0) {
+      edge_of(0, nb_nx, q_nx);
+      geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+    }
+    for (int c0 = 0; c0 < n_total; c0 += 32) {
+      const int cnt = min(32, n_total - c0);
+      const int q = q_nx;
+      const int qoff = q * row_bytes;
+      float xn[3], rn[9], d[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+      const bool more = c0 + 32 < n_total;  // wave-uniform
+      if (more) edge_of(c0 + 32, nb_nx, q_nx);
       if (!g.transposed)
         edge_descriptor(xn, rn, yc, rc, rho, d);
       else
@@ -213,6 +236,8 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
         }
       }
 
+      if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+
 #pragma unroll
       for (int a = 0; a < FC; ++a) {
         const bool dims07 = FC == 1 ? h == 0 : h == a;
@@ -222,7 +247,9 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
           a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
           a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
         }
-        f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi[a], wb_lo[a], zero16());
+        const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[a][0][lane][0]);
+        const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[a][1][lane][0]);
+        f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s * 16 < cnt) {
@@ -248,9 +275,12 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
 #pragma unroll
       for (int t = 0; t < VW; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ch = cbase + VW * acc_row(r, h) + t;
-          if (FULL || ch < channels) t_row[ch * kBasis + kcol] = split_pack(acc[a][t][r]);
+        for (int r = 0; r < 16; r += 2) {
+          const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
+          uint32_t w0, w1;
+          split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
+          if (FULL || ch0 < channels) t_row[ch0 * kBasis + kcol] = w0;
+          if (FULL || ch1 < channels) t_row[ch1 * kBasis + kcol] = w1;
         }
     }
   }

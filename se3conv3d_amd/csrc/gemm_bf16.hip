@@ -19,21 +19,23 @@ constexpr int BM = 128, BN = 64, BK = 32;
 constexpr int A_LD = BK + 4;   // words; 144-byte pitch keeps 16-byte alignment and spreads ds_read_b128 over all banks
 constexpr int B_LD = BK + 8;   // bf16;  80-byte pitch, same properties
 
-__device__ __forceinline__ uint4 ld4_words(const uint32_t* p, int64_t avail, bool vec) {
-  if (avail >= 4 && vec) return *reinterpret_cast<const uint4*>(p);
-  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-  if (avail > 0) v.x = p[0];
-  if (avail > 1) v.y = p[1];
-  if (avail > 2) v.z = p[2];
-  if (avail > 3) v.w = p[3];
-  return v;
+// up to 4 consecutive words starting at p, `avail` of them readable (<= 0: none).  Native vector
+// type on purpose: HIP's uint4 struct made the register tiles of the pipeline land in scratch.
+__device__ __forceinline__ u32x4 ld4_words(const uint32_t* p, int64_t avail, bool vec) {
+  if (avail >= 4 && vec) return *reinterpret_cast<const u32x4*>(p);
+  const uint32_t x = avail > 0 ? p[0] : 0u, y = avail > 1 ? p[1] : 0u, z = avail > 2 ? p[2] : 0u,
+                 w = avail > 3 ? p[3] : 0u;
+  return u32x4{x, y, z, w};
 }
 
-template <bool OUT_PACKED>
+// OUT_MODE 0: fp32 C * alpha, 1: packed words of C * alpha, 2: raw fp32 partial of split z (no alpha).
+// The A stream is prefetched DEPTH k-tiles ahead in registers: one k-tile of compute (~400 cycles) is
+// far shorter than an HBM round trip, so a single tile in flight leaves the kernel latency-bound.
+template <int OUT_MODE>
 __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __restrict__ a,
                                                            const uint16_t* __restrict__ bt_hi,
                                                            const uint16_t* __restrict__ bt_lo, void* __restrict__ c,
-                                                           int64_t m, int n, int k, int kp,
+                                                           int64_t m, int n, int k, int kp, int kt_per_split,
                                                            const float* __restrict__ alpha_num, float alpha_scale) {
   __shared__ __attribute__((aligned(16))) uint32_t as[2][BM][A_LD];
   __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BN][B_LD];
@@ -43,50 +45,47 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const bool a_vec = (k % 4) == 0;
+  const int kt_begin = blockIdx.z * kt_per_split;
+  const int nk = min(kp / BK - kt_begin, kt_per_split);  // k-tiles of this block (> 0 by construction)
 
-  uint4 ra[4], rbh, rbl;
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = p * 32 + (tid >> 3), kq = (tid & 7) * 4;
-      const int64_t gr = m0 + row;
-      ra[p] = gr < m ? ld4_words(a + gr * k + k0 + kq, k - (k0 + kq), a_vec) : make_uint4(0u, 0u, 0u, 0u);
-    }
+  struct Tile { u32x4 a0, a1, a2, a3, bh, bl; };
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_tile = [&](Tile& t, int kt) {
+    const int k0 = (kt_begin + kt) * BK;
+    const int row = tid >> 3, kq = (tid & 7) * 4;
+    const uint32_t* ap = a + (m0 + row) * k + k0 + kq;
+    const int64_t avail = k - (k0 + kq);
+    t.a0 = ld4_words(ap, m0 + row < m ? avail : 0, a_vec);
+    t.a1 = ld4_words(ap + (int64_t)32 * k, m0 + row + 32 < m ? avail : 0, a_vec);
+    t.a2 = ld4_words(ap + (int64_t)64 * k, m0 + row + 64 < m ? avail : 0, a_vec);
+    t.a3 = ld4_words(ap + (int64_t)96 * k, m0 + row + 96 < m ? avail : 0, a_vec);
     const int nl = tid >> 2, kq8 = (tid & 3) * 8;
-    if (n0 + nl < n) {
-      rbh = *reinterpret_cast<const uint4*>(bt_hi + (int64_t)(n0 + nl) * kp + k0 + kq8);
-      rbl = *reinterpret_cast<const uint4*>(bt_lo + (int64_t)(n0 + nl) * kp + k0 + kq8);
-    } else {
-      rbh = rbl = make_uint4(0u, 0u, 0u, 0u);
-    }
+    const bool ok = n0 + nl < n;
+    const int64_t boff = (int64_t)(ok ? n0 + nl : 0) * kp + k0 + kq8;
+    const u32x4 vh = *reinterpret_cast<const u32x4*>(bt_hi + boff), vl = *reinterpret_cast<const u32x4*>(bt_lo + boff);
+    t.bh = ok ? vh : zero4;
+    t.bl = ok ? vl : zero4;
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = p * 32 + (tid >> 3), kq = (tid & 7) * 4;
-      *reinterpret_cast<uint4*>(&as[buf][row][kq]) = ra[p];
-    }
+  auto store_tile = [&](const Tile& t, int buf) {
+    const int row = tid >> 3, kq = (tid & 7) * 4;
+    *reinterpret_cast<u32x4*>(&as[buf][row][kq]) = t.a0;
+    *reinterpret_cast<u32x4*>(&as[buf][row + 32][kq]) = t.a1;
+    *reinterpret_cast<u32x4*>(&as[buf][row + 64][kq]) = t.a2;
+    *reinterpret_cast<u32x4*>(&as[buf][row + 96][kq]) = t.a3;
     const int nl = tid >> 2, kq8 = (tid & 3) * 8;
-    *reinterpret_cast<uint4*>(&bsh[buf][nl][kq8]) = rbh;
-    *reinterpret_cast<uint4*>(&bsl[buf][nl][kq8]) = rbl;
+    *reinterpret_cast<u32x4*>(&bsh[buf][nl][kq8]) = t.bh;
+    *reinterpret_cast<u32x4*>(&bsl[buf][nl][kq8]) = t.bl;
   };
 
   f32x16 acc0 = zero16(), acc1 = zero16();
-  const int nk = kp / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int kk = 16 * s + 8 * h;
-      const uint4 w0 = *reinterpret_cast<const uint4*>(&as[buf][wave * 32 + rl][kk]);
-      const uint4 w1 = *reinterpret_cast<const uint4*>(&as[buf][wave * 32 + rl][kk + 4]);
-      const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-      u32x4 a_hi, a_lo;
-      frags_from_words(w, a_hi, a_lo);
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(&as[buf][wave * 32 + rl][kk]);
+      const u32x4 w1 = *reinterpret_cast<const u32x4*>(&as[buf][wave * 32 + rl][kk + 4]);
+      const u32x4 a_hi = {pair_hi(w0[0], w0[1]), pair_hi(w0[2], w0[3]), pair_hi(w1[0], w1[1]), pair_hi(w1[2], w1[3])};
+      const u32x4 a_lo = {pair_lo(w0[0], w0[1]), pair_lo(w0[2], w0[3]), pair_lo(w1[0], w1[1]), pair_lo(w1[2], w1[3])};
       const u32x4 b0h = *reinterpret_cast<const u32x4*>(&bsh[buf][rl][kk]);
       const u32x4 b0l = *reinterpret_cast<const u32x4*>(&bsl[buf][rl][kk]);
       const u32x4 b1h = *reinterpret_cast<const u32x4*>(&bsh[buf][32 + rl][kk]);
@@ -94,26 +93,57 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
       acc0 = mfma_bf16x3(a_hi, a_lo, b0h, b0l, acc0);
       acc1 = mfma_bf16x3(a_hi, a_lo, b1h, b1l, acc1);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+  };
+  // k-tile kt lives in register set (kt mod 3) until it is written to LDS buffer (kt & 1)
+  Tile t0, t1, t2;
+  load_tile(t0, 0);
+  if (1 < nk) load_tile(t1, 1);
+  if (2 < nk) load_tile(t2, 2);
+  store_tile(t0, 0);
+  __syncthreads();
+#define SE3_GEMM_STEP(KT, CUR, NEXT)                                  \
+  if ((KT) < nk) {                                                    \
+    if ((KT) + 3 < nk) load_tile(CUR, (KT) + 3);                      \
+    compute((KT) & 1);                                                \
+    if ((KT) + 1 < nk) store_tile(NEXT, ((KT) & 1) ^ 1);              \
+    __syncthreads();                                                  \
   }
+  for (int kt0 = 0; kt0 < nk; kt0 += 3) {
+    SE3_GEMM_STEP(kt0, t0, t1)
+    SE3_GEMM_STEP(kt0 + 1, t1, t2)
+    SE3_GEMM_STEP(kt0 + 2, t2, t0)
+  }
+#undef SE3_GEMM_STEP
 
-  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+  const float alpha = OUT_MODE == 2 ? 1.0f : (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t gr = m0 + wave * 32 + acc_row(r, h);
     if (gr < m) {
       const int gc = n0 + rl;
-      if constexpr (OUT_PACKED) {
+      if constexpr (OUT_MODE == 1) {
         uint32_t* out = static_cast<uint32_t*>(c);
         if (gc < n) out[gr * n + gc] = split_pack(alpha * acc0[r]);
         if (gc + 32 < n) out[gr * n + gc + 32] = split_pack(alpha * acc1[r]);
       } else {
-        float* out = static_cast<float*>(c);
+        float* out = static_cast<float*>(c) + (OUT_MODE == 2 ? (int64_t)blockIdx.z * m * n : 0);
         if (gc < n) out[gr * n + gc] = alpha * acc0[r];
         if (gc + 32 < n) out[gr * n + gc + 32] = alpha * acc1[r];
       }
     }
+  }
+}
+
+// out = alpha * sum_z partials[z]  (fp32 or packed words)
+template <bool OUT_PACKED>
+__global__ void reduce_splits_kernel(const float* __restrict__ partials, void* __restrict__ out, int64_t count,
+                                     int splits, const float* __restrict__ alpha_num, float alpha_scale) {
+  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partials[(int64_t)z * count + i];
+    if constexpr (OUT_PACKED) static_cast<uint32_t*>(out)[i] = split_pack(alpha * s);
+    else static_cast<float*>(out)[i] = alpha * s;
   }
 }
 
@@ -132,26 +162,26 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
   const int64_t me = min(m, mb + chunk);
   const bool b_vec = (n % 4) == 0;
 
-  uint4 ra[4], rb[2];
+  u32x4 ra[4], rb[2];
   auto load_tile = [&](int64_t mm) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = p * 8 + (tid >> 5), cq = (tid & 31) * 4;
       const int64_t gr = mm + row;
-      ra[p] = gr < me ? ld4_words(a + gr * ka + ka0 + cq, ka - (ka0 + cq), true) : make_uint4(0u, 0u, 0u, 0u);
+      ra[p] = ld4_words(a + gr * ka + ka0 + cq, gr < me ? ka - (ka0 + cq) : 0, true);
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = p * 16 + (tid >> 4), cq = (tid & 15) * 4;
       const int64_t gr = mm + row;
-      rb[p] = gr < me ? ld4_words(b + gr * n + n0 + cq, n - (n0 + cq), b_vec) : make_uint4(0u, 0u, 0u, 0u);
+      rb[p] = ld4_words(b + gr * n + n0 + cq, gr < me ? n - (n0 + cq) : 0, b_vec);
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&at[buf][p * 8 + (tid >> 5)][(tid & 31) * 4]) = ra[p];
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(&at[buf][p * 8 + (tid >> 5)][(tid & 31) * 4]) = ra[p];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(&bt[buf][p * 16 + (tid >> 4)][(tid & 15) * 4]) = rb[p];
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(&bt[buf][p * 16 + (tid >> 4)][(tid & 15) * 4]) = rb[p];
   };
 
   f32x16 acc0 = zero16(), acc1 = zero16();
@@ -233,20 +263,52 @@ int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, u
   return check_launch();
 }
 
+// Split the k loop over grid.z when the row blocks alone cannot fill the chip (small hierarchy levels):
+// a block's k loop is serial, so 64 k-tiles on a handful of blocks would cost ~100 us whatever M is.
+int gemm_nn_bf16_splits(int64_t m, int n, int k) {
+  const int64_t blocks = ((m + BM - 1) / BM) * ((n + BN - 1) / BN);
+  const int nkt = (k + BK - 1) / BK;
+  if (blocks >= 512 || nkt < 8) return 1;
+  int64_t s = (1024 + blocks - 1) / blocks;
+  if (s > nkt / 4) s = nkt / 4;  // >= 4 k-tiles per split
+  return (int)(s < 1 ? 1 : s);
+}
+
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
-                        bool out_packed, int64_t m, int n, int k, const float* alpha_num, float alpha_scale,
-                        hipStream_t stream) {
+                        bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
+                        float alpha_scale, hipStream_t stream) {
   if (m == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   const int kp = (k + 31) / 32 * 32;
-  const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN - 1) / BN));
-  if (out_packed)
-    hipLaunchKernelGGL(gemm_nn_bf16_kernel<true>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp, alpha_num,
+  const int nkt = kp / BK;
+  int splits = split_ws ? gemm_nn_bf16_splits(m, n, k) : 1;
+  const int per = (nkt + splits - 1) / splits;
+  splits = (nkt + per - 1) / per;
+  const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
+  if (splits > 1) {
+    hipLaunchKernelGGL(gemm_nn_bf16_kernel<2>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)split_ws, m, n, k, kp,
+                       per, alpha_num, alpha_scale);
+    const int64_t count = m * n;
+    const int rb = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    if (out_packed)
+      hipLaunchKernelGGL(reduce_splits_kernel<true>, dim3(rb), dim3(256), 0, stream, split_ws, c, count, splits,
+                         alpha_num, alpha_scale);
+    else
+      hipLaunchKernelGGL(reduce_splits_kernel<false>, dim3(rb), dim3(256), 0, stream, split_ws, c, count, splits,
+                         alpha_num, alpha_scale);
+  } else if (out_packed) {
+    hipLaunchKernelGGL(gemm_nn_bf16_kernel<1>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp, per, alpha_num,
                        alpha_scale);
-  else
-    hipLaunchKernelGGL(gemm_nn_bf16_kernel<false>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp,
-                       alpha_num, alpha_scale);
+  } else {
+    hipLaunchKernelGGL(gemm_nn_bf16_kernel<0>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp, per, alpha_num,
+                       alpha_scale);
+  }
   return check_launch();
+}
+
+size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k) {
+  const int s = gemm_nn_bf16_splits(m, n, k);
+  return s > 1 ? (size_t)s * m * n * 4 : 0;
 }
 
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
