@@ -197,9 +197,14 @@ def main():
     from oracle import se3conv_oracle as O  # cpu_baseline leg + radius helper only
     from se3conv3d_amd import _lib
 
+    from se3conv3d_amd.sharding import gather_scene_results, job_throughput, shard_scenes
+
     lib = _lib.load()
     amd.set_precision(args.precision)
-    levels = build_stack(amd, O, device, seed=rank)
+    # one scene (cloud) per GPU, sharded by size like a deployment would; scene id doubles as the seed
+    my_scenes = shard_scenes([N0] * world, world)[rank]
+    assert len(my_scenes) == 1
+    levels = build_stack(amd, O, device, seed=my_scenes[0])
 
     def barrier():
         torch.cuda.synchronize()
@@ -216,10 +221,7 @@ def main():
             fn()
         barrier()
         dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        _, dt = job_throughput(float(N0 * steps), dt, dist, device)  # MAX over ranks
         return dt
 
     if args.no_graph:
@@ -278,6 +280,13 @@ def main():
                          "unit": "Mpoints/s", "hbm_roofline": hbm},
         "roofline": roofline,
     }
+    # the "trivial result gather": one checksum of the level-0 output per scene, to rank 0
+    with torch.no_grad():
+        lv = levels[0]
+        out0 = lv["conv"](p_pc_in=lv["pc"], p_pc_out=lv["pc"], p_in_features=lv["x"], p_neighborhood=lv["nbh"])
+        sums = gather_scene_results({my_scenes[0]: out0.double().sum().reshape(1)}, dist, dst=0)
+    if rank == 0:
+        result["scene_checksums"] = {str(k): round(float(v), 6) for k, v in sorted(sums.items())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(O)
     if rank == 0:
