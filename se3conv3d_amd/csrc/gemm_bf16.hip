@@ -31,7 +31,10 @@ __device__ __forceinline__ u32x4 ld4_words(const uint32_t* p, int64_t avail, boo
 // OUT_MODE 0: fp32 C * alpha, 1: packed words of C * alpha, 2: raw fp32 partial of split z (no alpha).
 // The A stream is prefetched DEPTH k-tiles ahead in registers: one k-tile of compute (~400 cycles) is
 // far shorter than an HBM round trip, so a single tile in flight leaves the kernel latency-bound.
-template <int OUT_MODE>
+// FAST (k % 32 == 0, operands < 4 GB): every load is an unconditional raw buffer load whose out-of-range
+// lanes return 0 -- no branches around the loads, so the compiler keeps all three tiles in flight (with
+// guarded loads it drained vmcnt(0) after every tile and the kernel ran at half the HBM rate).
+template <int OUT_MODE, bool FAST>
 __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __restrict__ a,
                                                            const uint16_t* __restrict__ bt_hi,
                                                            const uint16_t* __restrict__ bt_lo, void* __restrict__ c,
@@ -50,9 +53,33 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
 
   struct Tile { u32x4 a0, a1, a2, a3, bh, bl; };
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  auto load_tile = [&](Tile& t, int kt) {
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(a), (short)0, FAST ? (int)(uint32_t)(m * k * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bh_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_hi), (short)0, FAST ? (int)(uint32_t)((int64_t)n * kp * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_lo), (short)0, FAST ? (int)(uint32_t)((int64_t)n * kp * 2) : 0, 0x00020000);
+  // Every block walks its k-tiles from a different starting phase (the sum is order-independent up to
+  // rounding): with a common phase all resident blocks read the same 128-byte column strip of their
+  // 8 KB rows at the same time, which concentrates the traffic on a few HBM channels.
+  const int phase = FAST ? (int)((blockIdx.x * 5u) % (unsigned)nk) : 0;
+  auto load_tile = [&](Tile& t, int kt_seq) {
+    int kt = kt_seq + phase;
+    if (kt >= nk) kt -= nk;
     const int k0 = (kt_begin + kt) * BK;
     const int row = tid >> 3, kq = (tid & 7) * 4;
+    if constexpr (FAST) {
+      const uint32_t aoff = (uint32_t)(((m0 + row) * k + k0 + kq) * 4);  // rows >= m fall outside the buffer -> 0
+      const uint32_t rstep = (uint32_t)k * 32u * 4u;
+      t.a0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff, 0, 0));
+      t.a1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + rstep, 0, 0));
+      t.a2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + 2 * rstep, 0, 0));
+      t.a3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + 3 * rstep, 0, 0));
+      const uint32_t boff = (uint32_t)((((int64_t)(n0 + (tid >> 2))) * kp + k0 + (tid & 3) * 8) * 2);
+      t.bh = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, boff, 0, 0));
+      t.bl = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, boff, 0, 0));
+      return;
+    }
     const uint32_t* ap = a + (m0 + row) * k + k0 + kq;
     const int64_t avail = k - (k0 + kq);
     t.a0 = ld4_words(ap, m0 + row < m ? avail : 0, a_vec);
@@ -101,6 +128,13 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   if (2 < nk) load_tile(t2, 2);
   store_tile(t0, 0);
   __syncthreads();
+  // steady state without any condition around the loads (conditional loads make the compiler drain
+  // vmcnt(0) every step), then a checked tail of at most 5 k-tiles
+#define SE3_GEMM_STEP_FULL(KT, CUR, NEXT)  \
+  load_tile(CUR, (KT) + 3);                \
+  compute((KT) & 1);                       \
+  store_tile(NEXT, ((KT) & 1) ^ 1);        \
+  __syncthreads();
 #define SE3_GEMM_STEP(KT, CUR, NEXT)                                  \
   if ((KT) < nk) {                                                    \
     if ((KT) + 3 < nk) load_tile(CUR, (KT) + 3);                      \
@@ -108,12 +142,19 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
     if ((KT) + 1 < nk) store_tile(NEXT, ((KT) & 1) ^ 1);              \
     __syncthreads();                                                  \
   }
-  for (int kt0 = 0; kt0 < nk; kt0 += 3) {
+  int kt0 = 0;
+  for (; kt0 + 6 <= nk; kt0 += 3) {
+    SE3_GEMM_STEP_FULL(kt0, t0, t1)
+    SE3_GEMM_STEP_FULL(kt0 + 1, t1, t2)
+    SE3_GEMM_STEP_FULL(kt0 + 2, t2, t0)
+  }
+  for (; kt0 < nk; kt0 += 3) {
     SE3_GEMM_STEP(kt0, t0, t1)
     SE3_GEMM_STEP(kt0 + 1, t1, t2)
     SE3_GEMM_STEP(kt0 + 2, t2, t0)
   }
 #undef SE3_GEMM_STEP
+#undef SE3_GEMM_STEP_FULL
 
   const float alpha = OUT_MODE == 2 ? 1.0f : (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
 #pragma unroll
@@ -285,9 +326,19 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
   const int per = (nkt + splits - 1) / splits;
   splits = (nkt + per - 1) / per;
   const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
+  const bool fast = (k % 32 == 0) && (m * (int64_t)k * 4 < (1ll << 32)) && ((int64_t)n * kp * 2 < (1ll << 32)) &&
+                    ((m + BM) * (int64_t)k * 4 < (1ll << 32));
+#define SE3_NN(MODE, OUT)                                                                                               \
+  do {                                                                                                                  \
+    if (fast)                                                                                                           \
+      hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, true>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), m, \
+                         n, k, kp, per, alpha_num, alpha_scale);                                                        \
+    else                                                                                                                \
+      hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, false>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), \
+                         m, n, k, kp, per, alpha_num, alpha_scale);                                                     \
+  } while (0)
   if (splits > 1) {
-    hipLaunchKernelGGL(gemm_nn_bf16_kernel<2>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)split_ws, m, n, k, kp,
-                       per, alpha_num, alpha_scale);
+    SE3_NN(2, split_ws);
     const int64_t count = m * n;
     const int rb = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
     if (out_packed)
@@ -297,12 +348,11 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
       hipLaunchKernelGGL(reduce_splits_kernel<false>, dim3(rb), dim3(256), 0, stream, split_ws, c, count, splits,
                          alpha_num, alpha_scale);
   } else if (out_packed) {
-    hipLaunchKernelGGL(gemm_nn_bf16_kernel<1>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp, per, alpha_num,
-                       alpha_scale);
+    SE3_NN(1, c);
   } else {
-    hipLaunchKernelGGL(gemm_nn_bf16_kernel<0>, grid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k, kp, per, alpha_num,
-                       alpha_scale);
+    SE3_NN(0, c);
   }
+#undef SE3_NN
   return check_launch();
 }
 
