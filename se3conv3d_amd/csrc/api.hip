@@ -374,6 +374,9 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   if (int rc = launch_split_pack(feat, featpk, s->n_in * s->f_in * s->c_in, stream)) return rc;
   if (int rc = launch_prep_weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, stream)) return rc;
+  if (conv_fused_bf16_supported(g, s->c_in))  // edge phase + contraction in one launch; T only if the caller wants it
+    return launch_conv_fused_bf16("conv_fused_fwd", g, featpk, s->n_in * s->f_in, axes_ext, rho, bt_hi, bt_lo, s->c_out,
+                                  out, (uint32_t*)t_save, nu, inv_fin, stream);
   if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream)) return rc;
   return launch_gemm_nn_bf16("gemm_out", (const uint32_t*)t, bt_hi, bt_lo, out, false, rows_out, s->c_out, ck,
                              (float*)(ws + l.split), nu, inv_fin, stream);
@@ -494,8 +497,11 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     }
   }
   if (want_feat && rows_in > 0) {
-    if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, bigw, stream)) return rc;
     if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, bt_hi, bt_lo, stream)) return rc;
+    if (conv_fused_bf16_supported(gt, s->c_out))
+      return launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, bt_hi, bt_lo, s->c_in,
+                                    grad_feat, nullptr, nu, inv_fin, stream);
+    if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, bigw, stream)) return rc;
     if (int rc = launch_gemm_nn_bf16("gemm_gradX", bigw, bt_hi, bt_lo, grad_feat, false, rows_in, s->c_in,
                                      s->c_out * kb, (float*)(ws + l.split), nu, inv_fin, stream))
       return rc;

@@ -189,6 +189,11 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 const float* axes_ext, const float* rho, const uint32_t* grad_t, float* partials,
                                 int n_partials, hipStream_t stream);
+bool conv_fused_bf16_supported(const EdgeGeom& g, int gathered_channels);
+int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int64_t feat_rows,
+                           const float* axes_ext, const float* rho, const uint16_t* bt_hi, const uint16_t* bt_lo,
+                           int co, float* out, uint32_t* t_save, const float* alpha_num, float alpha_scale,
+                           hipStream_t stream);
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream);
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,

@@ -10,6 +10,7 @@
 // Gathered operands (features, grad_out) are read as packed words (hi << 16 | lo) prepared by
 // split_pack_kernel; intermediates (T, grad_T, U) are written as packed words too.
 #include "common.h"
+#include "edge_bf16_body.h"
 
 namespace se3 {
 
@@ -81,209 +82,22 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], int
 // VALU is the bound of this kernel (MFMA ~15 % busy), so everything here is about instruction count:
 // 32-bit buffer addressing, ds_bpermute for the per-row source offsets, branch-free GELU.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, int64_t bytes) {
-  const uint32_t n = bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)n, 0x00020000);
-}
-
 template <int VW, int FC, bool FULL>
 __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
-                                                          int64_t feat_rows, const float* __restrict__ axes_ext,
-                                                          const float* __restrict__ rho_p,
-                                                          uint32_t* __restrict__ t_out, int64_t n_items,
-                                                          int fnb_shift) {
-  // MLP weights [A; beta] as MFMA B fragments, kept in LDS (16 VGPRs otherwise): arrangement a has
-  // descriptor dims 0..7 in the lane half that builds row a's descriptors.
+                                                             int64_t feat_rows, const float* __restrict__ axes_ext,
+                                                             const float* __restrict__ rho_p,
+                                                             uint32_t* __restrict__ t_out, int64_t n_items,
+                                                             int fnb_shift) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
-  const int lane = threadIdx.x & 63;
-  const int kcol = lane & 31, h = lane >> 5;
-  if (threadIdx.x < 64) {
-    float v07[8], v89[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v07[j] = axes_ext[j * kBasis + kcol];
-      v89[j] = j < 2 ? axes_ext[(8 + j) * kBasis + kcol] : 0.f;
-    }
-#pragma unroll
-    for (int a = 0; a < FC; ++a) {
-      const bool dims07 = FC == 1 ? h == 0 : h == a;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = dims07 ? v07[j] : v89[j];
-      u32x4 w_hi, w_lo;
-      frags_from_floats(v, w_hi, w_lo);
-      *reinterpret_cast<u32x4*>(&lds_w[a][0][lane][0]) = w_hi;
-      *reinterpret_cast<u32x4*>(&lds_w[a][1][lane][0]) = w_lo;
-    }
-  }
+  if (threadIdx.x < 64) mlp_weights_to_lds<FC>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
   const int64_t item = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (item >= n_items) return;
-  const int groups = g.f_ctr / FC;
-  const int64_t ctr = item / groups;
-  const int a0 = (int)(item - ctr * groups) * FC;
-  const float rho = *rho_p;
-
-  const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
-  const int n_total = (g.ends[ctr] - start) * g.f_nb;
-  float yc[3], rc[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
-  {
-    const int64_t fr = ctr * g.f_ctr + a0 + (FC == 2 ? h : 0);  // the centre frame this lane builds descriptors for
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[fr * 9 + i];
-  }
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * channels * 4);
-  const int row_bytes = channels * 4;
-  const int hb = 16 * h;  // ds_bpermute byte address of lane 4h
-
-  for (int cbase = 0; cbase < channels; cbase += 32 * VW) {
-    const int cb = cbase + VW * kcol;
-    const bool ch_ok = FULL || cb < channels;
-    const int cb4 = (ch_ok ? cb : 0) * 4;
-    f32x16 acc[FC][VW];
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-      for (int t = 0; t < VW; ++t) acc[a][t] = zero16();
-
-    // frame-edge -> (neighbour id, source row): lane n of both halves handles frame-edge c0 + n
-    auto edge_of = [&](int c0, int& nb, int& q) {
-      const int fe = min(c0 + kcol, n_total - 1);
-      int e, fn;
-      if (fnb_shift >= 0) {
-        e = start + (fe >> fnb_shift);
-        fn = fe & ((1 << fnb_shift) - 1);
-      } else {
-        e = start + fe / g.f_nb;
-        fn = fe % g.f_nb;
-      }
-      nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-      q = nb * g.f_nb + fn;
-    };
-    auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
-    };
-    // software pipeline: the neighbour ids and geometry of chunk c0+32 are fetched while chunk c0 computes
-    int nb_nx = 0, q_nx = 0;
-    float xn_nx[3], rn_nx[9];
-    if (n_total > 0) {
-      edge_of(0, nb_nx, q_nx);
-      geom_of(nb_nx, q_nx, xn_nx, rn_nx);
-    }
-    for (int c0 = 0; c0 < n_total; c0 += 32) {
-      const int cnt = min(32, n_total - c0);
-      const int q = q_nx;
-      const int qoff = q * row_bytes;
-      float xn[3], rn[9], d[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-      const bool more = c0 + 32 < n_total;  // wave-uniform
-      if (more) edge_of(c0 + 32, nb_nx, q_nx);
-      if (!g.transposed)
-        edge_descriptor(xn, rn, yc, rc, rho, d);
-      else
-        edge_descriptor(yc, rc, xn, rn, rho, d);
-
-      // MLP A operand pieces of this lane: its own dims 0..7, and {dim 8 of the row it serves as "other" half, 1}
-      u32x4 own_hi, own_lo, oth_hi, oth_lo;
-      frags_from_floats(d, own_hi, own_lo);
-      {
-        float d8 = d[8];
-        if constexpr (FC == 2) {
-          // lanes of half h hold the descriptor against frame a0+h; row a's dims 8,9 live in half 1-a
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
-          d8 = __uint_as_float(h ? sw[0] : sw[1]);
-        }
-        uint32_t p_hi, p_lo;
-        split2(d8, 1.0f, p_hi, p_lo);
-        oth_hi = u32x4{p_hi, 0u, 0u, 0u};
-        oth_lo = u32x4{p_lo, 0u, 0u, 0u};
-      }
-
-      // gathered feature fragments of the chunk's two k-steps (shared by the FC rows)
-      u32x4 fa_hi[2][VW], fa_lo[2][VW];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (s * 16 < cnt) {  // wave-uniform
-          uint32_t w[VW][8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            // byte offset of the source row of frame-edge acc_row(8s+j, h), fetched from the lane that owns it
-            const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
-            const int voff = src_off + cb4;
-            if constexpr (VW == 4) {
-              const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
-              w[0][j] = v[0], w[1][j] = v[1], w[2][j] = v[2], w[3][j] = v[3];
-            } else if constexpr (VW == 2) {
-              const auto v = __builtin_amdgcn_raw_buffer_load_b64(feat_rs, voff, 0, 0);
-              w[0][j] = v[0], w[1][j] = v[1];
-            } else {
-              w[0][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, voff, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < VW; ++t) {
-            frags_from_words(w[t], fa_hi[s][t], fa_lo[s][t]);
-            if (!ch_ok) fa_hi[s][t] = fa_lo[s][t] = u32x4{0u, 0u, 0u, 0u};
-          }
-        }
-      }
-
-      if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
-
-#pragma unroll
-      for (int a = 0; a < FC; ++a) {
-        const bool dims07 = FC == 1 ? h == 0 : h == a;
-        u32x4 a_hi, a_lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
-          a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
-        }
-        const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[a][0][lane][0]);
-        const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[a][1][lane][0]);
-        f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s * 16 < cnt) {
-            float pv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float y = gelu_erf(phi[8 * s + j]);
-              asm volatile("" : "+v"(y));  // keep the GELU unconditional (no exec-masked branch per register)
-              pv[j] = acc_row(8 * s + j, h) < cnt ? y : 0.f;
-            }
-            u32x4 b_hi, b_lo;
-            frags_from_floats(pv, b_hi, b_lo);
-#pragma unroll
-            for (int t = 0; t < VW; ++t) acc[a][t] = mfma_bf16x3(fa_hi[s][t], fa_lo[s][t], b_hi, b_lo, acc[a][t]);
-          }
-        }
-      }
-    }
-    // acc[a][t] register r, lane (kcol, h) = T[row a][cbase + VW*acc_row(r,h) + t][kcol]
-#pragma unroll
-    for (int a = 0; a < FC; ++a) {
-      uint32_t* t_row = t_out + ((ctr * g.f_ctr + a0 + a) * (int64_t)channels) * kBasis;
-#pragma unroll
-      for (int t = 0; t < VW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
-          uint32_t w0, w1;
-          split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
-          if (FULL || ch0 < channels) t_row[ch0 * kBasis + kcol] = w0;
-          if (FULL || ch1 < channels) t_row[ch1 * kBasis + kcol] = w1;
-        }
-    }
-  }
+  uint32_t* t_rows = t_out + item * FC * (int64_t)channels * kBasis;  // rows FC*item .. FC*item + FC-1
+  const int row_words = channels * kBasis;
+  edge_item_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, item, fnb_shift,
+                               [&](int a, int off, uint32_t w) { t_rows[a * row_words + off] = w; });
 }
 
 // ------------------------------------------------------------------------------------------------
