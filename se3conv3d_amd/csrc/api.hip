@@ -478,7 +478,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                                      (float*)(ws + l.split), nu, inv_fin, stream))
       return rc;
     if (grad_axes || grad_biases) {
-      if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, axes_ext, rho, bigw, partials,
+      if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
                                                l.n_param_partials, stream))
         return rc;
       hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,

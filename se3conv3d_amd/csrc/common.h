@@ -187,8 +187,8 @@ int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t st
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
-                                const float* axes_ext, const float* rho, const uint32_t* grad_t, float* partials,
-                                int n_partials, hipStream_t stream);
+                                int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
+                                float* partials, int n_partials, hipStream_t stream);
 bool conv_fused_bf16_supported(const EdgeGeom& g, int gathered_channels);
 int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int64_t feat_rows,
                            const float* axes_ext, const float* rho, const uint16_t* bt_hi, const uint16_t* bt_lo,

@@ -208,6 +208,210 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// edge_param_grad, two frames per wavefront (same sharing scheme as edge_item_bf16) and the d[A;beta]
+// accumulation moved from VALU to MFMA:
+//   gphi_a[n,k] = sum_i feat[q(n), i] * gT[row a][i,k]      A = gathered rows (shared by both frames),
+//                                                            B = gT fragments, fetched once per item
+//   gpre_a      = gphi_a * GELU'(pre_a)
+//   d[A;beta]^T[k, j] += sum_n gpre_a[n,k] * desc_a[n,j]     A = gpre (the accumulator registers, split in
+//                                                            place), B = descriptor columns read back from
+//                                                            a wave-private LDS image of packed words
+// CH16 = channels / 16 (1..4).  The gT fragments of the item's two rows are built once per item and parked in
+// a wave-private LDS image (CH16 * 4 KB per wavefront; in registers they cost CH16 * 16 VGPRs and spilled),
+// hence 512-thread blocks: 8 wavefronts share the CU's LDS at the same 2 waves/SIMD as before.
+// ------------------------------------------------------------------------------------------------
+template <int CH16>
+__global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+                                                                         int64_t feat_rows,
+                                                                         const float* __restrict__ axes_ext,
+                                                                         const float* __restrict__ rho_p,
+                                                                         const uint32_t* __restrict__ grad_t,
+                                                                         float* __restrict__ partials, int64_t n_items,
+                                                                         int fnb_shift) {
+  constexpr int C = CH16 * 16;
+  constexpr int NW = 8;  // wavefronts per block
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][2][64][4];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_desc[NW][2][32][12];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NW][2][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
+  // the final block reduction reuses the gT image (NW * 10 * 32 floats <= NW * CH16 * 1024 words)
+  float(*lds_red)[kDescExt][kBasis] = reinterpret_cast<float(*)[kDescExt][kBasis]>(&lds_gt[0][0][0][0][0][0]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kcol = lane & 31, h = lane >> 5;
+  if (threadIdx.x < 64) mlp_weights_to_lds<2>(lds_w, axes_ext, threadIdx.x);
+  __syncthreads();
+  const float rho = *rho_p;
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * C * 4);
+  f32x16 dacc = zero16();  // lane (j = kcol, h), register r: d[A;beta][j][k = acc_row(r,h)]
+
+  for (int64_t item = (int64_t)blockIdx.x * NW + wave; item < n_items; item += (int64_t)gridDim.x * NW) {
+    const int groups = g.f_ctr / 2;
+    const int64_t ctr = item / groups;
+    const int a0 = (int)(item - ctr * groups) * 2;
+    const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
+    const int n_total = (g.ends[ctr] - start) * g.f_nb;
+    if (n_total == 0) continue;
+    float yc[3], rc[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[(ctr * g.f_ctr + a0 + h) * 9 + i];
+
+    // gT fragments (MFMA B operand) of the item's two rows: lane (k = kcol, h) holds channels 16*st + 8h + j
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const uint32_t* gt_row = grad_t + (item * 2 + a) * (int64_t)C * kBasis;
+#pragma unroll
+      for (int st = 0; st < CH16; ++st) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = gt_row[(16 * st + 8 * h + j) * kBasis + kcol];
+        u32x4 f_hi, f_lo;
+        frags_from_words(w, f_hi, f_lo);
+        *reinterpret_cast<u32x4*>(&lds_gt[wave][a][st][0][lane][0]) = f_hi;
+        *reinterpret_cast<u32x4*>(&lds_gt[wave][a][st][1][lane][0]) = f_lo;
+      }
+    }
+
+    auto edge_of = [&](int c0, int& nb, int& q) {
+      const int fe = min(c0 + kcol, n_total - 1);
+      int e, fn;
+      if (fnb_shift >= 0) {
+        e = start + (fe >> fnb_shift);
+        fn = fe & ((1 << fnb_shift) - 1);
+      } else {
+        e = start + fe / g.f_nb;
+        fn = fe % g.f_nb;
+      }
+      nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+      q = nb * g.f_nb + fn;
+    };
+    auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+    };
+    int nb_nx, q_nx;
+    float xn_nx[3], rn_nx[9];
+    edge_of(0, nb_nx, q_nx);
+    geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+
+    for (int c0 = 0; c0 < n_total; c0 += 32) {
+      const int cnt = min(32, n_total - c0);
+      const int q = q_nx;
+      float xn[3], rn[9], d[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+      const bool more = c0 + 32 < n_total;
+      if (more) edge_of(c0 + 32, nb_nx, q_nx);
+      if (!g.transposed)
+        edge_descriptor(xn, rn, yc, rc, rho, d);
+      else
+        edge_descriptor(yc, rc, xn, rn, rho, d);
+
+      // gathered feature fragments (MFMA A operand of gphi): lane (n = kcol, h) reads its own source row
+      u32x4 fa_hi[CH16], fa_lo[CH16];
+#pragma unroll
+      for (int st = 0; st < CH16; ++st) {
+        const int voff = q * (C * 4) + (16 * st + 8 * h) * 4;
+        const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
+        const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff + 16, 0, 0);
+        const uint32_t w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        frags_from_words(w, fa_hi[st], fa_lo[st]);
+      }
+      if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+
+      // descriptor image for the d[A;beta] product: half h writes the rows of frame a0+h
+      {
+        uint32_t* dst = &lds_desc[wave][h][kcol][0];
+        uint32_t pw[12];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) split_pack2(d[i], d[i + 1], pw[i], pw[i + 1]);
+        split_pack2(d[8], 1.0f, pw[8], pw[9]);
+        pw[10] = pw[11] = 0u;
+        *reinterpret_cast<u32x4*>(dst) = u32x4{pw[0], pw[1], pw[2], pw[3]};
+        *reinterpret_cast<u32x4*>(dst + 4) = u32x4{pw[4], pw[5], pw[6], pw[7]};
+        *reinterpret_cast<u32x4*>(dst + 8) = u32x4{pw[8], pw[9], pw[10], pw[11]};
+      }
+      u32x4 own_hi, own_lo, oth_hi, oth_lo;
+      frags_from_floats(d, own_hi, own_lo);
+      {
+        float d8 = d[8];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
+        d8 = __uint_as_float(h ? sw[0] : sw[1]);
+        uint32_t p_hi, p_lo;
+        split2(d8, 1.0f, p_hi, p_lo);
+        oth_hi = u32x4{p_hi, 0u, 0u, 0u};
+        oth_lo = u32x4{p_lo, 0u, 0u, 0u};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bool dims07 = h == a;
+        u32x4 a_hi, a_lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
+          a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
+        }
+        const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[a][0][lane][0]);
+        const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[a][1][lane][0]);
+        const f32x16 pre = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+        f32x16 gphi = zero16();
+#pragma unroll
+        for (int st = 0; st < CH16; ++st) {
+          const u32x4 bg_hi = *reinterpret_cast<const u32x4*>(&lds_gt[wave][a][st][0][lane][0]);
+          const u32x4 bg_lo = *reinterpret_cast<const u32x4*>(&lds_gt[wave][a][st][1][lane][0]);
+          gphi = mfma_bf16x3(fa_hi[st], fa_lo[st], bg_hi, bg_lo, gphi);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s * 16 < cnt) {
+            float gp[8];
+            uint32_t wd[8];
+            const int jcol = min(kcol, 11);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float y, dy;
+              gelu_erf_grad(pre[8 * s + j], y, dy);
+              asm volatile("" : "+v"(dy));
+              gp[j] = acc_row(8 * s + j, h) < cnt ? gphi[8 * s + j] * dy : 0.f;
+              wd[j] = lds_desc[wave][a][acc_row(8 * s + j, h)][jcol];
+            }
+            u32x4 ga_hi, ga_lo, db_hi, db_lo;
+            frags_from_floats(gp, ga_hi, ga_lo);
+            frags_from_words(wd, db_hi, db_lo);
+            dacc = mfma_bf16x3(ga_hi, ga_lo, db_hi, db_lo, dacc);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // dacc: rows = k (acc_row(r,h)), columns = descriptor dim j = kcol (only j < 10 are meaningful)
+  __syncthreads();  // every wavefront is done with its gT image
+  if (kcol < kDescExt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds_red[wave][kcol][acc_row(r, h)] = dacc[r];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kDescExt * kBasis; i += blockDim.x) {
+    const int j = i / kBasis, k = i % kBasis;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += lds_red[w][j][k];
+    partials[(int64_t)blockIdx.x * kDescExt * kBasis + i] = sum;
+  }
+}
+
 __global__ void split_pack_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) {
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 + 3 < n) {
@@ -257,10 +461,27 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
 }
 
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
-                                const float* axes_ext, const float* rho, const uint32_t* grad_t, float* partials,
-                                int n_partials, hipStream_t stream) {
+                                int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
+                                float* partials, int n_partials, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   ProfScope prof(tag, stream);
+  if (g.f_ctr % 2 == 0 && channels % 16 == 0 && channels <= 64 && channels > 0) {
+    int shift = -1;
+    for (int sft = 0; sft < 8; ++sft)
+      if ((1 << sft) == g.f_nb) shift = sft;
+    const int64_t items = rows / 2;
+#define SE3_PG(CH16)                                                                                                  \
+  hipLaunchKernelGGL(edge_param_grad_bf16_v2_kernel<CH16>, dim3(n_partials), dim3(512), 0, stream, g, feat, feat_rows, \
+                     axes_ext, rho, grad_t, partials, items, shift)
+    switch (channels / 16) {
+      case 1: SE3_PG(1); break;
+      case 2: SE3_PG(2); break;
+      case 3: SE3_PG(3); break;
+      default: SE3_PG(4); break;
+    }
+#undef SE3_PG
+    return check_launch();
+  }
   hipLaunchKernelGGL(edge_param_grad_bf16_kernel, dim3(n_partials), dim3(256), 0, stream, g, feat, channels, axes_ext,
                      rho, grad_t, partials, rows);
   return check_launch();

@@ -3,6 +3,10 @@
 // stage contracts with the weights before anything leaves the CU).  See edge_bf16.hip for the scheme.
 #pragma once
 
+#ifndef SE3_ABLATE
+#define SE3_ABLATE 0  // diagnostic builds only (tools/ablate.sh): 1 no GELU, 2 no feature gather, 3 no geometry gather, 4 no stores
+#endif
+
 #include "common.h"
 
 namespace se3 {
@@ -87,10 +91,17 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
       q = nb * g.f_nb + fn;
     };
     auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
+#if SE3_ABLATE == 3
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xn[i] = (float)(nb & 255) * 0.001f + i;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rn[i] = (float)(q & 127) * 0.002f - i;
+#else
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
 #pragma unroll
       for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+#endif
     };
     // software pipeline: the neighbour ids and geometry of chunk c0+32 are fetched while chunk c0 computes
     int nb_nx = 0, q_nx = 0;
@@ -142,6 +153,12 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
             // byte offset of the source row of frame-edge acc_row(8s+j, h), fetched from the lane that owns it
             const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
             const int voff = src_off + cb4;
+#if SE3_ABLATE == 2
+            if constexpr (VW >= 1) {
+#pragma unroll
+              for (int t = 0; t < VW; ++t) w[t][j] = (uint32_t)voff * 2654435761u + t;
+            } else
+#endif
             if constexpr (VW == 4) {
               const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
               w[0][j] = v[0], w[1][j] = v[1], w[2][j] = v[2], w[3][j] = v[3];
@@ -180,7 +197,11 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
             float pv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+#if SE3_ABLATE == 1
+              float y = phi[8 * s + j];
+#else
               float y = gelu_erf(phi[8 * s + j]);
+#endif
               asm volatile("" : "+v"(y));  // keep the GELU unconditional (no exec-masked branch per register)
               pv[j] = acc_row(8 * s + j, h) < cnt ? y : 0.f;
             }
@@ -202,8 +223,13 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
           const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
           uint32_t w0, w1;
           split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
+#if SE3_ABLATE == 4
+          asm volatile("" ::"v"(w0), "v"(w1));
+          if (w0 == 0x12345678u) sink(a, ch0 * kBasis + kcol, w0);
+#else
           if (FULL || ch0 < channels) sink(a, ch0 * kBasis + kcol, w0);
           if (FULL || ch1 < channels) sink(a, ch1 * kBasis + kcol, w1);
+#endif
         }
   }
 }
