@@ -175,6 +175,86 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   }
 }
 
+// Row-strip variant for a short k (kp <= 64) and a wide N, packed output -- the grad_T GEMM
+// (grad_T[rows, C_in*K] = g[rows, C_out] @ W^T).  A wavefront keeps the A fragments of its 32 rows in
+// registers and walks all N columns, so every output row is written front to back (the generic kernel's
+// 64-column blocks write 256-byte pieces 8 KB apart); the weight planes stream from L2.
+template <int KS>  // kp / 16
+__global__ __launch_bounds__(256) void gemm_strip_bf16_kernel(const uint32_t* __restrict__ a,
+                                                              const uint16_t* __restrict__ bt_hi,
+                                                              const uint16_t* __restrict__ bt_lo,
+                                                              uint32_t* __restrict__ c, int64_t m, int n, int k,
+                                                              const float* __restrict__ alpha_num, float alpha_scale) {
+  constexpr int KP = KS * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rl = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+  const __amdgpu_buffer_rsrc_t a_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a), (short)0, (int)(uint32_t)(m * k * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bh_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_hi), (short)0, (int)(uint32_t)((int64_t)n * KP * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_lo), (short)0, (int)(uint32_t)((int64_t)n * KP * 2), 0x00020000);
+
+  u32x4 a_hi[KS], a_lo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int kk = 16 * ks + 8 * h;
+    uint32_t w[8];
+    if (k % 8 == 0) {  // block-uniform: whole 8-word groups are inside or outside the row
+      const uint32_t off = kk < k ? (uint32_t)(((row0 + rl) * k + kk) * 4) : 0xfffffff0u;
+      const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0);
+      const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, kk < k ? off + 16 : 0xfffffff0u, 0, 0);
+      w[0] = v0[0], w[1] = v0[1], w[2] = v0[2], w[3] = v0[3], w[4] = v1[0], w[5] = v1[1], w[6] = v1[2], w[7] = v1[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        w[j] = __builtin_amdgcn_raw_buffer_load_b32(
+            a_rs, kk + j < k ? (uint32_t)(((row0 + rl) * k + kk + j) * 4) : 0xfffffff0u, 0, 0);
+    }
+    frags_from_words(w, a_hi[ks], a_lo[ks]);
+  }
+
+  u32x4 bh[2][KS], bl[2][KS];
+  auto load_b = [&](int n0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint32_t off = (uint32_t)(((int64_t)(n0 + 32 * j + rl) * KP + 16 * ks + 8 * h) * 2);  // cols >= n: out of range -> 0
+        bh[j][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, off, 0, 0));
+        bl[j][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, off, 0, 0));
+      }
+  };
+  load_b(0);
+  for (int n0 = 0; n0 < n; n0 += 64) {
+    f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      acc0 = mfma_bf16x3(a_hi[ks], a_lo[ks], bh[0][ks], bl[0][ks], acc0);
+      acc1 = mfma_bf16x3(a_hi[ks], a_lo[ks], bh[1][ks], bl[1][ks], acc1);
+    }
+    if (n0 + 64 < n) load_b(n0 + 64);  // in flight during the epilogue below
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int64_t g0 = row0 + acc_row(r, h), g1 = row0 + acc_row(r + 1, h);
+      uint32_t w00, w01, w10, w11;
+      split_pack2(alpha * acc0[r], alpha * acc0[r + 1], w00, w01);
+      split_pack2(alpha * acc1[r], alpha * acc1[r + 1], w10, w11);
+      const int c0 = n0 + rl, c1 = n0 + 32 + rl;
+      if (g0 < m) {
+        if (c0 < n) c[g0 * n + c0] = w00;
+        if (c1 < n) c[g0 * n + c1] = w10;
+      }
+      if (g1 < m) {
+        if (c0 < n) c[g1 * n + c0] = w01;
+        if (c1 < n) c[g1 * n + c1] = w11;
+      }
+    }
+  }
+}
+
 // out = alpha * sum_z partials[z]  (fp32 or packed words)
 template <bool OUT_PACKED>
 __global__ void reduce_splits_kernel(const float* __restrict__ partials, void* __restrict__ out, int64_t count,
@@ -189,6 +269,9 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partials, void* _
 }
 
 // One block: 128 (ka) x 64 (n) outputs over rows [split*chunk, (split+1)*chunk) in stages of 32 rows.
+// FAST (n % 4 == 0, operands < 4 GB): unconditional raw buffer loads bounded at the split's last row (rows
+// past it and columns past ka / n read as 0), stages prefetched 3 deep in registers like gemm_nn.
+template <bool FAST>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __restrict__ a,
                                                            const uint32_t* __restrict__ b,
                                                            float* __restrict__ partials, int64_t m, int ka, int n,
@@ -202,39 +285,54 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
   const int64_t mb = (int64_t)blockIdx.z * chunk;
   const int64_t me = min(m, mb + chunk);
   const bool b_vec = (n % 4) == 0;
+  const int64_t nst = me > mb ? (me - mb + BK - 1) / BK : 0;
 
-  u32x4 ra[4], rb[2];
-  auto load_tile = [&](int64_t mm) {
+  struct Stage { u32x4 a0, a1, a2, a3, b0, b1; };
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(a), (short)0, FAST ? (int)(uint32_t)(me * ka * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(b), (short)0, FAST ? (int)(uint32_t)(me * n * 4) : 0, 0x00020000);
+  const int arow = tid >> 5, acq = (tid & 31) * 4, brow = tid >> 4, bcq = (tid & 15) * 4;
+  const bool a_ok = ka0 + acq < ka, b_ok = n0 + bcq < n;
+  auto load_stage = [&](Stage& t, int64_t st) {
+    const int64_t mm = mb + st * BK;
+    if constexpr (FAST) {
+      const uint32_t oob = 0xfffffff0u;  // beyond num_records: the load returns 0
+      const uint32_t ao = a_ok ? (uint32_t)(((mm + arow) * ka + ka0 + acq) * 4) : oob;
+      const uint32_t bo = b_ok ? (uint32_t)(((mm + brow) * n + n0 + bcq) * 4) : oob;
+      const uint32_t as8 = (uint32_t)ka * 32u, bs16 = (uint32_t)n * 64u;
+      t.a0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, ao, 0, 0));
+      t.a1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_ok ? ao + as8 : oob, 0, 0));
+      t.a2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_ok ? ao + 2 * as8 : oob, 0, 0));
+      t.a3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_ok ? ao + 3 * as8 : oob, 0, 0));
+      t.b0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, bo, 0, 0));
+      t.b1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_ok ? bo + bs16 : oob, 0, 0));
+    } else {
+      u32x4* ta[4] = {&t.a0, &t.a1, &t.a2, &t.a3};
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = p * 8 + (tid >> 5), cq = (tid & 31) * 4;
-      const int64_t gr = mm + row;
-      ra[p] = ld4_words(a + gr * ka + ka0 + cq, gr < me ? ka - (ka0 + cq) : 0, true);
-    }
+      for (int p = 0; p < 4; ++p) {
+        const int64_t gr = mm + p * 8 + arow;
+        *ta[p] = ld4_words(a + gr * ka + ka0 + acq, gr < me ? ka - (ka0 + acq) : 0, true);
+      }
+      u32x4* tb[2] = {&t.b0, &t.b1};
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = p * 16 + (tid >> 4), cq = (tid & 15) * 4;
-      const int64_t gr = mm + row;
-      rb[p] = ld4_words(b + gr * n + n0 + cq, gr < me ? n - (n0 + cq) : 0, b_vec);
+      for (int p = 0; p < 2; ++p) {
+        const int64_t gr = mm + p * 16 + brow;
+        *tb[p] = ld4_words(b + gr * n + n0 + bcq, gr < me ? n - (n0 + bcq) : 0, b_vec);
+      }
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(&at[buf][p * 8 + (tid >> 5)][(tid & 31) * 4]) = ra[p];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(&bt[buf][p * 16 + (tid >> 4)][(tid & 15) * 4]) = rb[p];
+  auto store_stage = [&](const Stage& t, int buf) {
+    *reinterpret_cast<u32x4*>(&at[buf][arow][acq]) = t.a0;
+    *reinterpret_cast<u32x4*>(&at[buf][arow + 8][acq]) = t.a1;
+    *reinterpret_cast<u32x4*>(&at[buf][arow + 16][acq]) = t.a2;
+    *reinterpret_cast<u32x4*>(&at[buf][arow + 24][acq]) = t.a3;
+    *reinterpret_cast<u32x4*>(&bt[buf][brow][bcq]) = t.b0;
+    *reinterpret_cast<u32x4*>(&bt[buf][brow + 16][bcq]) = t.b1;
   };
 
   f32x16 acc0 = zero16(), acc1 = zero16();
-  const int64_t nst = me > mb ? (me - mb + BK - 1) / BK : 0;
-  if (nst > 0) {
-    load_tile(mb);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int64_t st = 0; st < nst; ++st) {
-    const int buf = (int)(st & 1);
-    if (st + 1 < nst) load_tile(mb + (st + 1) * BK);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint32_t wa[8], wb0[8], wb1[8];
@@ -252,8 +350,39 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
       frags_from_words(wb1, b_hi, b_lo);
       acc1 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc1);
     }
-    if (st + 1 < nst) store_tile(buf ^ 1);
+  };
+  if (nst > 0) {
+    Stage t0, t1, t2;
+    load_stage(t0, 0);
+    if (1 < nst) load_stage(t1, 1);
+    if (2 < nst) load_stage(t2, 2);
+    store_stage(t0, 0);
     __syncthreads();
+#define SE3_TN_STEP_FULL(ST, CUR, NEXT) \
+  load_stage(CUR, (ST) + 3);            \
+  compute((int)((ST) & 1));             \
+  store_stage(NEXT, (int)((ST) & 1) ^ 1); \
+  __syncthreads();
+#define SE3_TN_STEP(ST, CUR, NEXT)                                   \
+  if ((ST) < nst) {                                                  \
+    if ((ST) + 3 < nst) load_stage(CUR, (ST) + 3);                   \
+    compute((int)((ST) & 1));                                        \
+    if ((ST) + 1 < nst) store_stage(NEXT, (int)((ST) & 1) ^ 1);      \
+    __syncthreads();                                                 \
+  }
+    int64_t st = 0;
+    for (; st + 6 <= nst; st += 3) {
+      SE3_TN_STEP_FULL(st, t0, t1)
+      SE3_TN_STEP_FULL(st + 1, t1, t2)
+      SE3_TN_STEP_FULL(st + 2, t2, t0)
+    }
+    for (; st < nst; st += 3) {
+      SE3_TN_STEP(st, t0, t1)
+      SE3_TN_STEP(st + 1, t1, t2)
+      SE3_TN_STEP(st + 2, t2, t0)
+    }
+#undef SE3_TN_STEP
+#undef SE3_TN_STEP_FULL
   }
   float* out = partials + (int64_t)blockIdx.z * ka * n;
 #pragma unroll
@@ -322,6 +451,17 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
   ProfScope prof(tag, stream);
   const int kp = (k + 31) / 32 * 32;
   const int nkt = kp / BK;
+  if (out_packed && kp <= 64 && n >= 512 && m >= 128 * 256 && (m + 128) * (int64_t)k * 4 < (1ll << 32) - 64 &&
+      (int64_t)(n + 64) * kp * 2 < (1ll << 32) - 64) {
+    const dim3 sgrid((unsigned)((m + 127) / 128));
+    if (kp == 32)
+      hipLaunchKernelGGL(gemm_strip_bf16_kernel<2>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, (uint32_t*)c, m, n, k,
+                         alpha_num, alpha_scale);
+    else
+      hipLaunchKernelGGL(gemm_strip_bf16_kernel<4>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, (uint32_t*)c, m, n, k,
+                         alpha_num, alpha_scale);
+    return check_launch();
+  }
   int splits = split_ws ? gemm_nn_bf16_splits(m, n, k) : 1;
   const int per = (nkt + splits - 1) / splits;
   splits = (nkt + per - 1) / per;
@@ -369,7 +509,12 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
   chunk = (chunk + BK - 1) / BK * BK;
   if (chunk == 0) chunk = BK;
   const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
-  hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  const bool fast = (n % 4 == 0) && ((m + chunk) * (int64_t)ka * 4 < (1ll << 32) - 64) &&
+                    ((m + chunk) * (int64_t)n * 4 < (1ll << 32) - 64);
+  if (fast)
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  else
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
   return launch_reduce_partials(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, stream);
 }
 
