@@ -9,6 +9,8 @@
 //
 // Gathered operands (features, grad_out) are read as packed words (hi << 16 | lo) prepared by
 // split_pack_kernel; intermediates (T, grad_T, U) are written as packed words too.
+#include <cstdlib>
+
 #include "common.h"
 #include "edge_bf16_body.h"
 
@@ -83,7 +85,7 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], int
 // 32-bit buffer addressing, ds_bpermute for the per-row source offsets, branch-free GELU.
 // ------------------------------------------------------------------------------------------------
 template <int VW, int FC, bool FULL>
-__global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
+__global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
                                                              int64_t feat_rows, const float* __restrict__ axes_ext,
                                                              const float* __restrict__ rho_p,
                                                              uint32_t* __restrict__ t_out, int64_t n_items,
@@ -98,6 +100,23 @@ __global__ __launch_bounds__(256, 2) void edge_t_bf16_kernel(EdgeGeom g, const u
   const int row_words = channels * kBasis;
   edge_item_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, item, fnb_shift,
                                [&](int a, int off, uint32_t w) { t_rows[a * row_words + off] = w; });
+}
+
+// persistent variant (single channel pass): see edge_stream_bf16
+template <int VW, int FC, bool FULL>
+__global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_stream_bf16_kernel(
+    EdgeGeom g, const uint32_t* __restrict__ feat, int channels, int64_t feat_rows, const float* __restrict__ axes_ext,
+    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t n_items, int fnb_shift) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
+  if (threadIdx.x < 64) mlp_weights_to_lds<FC>(lds_w, axes_ext, threadIdx.x);
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * channels * 4);
+  const int64_t row_words = (int64_t)channels * kBasis;
+  const int64_t first = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  edge_stream_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, first, (int64_t)gridDim.x * 4, n_items, fnb_shift,
+                                 [&](int64_t item, int a, int off, uint32_t w) {
+                                   t_out[(item * FC + a) * row_words + off] = w;
+                                 });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,12 +457,37 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   if (rows == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   // two frames per wavefront share the gather; with 4 channel tiles per frame that would spill, so VW = 4 stays at 1
-  const int fc = (g.f_ctr % 2 == 0 && channels % 128 != 0) ? 2 : 1;
+  const int fc = (getenv("SE3_FC1") == nullptr && g.f_ctr % 2 == 0 && channels % 128 != 0) ? 2 : 1;
   const int64_t items = rows / fc;
   int shift = -1;
   for (int sft = 0; sft < 8; ++sft)
     if ((1 << sft) == g.f_nb) shift = sft;
-  const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+  const dim3 block(256);
+  if (channels <= 128 && getenv("SE3_NO_STREAM") == nullptr) {
+    // single channel pass: persistent wavefronts with cross-item prefetch, ~all wave slots of the chip filled
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int64_t want = (items + 3) / 4;
+    const int per_cu = fc == 1 ? 3 : 2;  // resident 256-thread blocks per CU at the kernels' register budgets
+    const dim3 pgrid((unsigned)(want < (int64_t)n_cu * per_cu ? want : (int64_t)n_cu * per_cu));
+#define SE3_STREAM(VW, FC, FULL)                                                                                     \
+  hipLaunchKernelGGL((edge_t_stream_bf16_kernel<VW, FC, FULL>), pgrid, block, 0, stream, g, feat, channels, feat_rows, \
+                     axes_ext, rho, t_out, items, shift)
+    if (channels == 128) SE3_STREAM(4, 1, true);
+    else if (channels == 64) { if (fc == 2) SE3_STREAM(2, 2, true); else SE3_STREAM(2, 1, true); }
+    else if (channels == 32) { if (fc == 2) SE3_STREAM(1, 2, true); else SE3_STREAM(1, 1, true); }
+    else if (channels < 32) { if (fc == 2) SE3_STREAM(1, 2, false); else SE3_STREAM(1, 1, false); }
+    else goto per_item;
+#undef SE3_STREAM
+    return check_launch();
+  }
+per_item:
+  const dim3 grid((unsigned)((items + 3) / 4));
 #define SE3_LAUNCH(VW, FC, FULL)                                                                                      \
   hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL>), grid, block, 0, stream, g, feat, channels, feat_rows,          \
                      axes_ext, rho, t_out, items, shift)
