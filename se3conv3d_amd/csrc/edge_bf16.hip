@@ -102,6 +102,157 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
                                [&](int a, int off, uint32_t w) { t_rows[a * row_words + off] = w; });
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-pair variant for 64 channels and two frames: the two output rows of an item are produced by a
+// 128-thread workgroup.  Wavefront v builds the descriptors, kernel MLP, GELU and hi/lo split for frame
+// a0+v only and publishes those B fragments through LDS (double buffered, one barrier per chunk); it then
+// aggregates channels 32v..32v+31 for BOTH frames.  No value is computed twice, and each wavefront
+// carries 32 accumulator registers instead of 64, which is what lets 3-4 wavefronts share a SIMD (the
+// single-wavefront kernel needs ~240 VGPRs: 2 per SIMD, 44 % of their life parked in s_waitcnt).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128, 4) void edge_t_pair_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+                                                                  int64_t feat_rows, const float* __restrict__ axes_ext,
+                                                                  const float* __restrict__ rho_p,
+                                                                  uint32_t* __restrict__ t_out, int64_t n_items,
+                                                                  int fnb_shift) {
+  constexpr int C = 64;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kcol = lane & 31, h = lane >> 5;
+  if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
+  __syncthreads();
+  const int64_t item = blockIdx.x;
+  if (item >= n_items) return;
+  const float rho = *rho_p;
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * C * 4);
+  const int groups = g.f_ctr / 2;
+  const int64_t ctr = item / groups;
+  const int a0 = (int)(item - ctr * groups) * 2;
+  const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
+  const int n_total = (g.ends[ctr] - start) * g.f_nb;
+  float yc[3], rc[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[(ctr * g.f_ctr + a0 + wv) * 9 + i];  // this wavefront's frame
+  const int hb = 16 * h;
+  const int cb4 = (32 * wv + kcol) * 4;  // this wavefront aggregates channels 32*wv .. 32*wv+31
+
+  auto edge_of = [&](int c0, int& nb, int& q) {
+    const int fe = min(c0 + kcol, n_total - 1);
+    int e, fn;
+    if (fnb_shift >= 0) {
+      e = start + (fe >> fnb_shift);
+      fn = fe & ((1 << fnb_shift) - 1);
+    } else {
+      e = start + fe / g.f_nb;
+      fn = fe % g.f_nb;
+    }
+    nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+    q = nb * g.f_nb + fn;
+  };
+  auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+  };
+
+  f32x16 acc[2] = {zero16(), zero16()};  // [frame]
+  int nb_nx = 0, q_nx = 0;
+  float xn_nx[3], rn_nx[9];
+  if (n_total > 0) {
+    edge_of(0, nb_nx, q_nx);
+    geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+  }
+  int buf = 0;
+  for (int c0 = 0; c0 < n_total; c0 += 32, buf ^= 1) {
+    const int cnt = min(32, n_total - c0);
+    const int qoff = q_nx * (C * 4);
+    float xn[3], rn[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+    const bool more = c0 + 32 < n_total;
+    if (more) edge_of(c0 + 32, nb_nx, q_nx);
+    if (!g.transposed)
+      edge_descriptor(xn, rn, yc, rc, rho, d);
+    else
+      edge_descriptor(yc, rc, xn, rn, rho, d);
+
+    // gathered feature fragments for this wavefront's 32 channels (shared by both frames)
+    u32x4 fa_hi[2], fa_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s * 16 < cnt) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+          w[j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + cb4, 0, 0);
+        }
+        frags_from_words(w, fa_hi[s], fa_lo[s]);
+      }
+    }
+    if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+
+    // kernel MLP + GELU for this wavefront's frame; both lane halves hold the same descriptor: half 0 feeds
+    // dims 0..7, half 1 dims 8, 9
+    {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
+      u32x4 a_hi, a_lo;
+      frags_from_floats(v, a_hi, a_lo);
+      const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
+      const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
+      const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s * 16 < cnt) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float y = gelu_erf(phi[8 * s + j]);
+            asm volatile("" : "+v"(y));
+            pv[j] = acc_row(8 * s + j, h) < cnt ? y : 0.f;
+          }
+          u32x4 b_hi, b_lo;
+          frags_from_floats(pv, b_hi, b_lo);
+          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
+          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
+        }
+      }
+    }
+    __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s * 16 < cnt) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const u32x4 b_hi = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
+          const u32x4 b_lo = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
+          acc[a] = mfma_bf16x3(fa_hi[s], fa_lo[s], b_hi, b_lo, acc[a]);
+        }
+      }
+    }
+  }
+  // acc[a] register r, lane (kcol, h) = T[row 2*item + a][32*wv + acc_row(r,h)][kcol]
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    uint32_t* t_row = t_out + ((item * 2 + a) * (int64_t)C + 32 * wv) * kBasis;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      uint32_t w0, w1;
+      split_pack2(acc[a][r], acc[a][r + 1], w0, w1);
+      t_row[acc_row(r, h) * kBasis + kcol] = w0;
+      t_row[acc_row(r + 1, h) * kBasis + kcol] = w1;
+    }
+  }
+}
+
 // persistent variant (single channel pass): see edge_stream_bf16
 template <int VW, int FC, bool FULL>
 __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_stream_bf16_kernel(
@@ -463,7 +614,12 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   for (int sft = 0; sft < 8; ++sft)
     if ((1 << sft) == g.f_nb) shift = sft;
   const dim3 block(256);
-  if (channels <= 128 && getenv("SE3_NO_STREAM") == nullptr) {
+  if (channels == 64 && fc == 2 && getenv("SE3_NO_PAIR") == nullptr) {
+    hipLaunchKernelGGL(edge_t_pair_bf16_kernel, dim3((unsigned)items), dim3(128), 0, stream, g, feat, feat_rows, axes_ext,
+                       rho, t_out, items, shift);
+    return check_launch();
+  }
+  if (channels <= 128 && getenv("SE3_STREAM") != nullptr) {
     // single channel pass: persistent wavefronts with cross-item prefetch, ~all wave slots of the chip filled
     static int n_cu = 0;
     if (n_cu == 0) {

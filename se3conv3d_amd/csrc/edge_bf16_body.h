@@ -6,6 +6,9 @@
 #ifndef SE3_ABLATE
 #define SE3_ABLATE 0  // diagnostic builds only (tools/ablate.sh): 1 no GELU, 2 no feature gather, 3 no geometry gather, 4 no stores
 #endif
+#ifndef SE3_ABLATE_MASK
+#define SE3_ABLATE_MASK (SE3_ABLATE ? (1 << (SE3_ABLATE - 1)) : 0)
+#endif
 
 #include "common.h"
 
@@ -91,7 +94,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
       q = nb * g.f_nb + fn;
     };
     auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-#if SE3_ABLATE == 3
+#if SE3_ABLATE_MASK & 4
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = (float)(nb & 255) * 0.001f + i;
 #pragma unroll
@@ -153,7 +156,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
             // byte offset of the source row of frame-edge acc_row(8s+j, h), fetched from the lane that owns it
             const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
             const int voff = src_off + cb4;
-#if SE3_ABLATE == 2
+#if SE3_ABLATE_MASK & 2
             if constexpr (VW >= 1) {
 #pragma unroll
               for (int t = 0; t < VW; ++t) w[t][j] = (uint32_t)voff * 2654435761u + t;
@@ -197,7 +200,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
             float pv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-#if SE3_ABLATE == 1
+#if SE3_ABLATE_MASK & 1
               float y = phi[8 * s + j];
 #else
               float y = gelu_erf(phi[8 * s + j]);
@@ -223,7 +226,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
           const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
           uint32_t w0, w1;
           split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
-#if SE3_ABLATE == 4
+#if SE3_ABLATE_MASK & 8
           asm volatile("" ::"v"(w0), "v"(w1));
           if (w0 == 0x12345678u) sink(a, ch0 * kBasis + kcol, w0);
 #else

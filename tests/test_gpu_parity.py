@@ -336,3 +336,107 @@ def test_headline_subset_against_oracle(headline, amd):
                          x.cpu(), conv.proj_axes_.detach().cpu(), conv.proj_biases_.detach().cpu(),
                          conv.conv_weights_.detach().cpu(), conv.norm_neigh_dist_.cpu(), conv.norm_num_neighs_.cpu())
     assert rel_err(out[int(sel[0]) * 2:(int(sel[-1]) + 1) * 2], ref) < tol(amd)
+
+
+# ---- other BASELINE.json configurations as parity cases --------------------------------------------------
+def test_scannet_like_single_frame_fixed_axis(amd):
+    """configs[2]: F = 1 frames about a fixed up-axis, a 150k-point scene, C_in = 3 colours -> 64 channels.
+    Size-independent checks: rotation about the up-axis leaves the output unchanged, rows without the
+    operator's own float atomics are bit-reproducible, a slice matches the oracle."""
+    torch.manual_seed(1)
+    n = 150000
+    pts = torch.rand(n, 3, device=DEV) * torch.tensor([8.0, 6.0, 2.5], device=DEV)
+    bid = torch.zeros(n, dtype=torch.int32, device=DEV)
+    pc = amd.pc.PointcloudRotEquiv(pts, bid, {"pca": False, "n_frames": 1, "fixed_axis": 2})
+    fr = pc.local_frames_.reshape(n, 3, 3)
+    assert torch.allclose(fr[:, 2, 2], torch.ones(n, device=DEV)) and float(fr[:, 2, :2].abs().max()) == 0.0
+    r = 0.12
+    nbh = amd.pc.BQNeighborhood(pc, pc, r)
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(3, 64).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r)
+    conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / nbh.neighbors_.shape[0])
+    x = torch.rand(n, 3, device=DEV).requires_grad_(True)
+    out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
+    out.backward(torch.ones_like(out))
+    assert out.shape == (n, 64) and bool(torch.isfinite(out).all()) and bool(torch.isfinite(x.grad).all())
+    out2 = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
+    assert torch.equal(out, out2)  # deterministic: no atomics anywhere on the path
+    # rotate the scene about z (points and frames): same graph, same output
+    c, s = math.cos(0.7), math.sin(0.7)
+    rot = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], device=DEV)
+    pc_r = amd.pc.PointcloudRotEquiv.from_frames(pts @ rot.t(), bid, torch.einsum("nm,iml->inl", rot, fr).reshape(n, 1, 9))
+    nbh_r = amd.pc.BQNeighborhood.__new__(amd.pc.BQNeighborhood)
+    nbh_r.neighbors_, nbh_r.start_ids_, nbh_r.radius_ = nbh.neighbors_, nbh.start_ids_, nbh.radius_
+    with torch.no_grad():
+        out_r = conv(p_pc_in=pc_r, p_pc_out=pc_r, p_in_features=x, p_neighborhood=nbh_r)
+    assert rel_err(out_r, out) < tol(amd)
+    # slice against the oracle
+    ends = nbh.start_ids_.long().cpu()
+    sel = torch.arange(70000, 70032)
+    e0, e1 = int(ends[sel[0] - 1]), int(ends[sel[-1]])
+    nb = nbh.neighbors_[e0:e1].cpu().clone()
+    nb[:, 0] -= int(sel[0])
+    ref = O.conv_forward(pts.cpu(), pts[sel].cpu(), pc.local_frames_.cpu(), pc.local_frames_[sel].cpu(), nb,
+                         x.detach().cpu(), conv.proj_axes_.detach().cpu(), conv.proj_biases_.detach().cpu(),
+                         conv.conv_weights_.detach().cpu(), conv.norm_neigh_dist_.cpu(), conv.norm_num_neighs_.cpu())
+    assert rel_err(out[int(sel[0]):int(sel[-1]) + 1], ref) < tol(amd)
+
+
+def test_dfaust_like_four_frames_batched(amd):
+    """configs[3]: F = 4 frames, a batch of ~6.9k-point bodies (batch ids in the grid keys), down-conv between
+    two levels of the hierarchy with C 32 -> 64 -- against the oracle."""
+    torch.manual_seed(2)
+    b, n_per = 3, 2300
+    pts = torch.rand(b * n_per, 3, device=DEV)
+    bid = torch.arange(b, dtype=torch.int32, device=DEV).repeat_interleave(n_per)
+    pc0 = amd.pc.PointcloudRotEquiv(pts, bid, {"pca": False, "n_frames": 4, "fixed_axis": False})
+    hier = amd.pc.PointHierarchyRotEquiv(pc0, 1, "grid_avg", grid_radii=[0.1])
+    pc1 = hier.pcs_[1]
+    assert int(pc1.batch_ids_.max()) == b - 1 and pc1.n_frames_ == 4
+    nbh = hier.create_neighborhood(0, 1, "ball_query", bq_radius=0.2)
+    assert hier.create_neighborhood(0, 1, "ball_query", bq_radius=0.2) is nbh  # memoised like the reference
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(32, 64).to(DEV)
+    conv.norm_neigh_dist_.fill_(5.0)
+    conv.norm_num_neighs_.fill_(0.02)
+    x = torch.randn(pts.shape[0] * 4, 32, device=DEV).requires_grad_(True)
+    out = conv(p_pc_in=pc0, p_pc_out=pc1, p_in_features=x, p_neighborhood=nbh)
+    g = torch.randn_like(out)
+    out.backward(g)
+    nb_ref, ends_ref = O.ball_query(pts.cpu(), pc1.pts_.cpu(), bid.cpu(), pc1.batch_ids_.cpu(), 0.2)
+    assert torch.equal(nbh.start_ids_.cpu(), ends_ref) and torch.equal(canon_edges(nbh.neighbors_), canon_edges(nb_ref))
+    ref = O.conv_forward_backward(pts.cpu(), pc1.pts_.cpu(), pc0.local_frames_.cpu(), pc1.local_frames_.cpu(), nb_ref,
+                                  x.detach().cpu(), conv.proj_axes_.detach().cpu(), conv.proj_biases_.detach().cpu(),
+                                  conv.conv_weights_.detach().cpu(), torch.tensor(5.0), torch.tensor(0.02), g.cpu())
+    got = (out, x.grad, conv.proj_axes_.grad, conv.proj_biases_.grad, conv.conv_weights_.grad)
+    for u, v in zip(got, ref):
+        assert rel_err(u, v) < tol(amd)
+    # frame pooling of the result (what the segmentation models apply last)
+    pooled = pc1.feature_pooling(out.detach(), "avg")
+    assert pooled.shape == (pc1.pts_.shape[0], 64)
+    assert rel_err(pooled, out.detach().reshape(-1, 4, 64).mean(1)) == 0.0
+
+
+def test_state_dict_and_init_match_reference_layout(amd):
+    """Checkpoint compatibility: parameter / buffer names, shapes, dtypes and the init ranges of
+    PNEConvLayer.py:79-88,151-158 / IConvLayer.py:33-36."""
+    torch.manual_seed(0)
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(48, 96)
+    sd = conv.state_dict()
+    assert list(sd) == ["proj_axes_", "proj_biases_", "conv_weights_", "norm_neigh_dist_", "norm_num_neighs_"]
+    assert sd["proj_axes_"].shape == (9, 32) and sd["proj_biases_"].shape == (32,)
+    assert sd["conv_weights_"].shape == (48, 32, 96)
+    assert sd["norm_neigh_dist_"].shape == () and float(sd["norm_neigh_dist_"]) == 0.0
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    assert float(sd["proj_axes_"].abs().max()) <= math.sqrt(1 / 9) and float(sd["proj_biases_"].abs().max()) == 0.0
+    assert float(sd["conv_weights_"].abs().max()) <= math.sqrt(1 / (48 * 32))
+    assert float(sd["conv_weights_"].std()) > 0.5 * math.sqrt(1 / (48 * 32)) / math.sqrt(3)
+    d = load_npz(FILES[0])
+    ref_like = {"proj_axes_": d["proj_axes"], "proj_biases_": d["proj_biases"], "conv_weights_": d["conv_weights"],
+                "norm_neigh_dist_": d["rho"], "norm_num_neighs_": d["nu"]}
+    c2 = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(32, 32)
+    c2.load_state_dict(ref_like, strict=True)
+    fac = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu")
+    fac.update_parameters(num_basis=32)
+    assert fac.create_conv_layer(8, 8) in fac.conv_list_
+    with pytest.raises(Exception):
+        amd.PNEConvLayerRotEquivFactory(9, 32, "kp_gauss").create_conv_layer(8, 8)(None, None, None, None)
