@@ -1,4 +1,5 @@
 // extern "C" entry points of the fused operator + the API-parity ops (see include/se3conv.h).
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -212,6 +213,7 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
 
 struct BwdLayout {
   size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, split, total;
+  size_t big_u, bt2_hi, bt2_lo, split2;  // feature-gradient branch when it runs beside the parameter branch
   int n_param_partials, tn_splits;
 };
 BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
@@ -244,6 +246,13 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   if (want_params) big = rows_out * s->c_in * kb * 4;
   if (want_feat && rows_in * s->c_out * kb * 4 > big) big = rows_in * s->c_out * kb * 4;
   l.big = take(big);
+  if (fast && want_feat && want_params) {
+    l.big_u = take(rows_in * s->c_out * kb * 4);
+    const size_t p2 = (size_t)s->c_in * align_up((size_t)s->c_out * kb, 32) * 2;
+    l.bt2_hi = take(p2);
+    l.bt2_lo = take(p2);
+    l.split2 = take(gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb));
+  }
   l.t = (want_params && !have_t) ? take(rows_out * s->c_in * kb * 4) : 0;
   l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
   l.param_partials = want_params ? take((size_t)l.n_param_partials * kDescExt * kBasis * 4) : 0;
@@ -251,6 +260,27 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   l.tn_partials = want_params ? take((size_t)l.tn_splits * wsz) : 0;
   l.total = off;
   return l;
+}
+
+// Optional second stream for the backward pass (SE3_OVERLAP=1): the parameter branch (grad_T GEMM ->
+// edge_param_grad, weight-gradient GEMM) and the feature branch (transposed edge kernel -> grad_X GEMM) are
+// independent.  Measured on MI355X at the headline shape: 2.90 ms with the branches side by side vs 2.89 ms
+// back to back -- the kernels slow each other down in proportion (both are limited by the memory system), so
+// it is off by default.  The stream and its two events are created once per process.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+SideStream& side_stream() {
+  static SideStream ss = [] {
+    SideStream v;
+    v.ok = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&v.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&v.join, hipEventDisableTiming) == hipSuccess;
+    return v;
+  }();
+  return ss;
 }
 
 EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
@@ -470,6 +500,35 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   uint32_t* gpk = (uint32_t*)(ws + l.gpk);
   uint32_t* bigw = (uint32_t*)big;
   if (int rc = launch_split_pack(grad_out, gpk, rows_out * s->c_out, stream)) return rc;
+  bool branch_forked = false;
+  SideStream& side = side_stream();
+  if (want_feat && rows_in > 0) {
+    // feature branch: on the side stream when there is a parameter branch to overlap with
+    hipStream_t fs = stream;
+    uint16_t *fbh = bt_hi, *fbl = bt_lo;
+    uint32_t* ubuf = bigw;
+    float* fsplit = (float*)(ws + l.split);
+    if (want_params && l.big_u != 0 && side.ok && getenv("SE3_OVERLAP") != nullptr) {
+      if (hipEventRecord(side.fork, stream) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess)
+        return SE3_ERR_LAUNCH;
+      fs = side.stream;
+      fbh = (uint16_t*)(ws + l.bt2_hi), fbl = (uint16_t*)(ws + l.bt2_lo);
+      ubuf = (uint32_t*)(ws + l.big_u);
+      fsplit = (float*)(ws + l.split2);
+      branch_forked = true;
+    }
+    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, fbh, fbl, fs)) return rc;
+    if (conv_fused_bf16_supported(gt, s->c_out)) {
+      if (int rc = launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, fbh, fbl, s->c_in, grad_feat,
+                                          nullptr, nu, inv_fin, fs))
+        return rc;
+    } else {
+      if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs)) return rc;
+      if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, fbh, fbl, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
+                                       fsplit, nu, inv_fin, fs))
+        return rc;
+    }
+  }
   if (want_params) {
     uint32_t* featpk = (uint32_t*)(ws + l.featpk);
     if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
@@ -496,15 +555,9 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
         return rc;
     }
   }
-  if (want_feat && rows_in > 0) {
-    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, bt_hi, bt_lo, stream)) return rc;
-    if (conv_fused_bf16_supported(gt, s->c_out))
-      return launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, bt_hi, bt_lo, s->c_in,
-                                    grad_feat, nullptr, nu, inv_fin, stream);
-    if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, bigw, stream)) return rc;
-    if (int rc = launch_gemm_nn_bf16("gemm_gradX", bigw, bt_hi, bt_lo, grad_feat, false, rows_in, s->c_in,
-                                     s->c_out * kb, (float*)(ws + l.split), nu, inv_fin, stream))
-      return rc;
+  if (branch_forked) {
+    if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(stream, side.join, 0) != hipSuccess)
+      return SE3_ERR_LAUNCH;
   }
   return check_launch();
 }
