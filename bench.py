@@ -105,12 +105,13 @@ def layer_flops(n, e):
 def stage_bytes(n, e):
     """HBM bytes each kernel of the (unfused) pipeline has to move at least: its gathered rows counted
     once per edge (uncached-gather model), its dense operands and results once."""
-    ep_pt = e * FRAMES            # (edge, neighbour frame) pairs: one C-row gather each per centre frame pass
     rows = n * FRAMES
     t_bytes = 4 * rows * CH * KB  # T / grad_T / U: [rows, C, K] words
     geom = 8 * e + 4 * n + 12 * 2 * n + 36 * 2 * rows
     w = 4 * CH * KB * CH
-    edge = geom + 4 * ep_pt * CH * FRAMES + t_bytes
+    # every point-edge touches its neighbour's F*C block once per pass (SURVEY.md section 8d); the two centre
+    # frames of a point share that gather
+    edge = geom + 4 * e * FRAMES * CH + t_bytes
     return {"edge_t_fwd": edge, "edge_t_transposed": edge, "edge_param_grad": edge,
             "gemm_out": t_bytes + w + 4 * rows * CH, "gemm_gradT": t_bytes + w + 4 * rows * CH,
             "gemm_gradX": t_bytes + w + 4 * rows * CH, "gemm_gradW": t_bytes + 4 * rows * CH + w,
@@ -256,6 +257,12 @@ def main():
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
                         "frac": round(frac_mfma, 4), "traffic": None, "algorithmic_flops_per_launch": fl.get(dom, 0),
                         "hbm_frac": round(frac_hbm, 4)}
+        try:  # measured PMC traffic of the same kernel (separate rocprofv3 --pmc passes, committed under profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                tr = json.load(fh).get(dom) if args.precision == "bf16x3" else None
+            roofline["traffic"] = tr["hbm_bytes"] if tr else None
+        except OSError:
+            pass
         roofline.update({"avg_launch_ms": round(stages[dom][0], 4), "launches": stages[dom][1],
                          "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}})
     lb = layer_bytes(levels[0]["n"], levels[0]["e"])
