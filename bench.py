@@ -39,10 +39,6 @@ def build_stack(amd, O, device, seed):
     cfg = {"pca": False, "n_frames": FRAMES, "fixed_axis": False}
     r0 = O.radius_for_degree(N0, K_DEG)
     pts = torch.rand(N0, 3, device=device)
-    if os.environ.get("SE3_BENCH_SORT", "0") == "1":  # experiment: spatially coherent point order
-        cell = (pts / r0).floor().long()
-        key = (cell[:, 0] * 4096 + cell[:, 1]) * 4096 + cell[:, 2]
-        pts = pts[torch.argsort(key)].contiguous()
     bid = torch.zeros(N0, dtype=torch.int32, device=device)
     pc0 = amd.pc.PointcloudRotEquiv(pts, bid, cfg)
     hier = amd.pc.PointHierarchyRotEquiv(pc0, 3, "grid_avg", grid_radii=[r0, 2 * r0, 4 * r0])
