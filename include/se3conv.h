@@ -78,6 +78,13 @@ int se3_compute_keys(const float* pts, const int32_t* batch_ids, const float* aa
                      const int32_t* num_cells, const float* cell_size, int64_t n, int64_t* keys,
                      void* stream);
 
+/* Per-batch axis-aligned bounding boxes: aabb_min / aabb_max [n_batches,3] f32 (batches without points:
+ * +inf / -inf).  Stands in for the torch_scatter scatter_min / scatter_max calls of
+ * point_cloud_lib/custom_ops/BallQuery.py:35-36 and point_cloud_lib/pc/BoundingBox.py:17-18 (the callers then
+ * apply their -1e-6 / +1e-6 shifts themselves). */
+int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float* aabb_min,
+                   float* aabb_max, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ball query  <-  point_cloud_lib_ops.ball_query
  *   (custom_ops/ball_query/ball_query.cuh:30-38, host ball_query.cu:22-103; max_neighbors = 0,
@@ -181,6 +188,24 @@ int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_i
                 const se3conv_shape* shape, float* grad_feat, float* grad_axes,
                 float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * reference frames (scope row f-1: upstream of the operator, frames are an input of the hot path)
+ *   se3_knn_query  <-  point_cloud_lib_ops.knn_query (custom_ops/knn_query/knn_query.cuh:25-28, kernel
+ *     knn_query.cu:18-132): exact k nearest neighbours inside the point's batch element (batch ids sorted),
+ *     the point itself first, ascending distance, ties to the lower index, -1 padded; k <= 32.
+ *     pts [n,3] f32, batch_ids [n] i32 -> out [n,k] i32.
+ *   se3_pca_frames <-  sample_reference_frames_pca (point_cloud_lib/pc/RotationFunctions.py:307-406):
+ *     covariance of the k neighbours (missing ones = the point itself), symmetric 3x3 eigen-decomposition,
+ *     right-handed orientation fix and the sign-flipped copies.  axis_fixed < 0: frames [n,4,9] (eigenvalues
+ *     ascending, column c scaled by the patterns (1,1,1),(1,-1,-1),(-1,1,-1),(-1,-1,1)); axis_fixed = 1 or 2:
+ *     frames [n,2,9] (that coordinate zeroed, eigenvalues descending, patterns (1,1,1),(-1,-1,1), the fixed axis
+ *     as +e_axis -- its sign is implementation-defined in the reference's LAPACK call).
+ * ------------------------------------------------------------------------------------------- */
+int se3_knn_query(const float* pts, const int32_t* batch_ids, int64_t n, int32_t k, int32_t* out,
+                  void* stream);
+int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, int32_t axis_fixed,
+                   float* frames, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optional per-kernel timing for bench.py's roofline line (no reference counterpart: the reference

@@ -192,6 +192,53 @@ def random_frames(n: int, f: int, generator: torch.Generator | None = None) -> t
     return quaternion_to_matrix(o).reshape(n, f, 9)
 
 
+def knn_query(pts: torch.Tensor, batch_ids: torch.Tensor, k: int) -> torch.Tensor:
+    """Exact self-kNN inside each batch element (OPS/knn_query/knn_query.cu:18-132): the point itself first,
+    ascending squared distance, ties to the lower index (strict ``>`` at :68), ``-1`` padded.  ``[N,k]`` int32."""
+    pts = pts.to(torch.float32)
+    n = pts.shape[0]
+    out = torch.full((n, k), -1, dtype=torch.int32)
+    for b in torch.unique(batch_ids):
+        idx = torch.nonzero(batch_ids == b)[:, 0]
+        p = pts[idx]
+        d = p[:, None, :] - p[None, :, :]
+        d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+        order = torch.argsort(d2, dim=1, stable=True)[:, :k]
+        out[idx, : order.shape[1]] = idx[order].to(torch.int32)
+    return out
+
+
+def sample_reference_frames_pca(points: torch.Tensor, knn_ids: torch.Tensor, axis_fixed=False) -> torch.Tensor:
+    """PCA frames (PCL/pc/RotationFunctions.py:307-406) from fixed-k neighbour ids ``[N,k]`` (-1 = missing ->
+    the point itself, :314-317).  Free case: covariance of the centred neighbours, ``torch.linalg.eigh``
+    (ascending), whole matrix negated where det < 0, then the four column sign patterns with product +1
+    -> ``[N,4,9]``.  Fixed axis (1 or 2): that coordinate zeroed, eigenpairs flipped to descending, patterns
+    (1,1,1), (-1,-1,1), column permutation for axis 1, |x| < 1e-6 -> 0 -> ``[N,2,9]``."""
+    n, k = knn_ids.shape
+    ids = knn_ids.to(torch.int64).clone()
+    rows = torch.arange(n)[:, None].expand(-1, k)
+    ids[ids < 0] = rows[ids < 0]
+    nm = points[ids].clone()  # [N,k,3]
+    fixed = bool(axis_fixed)
+    if fixed:
+        nm[:, :, int(axis_fixed)] = 0
+    nm = nm - nm.mean(dim=1, keepdim=True)
+    c = torch.einsum("bij,bjk->bik", nm.transpose(1, 2), nm)
+    _, vec = torch.linalg.eigh(c)
+    if fixed:
+        vec = torch.flip(vec, dims=[-1])
+    vec = vec.clone()
+    vec[torch.linalg.det(vec) < 0] *= -1
+    pats = [(1, 1, 1), (-1, -1, 1)] if fixed else [(1, 1, 1), (1, -1, -1), (-1, 1, -1), (-1, -1, 1)]
+    pm = torch.tensor(pats, dtype=vec.dtype)[:, None, :]  # [P,1,3]: scales the columns
+    frames = pm[None] * vec[:, None]
+    if fixed:
+        if int(axis_fixed) == 1:
+            frames = frames[:, :, :, [0, 2, 1]]
+        frames = torch.where(frames.abs() < 1e-6, torch.zeros_like(frames), frames)
+    return frames.reshape(n, len(pats), 9)
+
+
 # ----------------------------------------------------------------------------------------------
 # a1: frame-edge list and 9-D descriptors  (PCL/layers/PNEConvLayerRotEquiv.py:62-128)
 # ----------------------------------------------------------------------------------------------

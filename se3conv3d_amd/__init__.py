@@ -13,9 +13,9 @@ not been built (``python -m se3conv3d_amd.build``).
 from . import layers, ops, pc  # noqa: F401
 from .layers import (IConvLayer, IConvLayerFactory, PNEConvLayerRotEquiv,  # noqa: F401
                      PNEConvLayerRotEquivFactory, PreProcessModule)
-from .ops import (BallQuery, ComputeKeys, FeatBasisProj, SE3ConvFunction, get_precision,  # noqa: F401
-                  set_precision)
-from .pc import (BQNeighborhood, Pointcloud, PointcloudRotEquiv, PointHierarchy,  # noqa: F401
+from .ops import (BallQuery, ComputeKeys, FeatBasisProj, KNNQuery, SE3ConvFunction,  # noqa: F401
+                  get_precision, set_precision)
+from .pc import (BQNeighborhood, KnnNeighborhood, Pointcloud, PointcloudRotEquiv, PointHierarchy,  # noqa: F401
                  PointHierarchyRotEquiv)
 
 __version__ = "0.1.0"

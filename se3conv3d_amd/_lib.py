@@ -40,6 +40,7 @@ SIGNATURES = {
     "se3_abi_version": (C.c_int, []),
     "se3_error_string": (C.c_char_p, [C.c_int]),
     "se3_compute_keys": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "se3_batch_aabb": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
     "se3_ball_query_workspace_bytes": (_SZ, [_I64, _I64]),
     "se3_ball_query_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _SZ, _P, _P]),
     "se3_ball_query_store": (C.c_int, [_P, _P, _F, _I64, _I64, _P, _SZ, _P, _I64, _P, _P]),
@@ -52,6 +53,8 @@ SIGNATURES = {
     "se3conv_fwd": (C.c_int, [_P] * 12 + [_SHP, _P, _P, _P, _SZ, _P]),
     "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
     "se3conv_bwd": (C.c_int, [_P] * 16 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
+    "se3_knn_query": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "se3_pca_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_profile_enable": (C.c_int, [C.c_int]),
     "se3_profile_reset": (C.c_int, []),
     "se3_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

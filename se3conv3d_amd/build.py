@@ -17,7 +17,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libse3conv_hip.so")
-SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "gemm.hip", "gemm_bf16.hip", "fused_bf16.hip", "api.hip"]
+SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "gemm.hip", "gemm_bf16.hip", "fused_bf16.hip", "frames.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_bf16_body.h"), os.path.join(os.path.dirname(PKG), "include", "se3conv.h")]
 ARCH = "gfx950"
 FLAGS = os.environ.get("SE3_CXXFLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,260 @@
+// Reference-frame construction (scope row f-1): exact self-kNN and per-point PCA frames.
+//
+//   se3_knn_query  <- point_cloud_lib_ops.knn_query (custom_ops/knn_query/knn_query.cu:18-196): the k nearest
+//                     points of the same batch element, the point itself first, ascending distance, -1 padded.
+//   se3_pca_frames <- sample_reference_frames_pca (point_cloud_lib/pc/RotationFunctions.py:307-406): covariance
+//                     of the k neighbours, symmetric 3x3 eigen-decomposition, orientation fix, sign-flipped copies.
+//
+// kNN is a tiled all-pairs scan inside the batch segment (batch ids are sorted, as everywhere in the
+// reference): one query per thread, candidate tiles staged in LDS, the k best kept in registers by an
+// unrolled insertion.  N = 65k: 4.3 G distance tests ~ 1 ms; it runs once per hierarchy level.
+#include "common.h"
+
+namespace se3 {
+
+namespace {
+
+constexpr int kKnnQueries = 64;  // queries per block (one per lane)
+constexpr int kKnnSlices = 8;    // wavefronts per block, each scanning 1/8 of the candidate range
+
+// A block owns 64 consecutive queries; its 8 wavefronts scan disjoint slices of the candidate range (all-pairs
+// inside the batch segment), each keeping the K best per query in registers; the 8 partial lists meet in LDS
+// and wavefront 0 merges them.  8x the wavefronts of the one-wave-per-64-queries version (which left 3 of 4
+// SIMD slots idle and serialised on LDS latency).
+template <int K>
+__global__ __launch_bounds__(kKnnQueries* kKnnSlices) void knn_kernel(const float* __restrict__ pts,
+                                                                       const int32_t* __restrict__ batch_ids,
+                                                                       int64_t n, int k_out,
+                                                                       int32_t* __restrict__ out) {
+  __shared__ float4 tile[kKnnSlices][64];  // per wavefront: x, y, z, batch id (as bits)
+  __shared__ float m_d[kKnnSlices][K][kKnnQueries];
+  __shared__ int m_i[kKnnSlices][K][kKnnQueries];
+  __shared__ int64_t s_lo, s_hi;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kKnnQueries + lane;
+  const bool active = i < n;
+  const int64_t ic = active ? i : n - 1;
+  const float qx = pts[ic * 3], qy = pts[ic * 3 + 1], qz = pts[ic * 3 + 2];
+  const int qb = batch_ids[ic];
+  if (threadIdx.x == 0) {
+    // candidate range of the block: batch ids are sorted, so [first point of the first query's batch,
+    // last point of the last query's batch]
+    const int64_t first = (int64_t)blockIdx.x * kKnnQueries;
+    const int64_t last = min(n, first + kKnnQueries) - 1;
+    const int b0 = batch_ids[first], b1 = batch_ids[last];
+    int64_t lo = 0, hi = first;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] < b0) lo = mid + 1; else hi = mid; }
+    s_lo = lo;
+    lo = last, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] <= b1) lo = mid + 1; else hi = mid; }
+    s_hi = lo;
+  }
+  __syncthreads();
+  float best_d[K];
+  int best_i[K];
+#pragma unroll
+  for (int e = 0; e < K; ++e) best_d[e] = 1e10f, best_i[e] = -1;
+  auto insert = [&](float d, int j) {
+    // strict '<' keeps the earlier index among equal distances (knn_query.cu:68 `best_dist[e1] > tmp_dist`);
+    // slices are scanned in ascending index order and merged in slice order, so this holds globally
+    best_d[K - 1] = d;
+    best_i[K - 1] = j;
+#pragma unroll
+    for (int e = K - 1; e > 0; --e) {
+      const bool sw = best_d[e] < best_d[e - 1];
+      const float dl = sw ? best_d[e] : best_d[e - 1], dh = sw ? best_d[e - 1] : best_d[e];
+      const int il = sw ? best_i[e] : best_i[e - 1], ih = sw ? best_i[e - 1] : best_i[e];
+      best_d[e - 1] = dl, best_d[e] = dh, best_i[e - 1] = il, best_i[e] = ih;
+    }
+  };
+  // slice of this wavefront (multiples of 64 candidates)
+  const int64_t total = s_hi - s_lo;
+  const int64_t per = ((total + kKnnSlices - 1) / kKnnSlices + 63) / 64 * 64;
+  const int64_t w_lo = s_lo + wave * per, w_hi = min(s_hi, w_lo + per);
+  for (int64_t t0 = w_lo; t0 < w_hi; t0 += 64) {
+    const int64_t j = t0 + lane;
+    if (j < w_hi) tile[wave][lane] = make_float4(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], __int_as_float(batch_ids[j]));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int cnt = (int)min((int64_t)64, w_hi - t0);
+#pragma unroll 4
+    for (int c = 0; c < cnt; ++c) {
+      const float4 p = tile[wave][c];
+      const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (d < best_d[K - 1] && __float_as_int(p.w) == qb) insert(d, (int)(t0 + c));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int e = 0; e < K; ++e) m_d[wave][e][lane] = best_d[e], m_i[wave][e][lane] = best_i[e];
+  __syncthreads();
+  if (wave == 0) {
+    // merge the other slices' lists in slice order (their indices are larger: ties keep the lower index)
+    for (int w = 1; w < kKnnSlices; ++w)
+#pragma unroll
+      for (int e = 0; e < K; ++e) {
+        const float d = m_d[w][e][lane];
+        const int j = m_i[w][e][lane];
+        if (j >= 0 && d < best_d[K - 1]) insert(d, j);
+      }
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < K; ++e)
+        if (e < k_out) out[i * k_out + e] = best_i[e];
+    }
+  }
+}
+
+// Cyclic Jacobi for a symmetric 3x3 matrix: a <- V^T a V diagonal, columns of V = eigenvectors.
+__device__ __forceinline__ void jacobi3(float a[3][3], float v[3][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[i][j] = i == j ? 1.f : 0.f;
+  for (int sweep = 0; sweep < 10; ++sweep) {
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      const float apq = a[p][q];
+      if (fabsf(apq) > 1e-30f) {
+        const float theta = (a[q][q] - a[p][p]) / (2.f * apq);
+        const float t = copysignf(1.f, theta) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+        const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {  // a <- a J
+          const float arp = a[r][p], arq = a[r][q];
+          a[r][p] = c * arp - s * arq, a[r][q] = s * arp + c * arq;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {  // a <- J^T a
+          const float apr = a[p][r], aqr = a[q][r];
+          a[p][r] = c * apr - s * aqr, a[q][r] = s * apr + c * aqr;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float vrp = v[r][p], vrq = v[r][q];
+          v[r][p] = c * vrp - s * vrq, v[r][q] = s * vrp + c * vrq;
+        }
+      }
+    }
+  }
+}
+
+// frames_out [n, NF, 9]: NF = 4 (axis_fixed < 0) or 2.
+__global__ void pca_frames_kernel(const float* __restrict__ pts, const int32_t* __restrict__ knn, int64_t n, int k,
+                                  int axis_fixed, float* __restrict__ frames) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // neighbourhood matrix (missing neighbours -> the point itself, RotationFunctions.py:314-317)
+  float mean[3] = {0.f, 0.f, 0.f};
+  for (int e = 0; e < k; ++e) {
+    int j = knn[i * k + e];
+    if (j < 0) j = (int)i;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) mean[d] += (d == axis_fixed) ? 0.f : pts[(int64_t)j * 3 + d];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) mean[d] /= (float)k;
+  float a[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  for (int e = 0; e < k; ++e) {
+    int j = knn[i * k + e];
+    if (j < 0) j = (int)i;
+    float x[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = ((d == axis_fixed) ? 0.f : pts[(int64_t)j * 3 + d]) - mean[d];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[r][c] += x[r] * x[c];
+  }
+  float v[3][3];
+  jacobi3(a, v);
+  // order the eigenpairs: ascending like torch.linalg.eigh (descending after the flip of the fixed-axis branch)
+  int ord[3] = {0, 1, 2};
+  float ev[3] = {a[0][0], a[1][1], a[2][2]};
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+    for (int t = 0; t < 2 - pass; ++t)
+      if (ev[ord[t]] > ev[ord[t + 1]]) { const int tmp = ord[t]; ord[t] = ord[t + 1]; ord[t + 1] = tmp; }
+  float f[3][3];  // columns = frame axes
+  const bool fixed = axis_fixed >= 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int src = fixed ? ord[2 - c] : ord[c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) f[r][c] = src == 0 ? v[r][0] : (src == 1 ? v[r][1] : v[r][2]);
+  }
+  if (fixed) {
+    // the zeroed coordinate gives the eigenvalue-0 direction +-e_axis (last column after the flip); its sign is
+    // implementation-defined in LAPACK -- here it is made +e_axis before the orientation fix
+    if (f[axis_fixed][2] < 0.f) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) f[r][2] = -f[r][2];
+    }
+  }
+  const float det = f[0][0] * (f[1][1] * f[2][2] - f[1][2] * f[2][1]) - f[0][1] * (f[1][0] * f[2][2] - f[1][2] * f[2][0]) +
+                    f[0][2] * (f[1][0] * f[2][1] - f[1][1] * f[2][0]);
+  if (det < 0.f) {
+    if (fixed) {  // keep +e_axis: flip one in-plane axis instead of the whole matrix
+#pragma unroll
+      for (int r = 0; r < 3; ++r) f[r][1] = -f[r][1];
+    } else {      // eigenvec[det < 0] *= -1 (RotationFunctions.py:339)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[r][c] = -f[r][c];
+    }
+  }
+  const int nf = fixed ? 2 : 4;
+  // sign patterns with product +1 (columns scaled): free (1,1,1),(1,-1,-1),(-1,1,-1),(-1,-1,1); fixed (1,1,1),(-1,-1,1)
+  for (int p = 0; p < nf; ++p) {
+    float sg[3];
+    if (fixed) sg[0] = p ? -1.f : 1.f, sg[1] = p ? -1.f : 1.f, sg[2] = 1.f;
+    else sg[0] = (p & 2) ? -1.f : 1.f, sg[1] = (p == 1 || p == 3) ? -1.f : 1.f, sg[2] = (p == 1 || p == 2) ? -1.f : 1.f;
+    float* o = frames + (i * nf + p) * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        int cc = c;
+        if (fixed && axis_fixed == 1) cc = c == 1 ? 2 : (c == 2 ? 1 : 0);   // ref_frames[..., [0, 2, 1]]
+        float val = f[r][cc] * sg[cc];
+        if (fixed && fabsf(val) < 1e-6f) val = 0.f;
+        o[r * 3 + c] = val;
+      }
+  }
+}
+
+}  // namespace
+}  // namespace se3
+
+using namespace se3;
+
+extern "C" int se3_knn_query(const float* pts, const int32_t* batch_ids, int64_t n, int32_t k, int32_t* out,
+                             void* stream) {
+  if (n < 0 || k < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (k > 32 || n >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  if (n == 0) return SE3_OK;
+  if (!pts || !batch_ids || !out) return SE3_ERR_INVALID_ARGUMENT;
+  const dim3 grid((unsigned)((n + kKnnQueries - 1) / kKnnQueries)), block(kKnnQueries * kKnnSlices);
+  hipStream_t s = (hipStream_t)stream;
+  if (k <= 8) hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, pts, batch_ids, n, (int)k, out);
+  else if (k <= 16) hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, s, pts, batch_ids, n, (int)k, out);
+  else hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, pts, batch_ids, n, (int)k, out);
+  return check_launch();
+}
+
+extern "C" int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, int32_t axis_fixed,
+                              float* frames, void* stream) {
+  if (n < 0 || k < 1 || axis_fixed > 2) return SE3_ERR_INVALID_ARGUMENT;
+  if (axis_fixed == 0) return SE3_ERR_UNSUPPORTED;  // the reference treats fixed_axis = 0 as "not fixed"; pass -1
+  if (n == 0) return SE3_OK;
+  if (!pts || !knn || !frames) return SE3_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(pca_frames_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, pts, knn,
+                     n, (int)k, axis_fixed < 0 ? -1 : (int)axis_fixed, frames);
+  return check_launch();
+}

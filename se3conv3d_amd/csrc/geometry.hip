@@ -147,6 +147,49 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
   if (!STORE && lane == 0) counts[s] = found;
 }
 
+// Per-batch bounding boxes (BallQuery.py:35-36 / BoundingBox.py:17-18 use torch_scatter's scatter_min/max).
+// Wave-level reduction first (batch ids are sorted, so a wavefront almost always holds one batch element), then
+// one float atomic per wavefront and coordinate -- torch's scatter_reduce on three addresses took 1.3 ms here.
+__device__ __forceinline__ void atomic_min_f(float* addr, float v) {
+  // order-preserving integer view of a float: positive floats as signed ints, negative ones reversed
+  if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void batch_aabb_init_kernel(float* __restrict__ mn, float* __restrict__ mx, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) mn[i] = __int_as_float(0x7f800000), mx[i] = __int_as_float(0xff800000);  // +inf / -inf
+}
+
+__global__ void batch_aabb_kernel(const float* __restrict__ pts, const int32_t* __restrict__ batch_ids, int64_t n,
+                                  float* __restrict__ mn, float* __restrict__ mx) {
+  for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ll; i0 < n;
+       i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + (threadIdx.x & 63);
+    const bool ok = i < n;
+    const int64_t ic = ok ? i : n - 1;
+    const int b = batch_ids[ic];
+    const int b0 = __builtin_amdgcn_readfirstlane(b);
+    const bool uniform = __all(b == b0);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float v = pts[ic * 3 + d];
+      if (uniform) {
+        float lo = v, hi = v;  // lanes past the end repeat the last point: harmless for min / max
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lo = fminf(lo, __shfl_xor(lo, off)), hi = fmaxf(hi, __shfl_xor(hi, off));
+        if ((threadIdx.x & 63) == 0) atomic_min_f(&mn[b0 * 3 + d], lo), atomic_max_f(&mx[b0 * 3 + d], hi);
+      } else if (ok) {
+        atomic_min_f(&mn[b * 3 + d], v), atomic_max_f(&mx[b * 3 + d], v);
+      }
+    }
+  }
+}
+
 __global__ void split_edges_kernel(const int32_t* __restrict__ neighbors, int64_t e, int32_t* __restrict__ src,
                                    int32_t* __restrict__ smp) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
@@ -215,6 +258,22 @@ extern "C" int se3_compute_keys(const float* pts, const int32_t* batch_ids, cons
   if (n == 0) return SE3_OK;
   hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, pts, batch_ids,
                      aabb_min, num_cells, cell_size, 0.f, n, keys, (int32_t*)nullptr);
+  return check_launch();
+}
+
+extern "C" int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float* aabb_min,
+                              float* aabb_max, void* stream_) {
+  if (n < 0 || n_batches < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (!aabb_min || !aabb_max || (n > 0 && (!pts || !batch_ids))) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(batch_aabb_init_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, aabb_min, aabb_max,
+                     n_batches * 3);
+  if (n > 0) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(batch_aabb_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pts, batch_ids, n, aabb_min,
+                       aabb_max);
+  }
   return check_launch();
 }
 

@@ -102,24 +102,33 @@ class ComputeKeys(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------- ball query (a10)
-def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float):
-    """Grid parameters exactly as BallQuery.forward builds them (BallQuery.py:34-38), on device,
-    without a host read-back."""
-    n_batches_t = batch_src.max() + 1 if batch_src.numel() else None
-    idx = batch_src.to(torch.int64)
-    # number of batches is needed for the output shape: one tiny sync, same as the reference's
-    # `torch::amax(...).item()` (ball_query.cu:46).
-    nb = int(n_batches_t.item()) if n_batches_t is not None else 1
-    mn = torch.full((nb, 3), float("inf"), dtype=torch.float32, device=pts_src.device)
-    mx = torch.full((nb, 3), float("-inf"), dtype=torch.float32, device=pts_src.device)
-    idx3 = idx[:, None].expand(-1, 3)
-    mn = mn.scatter_reduce(0, idx3, pts_src, "amin") - 1e-6
-    mx = mx.scatter_reduce(0, idx3, pts_src, "amax") - 1e-6
+def batch_aabb(pts, batch_ids, n_batches: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-batch bounding boxes ``(min [B,3], max [B,3])`` (the reference's scatter_min / scatter_max calls)."""
+    lib = _lib.load()
+    pts = _as(pts, torch.float32)
+    b = _as(batch_ids, torch.int32)
+    if n_batches is None:
+        # one tiny sync, the same one the reference pays with `torch::amax(...).item()` (ball_query.cu:46)
+        n_batches = int(b.max().item()) + 1 if b.numel() else 1
+    mn = torch.empty((n_batches, 3), dtype=torch.float32, device=pts.device)
+    mx = torch.empty((n_batches, 3), dtype=torch.float32, device=pts.device)
+    _lib.check(lib.se3_batch_aabb(_ptr(pts, torch.float32, "pts"), _ptr(b, torch.int32, "batch_ids", pts.device),
+                                  pts.shape[0], n_batches, _ptr(mn, torch.float32, "aabb_min"),
+                                  _ptr(mx, torch.float32, "aabb_max"), _stream()), "se3_batch_aabb")
+    return mn, mx
+
+
+def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float, n_batches: Optional[int] = None):
+    """Grid parameters exactly as BallQuery.forward builds them (BallQuery.py:34-38), on device."""
+    mn, mx = batch_aabb(pts_src, batch_src, n_batches)
+    mn = mn - 1e-6
+    mx = mx - 1e-6
     num_cells = (((mx - mn) / radius).to(torch.int32) + 1).max(dim=0)[0].to(torch.int32)
     return mn.contiguous(), num_cells.contiguous()
 
 
-def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float) -> Tuple[torch.Tensor, torch.Tensor]:
+def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
+               n_batches: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Radius neighbours: ``neighbors [E,2] int32`` (col0 sample, col1 source; grouped by sample)
     and ``ends [M] int32`` (inclusive end offsets).  Two-phase C ABI, one host sync for E."""
     lib = _lib.load()
@@ -136,7 +145,7 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float) -> Tuple[t
     ends = torch.zeros(n_dst, dtype=torch.int32, device=dev)
     if n_dst == 0 or n_src == 0:
         return torch.zeros((0, 2), dtype=torch.int32, device=dev), ends
-    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius)
+    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches)
     nbytes = lib.se3_ball_query_workspace_bytes(n_src, n_dst)
     ws = _workspace(nbytes, dev)
     f32, i32 = torch.float32, torch.int32
@@ -183,6 +192,50 @@ def csr_transpose(neighbors_i32: torch.Tensor, n_src: int) -> Tuple[torch.Tensor
                                      C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(t_samples, torch.int32, "t_samples"),
                                      _ptr(t_ends, torch.int32, "t_ends"), _stream()), "se3_csr_transpose")
     return t_samples, t_ends
+
+
+# ------------------------------------------------------------------------------- frames (row f-1)
+def knn_query(pts, batch_ids, k: int) -> torch.Tensor:
+    """``point_cloud_lib_ops.knn_query``: self-kNN inside each batch element, ``[N,k]`` int32 (self first,
+    ascending distance, -1 padded)."""
+    lib = _lib.load()
+    pts = _as(pts, torch.float32)
+    b = _as(batch_ids, torch.int32)
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("knn_query: only [N,3] point sets are supported")
+    out = torch.empty((pts.shape[0], int(k)), dtype=torch.int32, device=pts.device)
+    _lib.check(lib.se3_knn_query(_ptr(pts, torch.float32, "pts"), _ptr(b, torch.int32, "batch_ids", pts.device),
+                                 pts.shape[0], int(k), _ptr(out, torch.int32, "out"), _stream()), "se3_knn_query")
+    return out
+
+
+class KNNQuery(torch.autograd.Function):
+    """Drop-in for ``point_cloud_lib.custom_ops.KNNQuery`` (KNNQuery.py:11-35)."""
+
+    @staticmethod
+    def forward(ctx, p_pt_src, p_batch_id_src, p_k):
+        return knn_query(p_pt_src, p_batch_id_src, p_k)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, None, None
+
+
+def pca_frames(pts, knn_ids, axis_fixed=None) -> torch.Tensor:
+    """``sample_reference_frames_pca`` on the GPU: ``[N,4,9]`` frames (``[N,2,9]`` with a fixed axis 1 or 2).
+    ``axis_fixed`` follows the reference: ``None`` / ``False`` / ``0`` all mean "not fixed"."""
+    lib = _lib.load()
+    pts = _as(pts, torch.float32)
+    ids = _as(knn_ids, torch.int32)
+    n, k = ids.shape
+    axis = int(axis_fixed) if axis_fixed else -1
+    if axis not in (-1, 1, 2):
+        raise ValueError(f"axis_fixed = {axis_fixed}")
+    nf = 4 if axis < 0 else 2
+    frames = torch.empty((n, nf, 9), dtype=torch.float32, device=pts.device)
+    _lib.check(lib.se3_pca_frames(_ptr(pts, torch.float32, "pts"), _ptr(ids, torch.int32, "knn", pts.device), n, k, axis,
+                                  _ptr(frames, torch.float32, "frames"), _stream()), "se3_pca_frames")
+    return frames
 
 
 # ------------------------------------------------------------------- the operator's geometry bundle

@@ -4,9 +4,9 @@ Only what the convolution and the benchmark stack need:
 
   * ``Pointcloud`` / ``PointcloudRotEquiv``  (pc/Pointcloud.py:5-48, pc/PointcloudRotEquiv.py:13-52):
     ``pts_``, ``batch_ids_``, ``local_frames_ [N,F,9]``, ``n_frames_``,
-    ``batch_ids_considering_frames_``; frames sampled in the constructor -- random rotations or
-    rotations about a fixed axis (pc/RotationFunctions.py:428-508).  PCA frames (kNN + eigh) are
-    the next scope row and raise NotImplementedError here.
+    ``batch_ids_considering_frames_``; frames sampled in the constructor -- random rotations, rotations
+    about a fixed axis (pc/RotationFunctions.py:428-508) or PCA frames from a self-kNN neighbourhood
+    (``KnnNeighborhood`` + ``sample_reference_frames_pca``, scope row f-1, HIP kernels in csrc/frames.hip).
   * ``Neighborhood`` / ``BQNeighborhood``    (pc/Neighborhood.py, pc/BQNeighborhood.py:13-64) on the HIP ball query.
   * ``GridSubSample`` / ``PointHierarchy`` / ``PointHierarchyRotEquiv`` (pc/GridSubSample.py:40-93,
     pc/Grid.py:37-57, pc/PointHierarchy.py:10-93, pc/PointHierarchyRotEquiv.py:7-44): grid-average
@@ -75,6 +75,8 @@ class PointcloudRotEquiv(Pointcloud):
 
     def __init__(self, p_pts, p_batch_ids, p_ref_frames_config, ref_frames_pts=None, standard_knn=False, **kwargs):
         super().__init__(p_pts, p_batch_ids, **kwargs)
+        self.neigh_cache_ = {}
+        self.local_frames_pca_cache_ = {}
         self.local_frames_config_ = p_ref_frames_config
         self.ref_frames_pts = ref_frames_pts
         frames = self.get_local_ref_frames()
@@ -82,11 +84,37 @@ class PointcloudRotEquiv(Pointcloud):
         self.local_frames_ = torch.as_tensor(frames, **kwargs)
         self.batch_ids_considering_frames_ = self.batch_ids_.repeat_interleave(self.n_frames_)
 
+    def get_ref_frame_neighborhood(self, p_neigh_method, **kwargs):
+        """kNN / ball-query neighbourhood used to build PCA frames, memoised (PointcloudRotEquiv.py:54-75)."""
+        key = str(p_neigh_method) + str(kwargs.get("neigh_k" if p_neigh_method == "knn" else "bq_radius"))
+        if key not in self.neigh_cache_:
+            if p_neigh_method == "knn":
+                self.neigh_cache_[key] = KnnNeighborhood(self, self, kwargs["neigh_k"], p_keep_empty=True)
+            elif p_neigh_method == "ball_query":
+                self.neigh_cache_[key] = BQNeighborhood(self, self, kwargs["bq_radius"])
+            else:
+                raise ValueError(p_neigh_method)
+        return self.neigh_cache_[key]
+
     def get_local_ref_frames(self):
         cfg = self.local_frames_config_
+        if not hasattr(self, "neigh_cache_"):
+            self.neigh_cache_, self.local_frames_pca_cache_ = {}, {}
+        if self.ref_frames_pts is not None:
+            raise NotImplementedError("global reference frames from ref_frames_pts are not on the accelerated path")
         if cfg.get("pca", False):
-            raise NotImplementedError("PCA reference frames (kNN + eigh) are scope row f-1; pass frames explicitly "
-                                      "via from_frames() or use pca: False")
+            # PointcloudRotEquiv.py:131-167: all PCA frames once ("se3-all"), then a random permutation per point
+            # (torch.multinomial without replacement) and the first n_frames
+            if "se3-all" not in self.local_frames_pca_cache_:
+                nbh = self.get_ref_frame_neighborhood(cfg["neigh_method"], **cfg["neigh_kwargs"])
+                self.local_frames_pca_cache_["se3-all"] = sample_reference_frames_pca(
+                    self.pts_, nbh, axis_fixed=cfg.get("fixed_axis"), device=self.pts_.device)
+            all_frames = self.local_frames_pca_cache_["se3-all"]
+            n_points, n_all = all_frames.shape[0], all_frames.shape[1]
+            weights = torch.ones(n_all, device=self.pts_.device).expand(n_points, -1)
+            perm = torch.multinomial(weights, num_samples=n_all, replacement=False)
+            shuffled = torch.gather(all_frames, 1, perm[:, :, None].expand(-1, -1, all_frames.shape[-1]))
+            return shuffled[:, : cfg["n_frames"], :]
         return sample_reference_frames(self.pts_.shape[0], cfg["n_frames"], axis_fixed=cfg.get("fixed_axis"),
                                        device=self.pts_.device)
 
@@ -151,6 +179,37 @@ class BQNeighborhood(Neighborhood):
             self.radius_, self.max_neighbors_)
 
 
+class KnnNeighborhood(Neighborhood):
+    """Self-kNN neighbourhood (pc/KnnNeighborhood.py:14-75, the ``pc_src == samples`` / k <= 64 branch): fixed k
+    neighbours per point, ``neighbors_ [N*k, 2]`` (centre, neighbour; -1 where the batch element is too small),
+    ``start_ids_`` = ``(arange + 1) * k`` when empty slots are kept."""
+
+    def __init__(self, p_pc_src, p_samples, p_k, p_keep_empty=False, p_standard_knn=False):
+        if p_pc_src is not p_samples or p_k > 32 or p_standard_knn:
+            raise NotImplementedError("only the self-kNN path with k <= 32 (PCA frame construction) is implemented")
+        self.k_ = p_k
+        self.keep_empty_ = p_keep_empty
+        super().__init__(p_pc_src, p_samples)
+
+    def __compute_neighborhood__(self):
+        ids = ops.KNNQuery.apply(self.pc_src_.pts_, self.pc_src_.batch_ids_, self.k_)
+        n = ids.shape[0]
+        centers = torch.arange(n, dtype=torch.int32, device=ids.device)[:, None].expand(-1, self.k_)
+        self.neighbors_ = torch.stack((centers.reshape(-1), ids.reshape(-1)), -1)
+        if self.keep_empty_:
+            self.start_ids_ = torch.arange(n, dtype=torch.int32, device=ids.device) * self.k_ + self.k_
+        else:
+            mask = self.neighbors_[:, 1] >= 0
+            self.neighbors_ = self.neighbors_[mask]
+            self.start_ids_ = torch.cumsum(mask.reshape(n, self.k_).sum(1), 0).to(torch.int32)
+
+
+def sample_reference_frames_pca(points, p_neighborhood, axis_fixed=False, dtype=None, device=None):
+    """PCA frames from a fixed-k neighbourhood (pc/RotationFunctions.py:307-406), one HIP kernel."""
+    ids = p_neighborhood.neighbors_[:, 1].reshape(-1, p_neighborhood.k_)
+    return ops.pca_frames(points, ids, axis_fixed)
+
+
 # --------------------------------------------------------------------------------------- hierarchy
 class GridSubSample(object):
     """Grid-average sub-sampling (pc/GridSubSample.py, pc/Grid.py, pc/BoundingBox.py)."""
@@ -158,11 +217,9 @@ class GridSubSample(object):
     def __init__(self, p_pc_src, p_cell_size):
         self.pc_src_ = p_pc_src
         self.cell_size_ = p_cell_size
-        pts, bid = p_pc_src.pts_, p_pc_src.batch_ids_.to(torch.int64)
-        nb = int(p_pc_src.batch_size_)
-        idx3 = bid[:, None].expand(-1, 3)
-        mn = torch.full((nb, 3), float("inf"), dtype=pts.dtype, device=pts.device).scatter_reduce(0, idx3, pts, "amin") - 1e-6
-        mx = torch.full((nb, 3), float("-inf"), dtype=pts.dtype, device=pts.device).scatter_reduce(0, idx3, pts, "amax") + 1e-6
+        pts = p_pc_src.pts_
+        mn, mx = ops.batch_aabb(pts, p_pc_src.batch_ids_, int(p_pc_src.batch_size_))  # BoundingBox.py:17-18
+        mn, mx = mn - 1e-6, mx + 1e-6
         self.num_cells_ = (((mx - mn) / p_cell_size).to(torch.int32) + 1).max(dim=0)[0]
         keys = ops.ComputeKeys.apply(pts, p_pc_src.batch_ids_, mn, self.num_cells_,
                                      torch.full((3,), p_cell_size, dtype=torch.float32, device=pts.device))

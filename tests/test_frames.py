@@ -1,0 +1,131 @@
+"""Scope row f-1: self-kNN + PCA reference frames.  CPU: oracle vs the fixture generated from the reference's
+PointcloudRotEquiv(pca=True).  GPU: the HIP kernels vs oracle / fixture.
+
+Eigenvector signs are implementation-defined (LAPACK), so frames are compared as per-point SETS: the four
+sign-flipped copies of the free case are invariant under that choice; in the fixed-axis case the reference's
+up-axis column can come out as -e_axis, ours is +e_axis by construction (documented), so the in-plane axes are
+compared up to sign.  Points whose covariance has nearly equal eigenvalues are skipped for the vector
+comparison (ill-conditioned eigenvectors) but not for orthonormality / handedness."""
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_npz
+from oracle import se3conv_oracle as O
+
+DEV = "cuda:0"
+
+
+def frame_sets_match(a, b, tol):
+    """a, b: [N,P,9]; every frame of a has a partner in b within tol (max-abs), and vice versa."""
+    d = (a[:, :, None, :] - b[:, None, :, :]).abs().amax(-1)  # [N,P,P]
+    return (d.amin(2) < tol).all(1) & (d.amin(1) < tol).all(1)
+
+
+def well_conditioned(pts, knn, axis=None, gap=5e-2):
+    ids = knn.long().clone()
+    rows = torch.arange(ids.shape[0])[:, None].expand_as(ids)
+    ids[ids < 0] = rows[ids < 0]
+    nm = pts[ids].clone()
+    if axis:
+        nm[:, :, axis] = 0
+    nm = nm - nm.mean(1, keepdim=True)
+    ev = torch.linalg.eigvalsh(torch.einsum("bij,bjk->bik", nm.transpose(1, 2), nm))
+    ev = ev[:, 1:] if axis else ev  # the zeroed coordinate gives an exact 0 that is always separated
+    rel = (ev[:, 1:] - ev[:, :-1]) / ev[:, -1:].clamp_min(1e-12)
+    return rel.amin(1) > gap
+
+
+def test_oracle_knn_and_pca_match_reference_fixture():
+    d = load_npz(os.path.join(GOLDEN, "pca_frames.npz"))
+    knn = O.knn_query(d["pts"], d["batch"], 16)
+    assert torch.equal(knn, d["knn"])
+    assert bool((knn[:, 0] == torch.arange(knn.shape[0])).all())  # the point itself comes first
+    assert bool((d["batch"][knn.long()] == d["batch"][:, None]).all())
+    for tag, axis in (("free", False), ("axis2", 2), ("axis1", 1)):
+        fr = O.sample_reference_frames_pca(d["pts"], knn, axis)
+        assert fr.shape == d[f"frames_{tag}"].shape
+        assert float((fr - d[f"frames_{tag}"]).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_knn_matches_oracle(built_library):
+    import se3conv3d_amd as amd
+
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(3000, 3, generator=g)
+    bid = torch.sort(torch.randint(0, 3, (3000,), generator=g, dtype=torch.int32)).values
+    bid[-5:] = 3  # a batch element with fewer than k points -> -1 padding
+    for k in (8, 16, 20):
+        ref = O.knn_query(pts, bid, k)
+        got = amd.ops.knn_query(pts.to(DEV), bid.to(DEV), k).cpu()
+        assert torch.equal(got, ref)
+    assert int((ref[-1] < 0).sum()) == 20 - 5
+    nbh = amd.pc.KnnNeighborhood.__new__(amd.pc.KnnNeighborhood)
+    pc = amd.pc.Pointcloud(pts.to(DEV), bid.to(DEV))
+    amd.pc.KnnNeighborhood.__init__(nbh, pc, pc, 16, p_keep_empty=True)
+    assert nbh.neighbors_.shape == (3000 * 16, 2) and torch.equal(nbh.start_ids_.cpu(), (torch.arange(3000) + 1).int() * 16)
+
+
+@pytest.mark.gpu
+def test_gpu_pca_frames_match_reference_fixture(built_library):
+    import se3conv3d_amd as amd
+
+    d = load_npz(os.path.join(GOLDEN, "pca_frames.npz"))
+    pts, knn = d["pts"], d["knn"]
+    for tag, axis in (("free", None), ("axis2", 2), ("axis1", 1)):
+        fr = amd.ops.pca_frames(pts.to(DEV), knn.to(DEV), axis).cpu()
+        gold = d[f"frames_{tag}"]
+        assert fr.shape == gold.shape
+        m = fr.reshape(fr.shape[0], fr.shape[1], 3, 3)
+        eye = torch.eye(3).expand_as(m)
+        assert float((m.transpose(2, 3) @ m - eye).abs().max()) < 1e-5          # orthonormal columns
+        # right-handed -- except fixed_axis = 1, where the reference permutes columns [0, 2, 1] AFTER its orientation
+        # fix (RotationFunctions.py:400-401) and so returns left-handed frames; reproduced as is (quirk 7)
+        hand = -1.0 if axis == 1 else 1.0
+        assert float((torch.linalg.det(m) - hand).abs().max()) < 1e-5
+        assert float((torch.linalg.det(gold.reshape(m.shape)) - hand).abs().max()) < 1e-5
+        ok = well_conditioned(pts, knn, axis)
+        assert int(ok.sum()) > 0.7 * ok.shape[0]
+        if axis is None:
+            assert bool(frame_sets_match(fr, gold, 2e-3)[ok].all())
+        else:
+            up = 2  # the fixed axis is the third basis vector (after the reference's column permutation for axis 1)
+            col = {2: 2, 1: 1}[axis]
+            assert float((m[:, :, :, col].abs() - torch.eye(3)[axis]).abs().max()) < 1e-6 and bool((m[:, :, axis, col] > 0).all())
+            g = gold.reshape(gold.shape[0], gold.shape[1], 3, 3)
+            other = [c for c in range(3) if c != col]
+            for c in other:  # in-plane axes agree with the reference up to sign
+                dots = (m[:, 0, :, c] * g[:, 0, :, c]).sum(-1).abs()
+                assert bool((dots[ok] > 1 - 1e-4).all())
+            # the second frame is the first rotated by pi about the fixed axis
+            assert float((m[:, 1, :, other] + m[:, 0, :, other]).abs().max()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_pointcloud_with_pca_frames_runs_the_layer(built_library):
+    """PointcloudRotEquiv(pca=True) end to end on the GPU: cached 'se3-all' frames, random permutation per point,
+    n_frames kept, and the conv consumes them (rotation invariance holds for PCA frames of the rotated cloud)."""
+    import se3conv3d_amd as amd
+
+    torch.manual_seed(4)
+    n = 4000
+    pts = torch.rand(n, 3, device=DEV)
+    bid = torch.zeros(n, dtype=torch.int32, device=DEV)
+    cfg = {"pca": True, "n_frames": 2, "fixed_axis": False, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
+    pc = amd.pc.PointcloudRotEquiv(pts, bid, cfg)
+    assert pc.local_frames_.shape == (n, 2, 9) and pc.n_frames_ == 2
+    allf = pc.local_frames_pca_cache_["se3-all"]
+    assert allf.shape == (n, 4, 9)
+    # the two kept frames are two different members of the point's four
+    d = (pc.local_frames_[:, :, None, :] - allf[:, None, :, :]).abs().amax(-1)
+    assert bool((d.amin(2) == 0).all()) and bool((d.argmin(2)[:, 0] != d.argmin(2)[:, 1]).all())
+    nbh = amd.pc.BQNeighborhood(pc, pc, 0.08)
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(32, 32).to(DEV)
+    conv.norm_neigh_dist_.fill_(1 / 0.08)
+    conv.norm_num_neighs_.fill_(n / nbh.neighbors_.shape[0])
+    x = torch.randn(n * 2, 32, device=DEV)
+    with torch.no_grad():
+        out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
+    assert out.shape == (n * 2, 32) and bool(torch.isfinite(out).all())

@@ -78,7 +78,18 @@ def _install_shims():
     ops.feat_basis_proj = feat_basis_proj
     ops.feat_basis_proj_grad = feat_basis_proj_grad
     ops.ball_query = ball_query
-    ops.knn_query = _unavailable
+    def knn_query(pts, batch_ids, k):
+        n = pts.shape[0]
+        out = torch.full((n, k), -1, dtype=torch.int32)
+        for i in range(n):
+            same = torch.nonzero(batch_ids == batch_ids[i])[:, 0]
+            d = pts[same] - pts[i][None, :]
+            d2 = (d * d).sum(1)
+            order = torch.argsort(d2, stable=True)[:k]
+            out[i, : order.shape[0]] = same[order].to(torch.int32)
+        return out
+
+    ops.knn_query = knn_query
     ops.compute_keys = _unavailable
     sys.modules["point_cloud_lib_ops"] = ops
 
@@ -206,6 +217,24 @@ def rotation_case(pclib, seed):
     }
 
 
+def pca_case(pclib, seed):
+    """PCA frames through the reference's PointcloudRotEquiv (pca: True, knn 16): the un-shuffled 'se3-all'
+    cache for the free case and for a fixed up-axis, plus the kNN ids the (stand-in) kNN produced."""
+    torch.manual_seed(seed)
+    n = 240
+    pts = torch.rand(n, 3) * torch.tensor([1.0, 0.7, 0.4])
+    bid = torch.sort(torch.randint(0, 2, (n,), dtype=torch.int32)).values
+    out = {"pts": pts.numpy(), "batch": bid.numpy()}
+    for tag, axis in (("free", False), ("axis2", 2), ("axis1", 1)):
+        cfg = {"pca": True, "n_frames": 2, "fixed_axis": axis, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
+        pc = pclib.pc.PointcloudRotEquiv(pts, bid, cfg)
+        out[f"frames_{tag}"] = pc.local_frames_pca_cache_["se3-all"].numpy()
+        nbh = pc.get_ref_frame_neighborhood("knn", neigh_k=16)
+        out["knn"] = nbh.neighbors_[:, 1].reshape(n, 16).numpy().astype(np.int32)
+        assert pc.local_frames_.shape == (n, 2, 9)
+    return out
+
+
 CASES = [
     # name,             seed, n_in, n_out, F, c_in, c_out, k, batches
     ("cfg1_n1024_f1_c32", 0, 1024, None, 1, 32, 32, 16, 1),   # BASELINE.json configs[0]
@@ -228,6 +257,7 @@ def main():
         print(f"{path}: E={data['neighbors'].shape[0]} rows_out={data['out'].shape[0]} "
               f"size={os.path.getsize(path) / 1e6:.2f} MB")
     np.savez_compressed(os.path.join(OUT, "rotation_fns.npz"), **rotation_case(pclib, 7))
+    np.savez_compressed(os.path.join(OUT, "pca_frames.npz"), **pca_case(pclib, 8))
     print("done")
 
 
