@@ -17,10 +17,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libse3conv_hip.so")
-SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "gemm.hip", "gemm_bf16.hip", "fused_bf16.hip", "frames.hip", "api.hip"]
+SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "edge_bwd_bf16.hip", "gemm.hip", "gemm_bf16.hip", "fused_bf16.hip", "frames.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_bf16_body.h"), os.path.join(os.path.dirname(PKG), "include", "se3conv.h")]
 ARCH = "gfx950"
-FLAGS = os.environ.get("SE3_CXXFLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP pass packs adjacent fp32 ops into v_pk_fma_f32 / v_pk_mul_f32, which issue slower than the
+# two scalar ops they replace on gfx950 (edge_t_fwd at the headline shape: 0.55 ms packed, 0.44 ms scalar) and need
+# 64-bit aligned register pairs (spills at 128 VGPRs).
+FLAGS = os.environ.get("SE3_CXXFLAGS", "").split() + ["-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

@@ -233,11 +233,15 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     size_t plane = (size_t)s->c_in * kb * align_up((size_t)s->c_out, 32) * 2;
     const size_t p2 = (size_t)s->c_in * align_up((size_t)s->c_out * kb, 32) * 2;
     if (p2 > plane) plane = p2;
+    const size_t p3 = (size_t)s->c_out * kb * align_up((size_t)s->c_in, 32) * 2;
+    if (p3 > plane) plane = p3;
     l.bt_hi = take(plane);
     l.bt_lo = take(plane);
     l.featpk = want_params ? take(rows_in * s->c_in * 4) : 0;
     l.gpk = take(rows_out * s->c_out * 4);
     size_t sp = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_out, s->c_in * (int)kb, s->c_out) : 0;
+    const size_t sp3 = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_out * (int)kb, s->c_in) : 0;
+    if (sp3 > sp) sp = sp3;
     const size_t sp2 = want_feat ? gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb) : 0;
     if (sp2 > sp) sp = sp2;
     l.split = take(sp);
@@ -255,6 +259,8 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   }
   l.t = (want_params && !have_t) ? take(rows_out * s->c_in * kb * 4) : 0;
   l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
+  if (fast && edge_bwd_pair_bf16_blocks((int64_t)rows_in / 2) > l.n_param_partials)
+    l.n_param_partials = edge_bwd_pair_bf16_blocks((int64_t)rows_in / 2);
   l.param_partials = want_params ? take((size_t)l.n_param_partials * kDescExt * kBasis * 4) : 0;
   l.tn_splits = gemm_tn_splits((int64_t)rows_out, s->c_in * (int)kb, s->c_out);
   l.tn_partials = want_params ? take((size_t)l.tn_splits * wsz) : 0;
@@ -502,6 +508,41 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   if (int rc = launch_split_pack(grad_out, gpk, rows_out * s->c_out, stream)) return rc;
   bool branch_forked = false;
   SideStream& side = side_stream();
+  // Both gradients wanted and the shape fits the wave-pair kernel: one walk over the transposed graph yields U
+  // (feature gradient) and d[A;beta]; grad_T and the output-major parameter pass are not needed.
+  if (want_feat && want_params && (grad_axes || grad_biases) && rows_in > 0 && rows_out > 0 && l.big_u != 0 &&
+      edge_bwd_pair_bf16_supported(s->f_in, s->c_out)) {
+    uint32_t* featpk = (uint32_t*)(ws + l.featpk);
+    uint32_t* ubuf = (uint32_t*)(ws + l.big_u);
+    if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
+    // H[(p,b)][o,k] = alpha * sum_i f[(p,b),i] W[i,k,o]
+    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 3, bt_hi, bt_lo, stream)) return rc;
+    if (int rc = launch_gemm_nn_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, true, rows_in, s->c_out * kb, s->c_in,
+                                     (float*)(ws + l.split), nu, inv_fin, stream))
+      return rc;
+    int n_part = 0;
+    if (int rc = launch_edge_bwd_pair_bf16("edge_bwd", gt, gpk, rows_out, axes_ext, rho, bigw, ubuf, partials, &n_part,
+                                           stream))
+      return rc;
+    hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
+                       grad_axes, grad_biases);
+    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, bt_hi, bt_lo, stream)) return rc;
+    if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bt_hi, bt_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
+                                     (float*)(ws + l.split), nu, inv_fin, stream))
+      return rc;
+    if (grad_weights) {
+      const uint32_t* t = (const uint32_t*)t_save;
+      if (!t) {
+        uint32_t* tt = (uint32_t*)(ws + l.t);
+        if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, rows_in, axes_ext, rho, tt, stream)) return rc;
+        t = tt;
+      }
+      if (int rc = launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck,
+                                       s->c_out, nu, inv_fin, stream))
+        return rc;
+    }
+    return check_launch();
+  }
   if (want_feat && rows_in > 0) {
     // feature branch: on the side stream when there is a parameter branch to overlap with
     hipStream_t fs = stream;

@@ -97,25 +97,78 @@ __device__ __forceinline__ f32x16 zero16() {
 // erfc through Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 on erf, i.e. <= 7.5e-8 on the normal
 // CDF -- fp32 rounding level), evaluated on |x| so the negative tail keeps its relative accuracy:
 //   Phi(-|x|) = 0.5 * erfc(|x|/sqrt2) = 0.5 * t*(a1 + t*(a2 + ...)) * exp(-x^2/2),  t = 1/(1 + p|x|/sqrt2)
-// 11 full-rate VALU ops + v_rcp_f32 + v_exp_f32; the same exponential gives the density for GELU'.
+// The same exponential gives the density for GELU'.
+// Select-free arrangement (no compare / cndmask, 0.5 folded into the coefficients):
+//   q = Phi(-|x|) = (0.5 a(t)) t e,  cdf = 0.5 + s (0.5 - q),  s = sign(x),  y = x cdf,
+//   dy = 0.5 + s ((0.5 - q) + |x| e / sqrt(2 pi))
+// 12 (y) / 16 (y and dy) full-rate ops + v_rcp_f32 + v_exp_f32 per value.  The negative tail loses its relative
+// accuracy (absolute error <= 1 ulp of 0.5 on cdf), which is below the 7.5e-8 of the approximation itself.
+__device__ __forceinline__ void gelu_erf_core(float x, float& s, float& a, float& e, float& hq) {
+  a = fabsf(x);
+  s = __builtin_copysignf(1.0f, x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, a, 1.0f));  // 0.3275911 / sqrt2
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);                     // the 7.1.26 coefficients, halved
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);  // exp(-x^2/2)
+  hq = fmaf(-(p * t), e, 0.5f);
+}
 __device__ __forceinline__ void gelu_erf_grad(float x, float& y, float& dy) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);  // exp(-x^2/2)
-  const float q = 0.5f * p * t * e;                                            // Phi(-|x|)
-  const float cdf = x >= 0.f ? 1.0f - q : q;
-  y = x * cdf;
-  dy = fmaf(x * e, 0.39894228040143267794f, cdf);
+  float s, a, e, hq;
+  gelu_erf_core(x, s, a, e, hq);
+  y = fmaf(a, hq, 0.5f * x);
+  dy = fmaf(s, fmaf(a * e, 0.39894228040143267794f, hq), 0.5f);
 }
 __device__ __forceinline__ float gelu_erf(float x) {
-  float y, dy;
-  gelu_erf_grad(x, y, dy);
-  return y;
+  float s, a, e, hq;
+  gelu_erf_core(x, s, a, e, hq);
+  return fmaf(a, hq, 0.5f * x);  // == x * (0.5 + s hq), without needing s
 }
+
+// Pairwise entry points used by the bf16 edge kernels.  SE3_GELU_PK=1 builds evaluate the pair on the packed
+// fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32); the default evaluates the two values with scalar VALU ops.
+#ifndef SE3_GELU_PK
+#define SE3_GELU_PK 0
+#endif
+#if SE3_GELU_PK
+__device__ __forceinline__ void gelu_erf_core2(f32x2 x, f32x2& s, f32x2& a, f32x2& e, f32x2& hq) {
+  a = __builtin_elementwise_abs(x);
+  const f32x2 one = {1.0f, 1.0f};
+  s = __builtin_elementwise_copysign(one, x);
+  f32x2 t = a * 0.23164189f + 1.0f;
+  t[0] = __builtin_amdgcn_rcpf(t[0]);
+  t[1] = __builtin_amdgcn_rcpf(t[1]);
+  f32x2 p = t * 0.5307027145f - 0.7265760135f;
+  p = p * t + 0.7107068705f;
+  p = p * t - 0.142248368f;
+  p = p * t + 0.127414796f;
+  const f32x2 xe = (x * x) * -0.72134752044448170368f;
+  e[0] = __builtin_amdgcn_exp2f(xe[0]);
+  e[1] = __builtin_amdgcn_exp2f(xe[1]);
+  hq = 0.5f - (p * t) * e;
+}
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  f32x2 s, a, e, hq;
+  gelu_erf_core2(x, s, a, e, hq);
+  return x * (s * hq + 0.5f);
+}
+__device__ __forceinline__ void gelu_erf_grad2(f32x2 x, f32x2& y, f32x2& dy) {
+  f32x2 s, a, e, hq;
+  gelu_erf_core2(x, s, a, e, hq);
+  y = x * (s * hq + 0.5f);
+  dy = s * ((a * e) * 0.39894228040143267794f + hq) + 0.5f;
+}
+#else
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) { return f32x2{gelu_erf(x[0]), gelu_erf(x[1])}; }
+__device__ __forceinline__ void gelu_erf_grad2(f32x2 x, f32x2& y, f32x2& dy) {
+  float y0, y1, d0, d1;
+  gelu_erf_grad(x[0], y0, d0);
+  gelu_erf_grad(x[1], y1, d1);
+  y = f32x2{y0, y1};
+  dy = f32x2{d0, d1};
+}
+#endif
 
 // 9-D edge descriptor (reference PNEConvLayerRotEquiv.py:68-90):
 //   d[0..2] = (rho * (x_in - y_out))^T R_out          (RotationFunctions.py:637-665)
@@ -190,6 +243,11 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
                                 float* partials, int n_partials, hipStream_t stream);
 bool conv_fused_bf16_supported(const EdgeGeom& g, int gathered_channels);
+bool edge_bwd_pair_bf16_supported(int f_ctr, int gathered_channels);
+int edge_bwd_pair_bf16_blocks(int64_t items);
+int launch_edge_bwd_pair_bf16(const char* tag, const EdgeGeom& gt, const uint32_t* gpk, int64_t g_rows,
+                              const float* axes_ext, const float* rho, const uint32_t* h_rows, uint32_t* u_out,
+                              float* partials, int* n_partials, hipStream_t stream);
 int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int64_t feat_rows,
                            const float* axes_ext, const float* rho, const uint16_t* bt_hi, const uint16_t* bt_lo,
                            int co, float* out, uint32_t* t_save, const float* alpha_num, float alpha_scale,

@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 // carries 32 accumulator registers instead of 64, which is what lets 3-4 wavefronts share a SIMD (the
 // single-wavefront kernel needs ~240 VGPRs: 2 per SIMD, 44 % of their life parked in s_waitcnt).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128, 4) void edge_t_pair_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+#ifndef SE3_PAIR_WAVES
+#define SE3_PAIR_WAVES 4
+#endif
+__global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                   int64_t feat_rows, const float* __restrict__ axes_ext,
                                                                   const float* __restrict__ rho_p,
                                                                   uint32_t* __restrict__ t_out, int64_t n_items,
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(128, 4) void edge_t_pair_bf16_kernel(EdgeGeom g, co
   int buf = 0;
   for (int c0 = 0; c0 < n_total; c0 += 32, buf ^= 1) {
     const int cnt = min(32, n_total - c0);
-    const int qoff = q_nx * (C * 4);
+    // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
+    const int qoff = c0 + kcol < n_total ? q_nx * (C * 4) : kOobOffset;
     float xn[3], rn[9], d[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
@@ -214,10 +218,9 @@ __global__ __launch_bounds__(128, 4) void edge_t_pair_bf16_kernel(EdgeGeom g, co
         if (s * 16 < cnt) {
           float pv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float y = gelu_erf(phi[8 * s + j]);
-            asm volatile("" : "+v"(y));
-            pv[j] = acc_row(8 * s + j, h) < cnt ? y : 0.f;
+          for (int j = 0; j < 8; j += 2) {
+            const f32x2 y = gelu_erf2(f32x2{phi[8 * s + j], phi[8 * s + j + 1]});
+            pv[j] = y[0], pv[j + 1] = y[1];
           }
           u32x4 b_hi, b_lo;
           frags_from_floats(pv, b_hi, b_lo);
@@ -469,7 +472,8 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
 
     for (int c0 = 0; c0 < n_total; c0 += 32) {
       const int cnt = min(32, n_total - c0);
-      const int q = q_nx;
+      // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
+      const int qoff = c0 + kcol < n_total ? q_nx * (C * 4) : kOobOffset;
       float xn[3], rn[9], d[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
       u32x4 fa_hi[CH16], fa_lo[CH16];
 #pragma unroll
       for (int st = 0; st < CH16; ++st) {
-        const int voff = q * (C * 4) + (16 * st + 8 * h) * 4;
+        const int voff = qoff + (16 * st + 8 * h) * 4;
         const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
         const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff + 16, 0, 0);
         const uint32_t w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -550,8 +554,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
             for (int j = 0; j < 8; ++j) {
               float y, dy;
               gelu_erf_grad(pre[8 * s + j], y, dy);
-              asm volatile("" : "+v"(dy));
-              gp[j] = acc_row(8 * s + j, h) < cnt ? gphi[8 * s + j] * dy : 0.f;
+              gp[j] = gphi[8 * s + j] * dy;
               wd[j] = lds_desc[wave][a][acc_row(8 * s + j, h)][jcol];
             }
             u32x4 ga_hi, ga_lo, db_hi, db_lo;
@@ -606,6 +609,8 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (rows == 0) return SE3_OK;
+  // 32-bit byte offsets into the gathered operand; kOobOffset must lie beyond it
+  if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
   // two frames per wavefront share the gather; with 4 channel tiles per frame that would spill, so VW = 4 stays at 1
   const int fc = (getenv("SE3_FC1") == nullptr && g.f_ctr % 2 == 0 && channels % 128 != 0) ? 2 : 1;
@@ -664,6 +669,7 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
                                 float* partials, int n_partials, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
+  if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
   if (g.f_ctr % 2 == 0 && channels % 16 == 0 && channels <= 64 && channels > 0) {
     int shift = -1;

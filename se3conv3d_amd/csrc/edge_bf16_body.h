@@ -14,6 +14,9 @@
 
 namespace se3 {
 
+// byte offset no gathered buffer reaches: a raw buffer load from it returns 0
+constexpr int kOobOffset = 0x7fff0000;
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, int64_t bytes) {
   const uint32_t n = bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)n, 0x00020000);
@@ -116,7 +119,8 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
     for (int c0 = 0; c0 < n_total; c0 += 32) {
       const int cnt = min(32, n_total - c0);
       const int q = q_nx;
-      const int qoff = q * row_bytes;
+      // rows past the end of the edge list are read out of bounds (raw buffer loads return 0), so phi needs no mask
+      const int qoff = c0 + kcol < n_total ? q * row_bytes : kOobOffset;
       float xn[3], rn[9], d[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
@@ -205,8 +209,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 #else
               float y = gelu_erf(phi[8 * s + j]);
 #endif
-              asm volatile("" : "+v"(y));  // keep the GELU unconditional (no exec-masked branch per register)
-              pv[j] = acc_row(8 * s + j, h) < cnt ? y : 0.f;
+              pv[j] = y;
             }
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);
@@ -325,7 +328,8 @@ __device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdg
     for (int c0 = 0; c0 < n_total; c0 += 32) {
       const int cnt = min(32, n_total - c0);
       const int q = q_nx;
-      const int qoff = q * row_bytes;
+      // rows past the end of the edge list are read out of bounds (raw buffer loads return 0), so phi needs no mask
+      const int qoff = c0 + kcol < n_total ? q * row_bytes : kOobOffset;
       float xn[3], rn[9], d[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
@@ -403,9 +407,7 @@ __device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdg
             float pv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              float y = gelu_erf(phi[8 * s + j]);
-              asm volatile("" : "+v"(y));
-              pv[j] = acc_row(8 * s + j, h) < cnt ? y : 0.f;
+              pv[j] = gelu_erf(phi[8 * s + j]);
             }
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
 //   mode 0 (out = T W)      : nn = o,          kk = i*K + k     value W[i,k,o]
 //   mode 1 (gT = g W^T)     : nn = i*K + k,    kk = o           value W[i,k,o]
 //   mode 2 (dX = U W')      : nn = i,          kk = o*K + k     value W[i,k,o]
+//   mode 3 (H = f W'')      : nn = o*K + k,    kk = i           value W[i,k,o]
 __global__ void prep_weights_kernel(const float* __restrict__ w, int c_in, int kb, int c_out, int mode, int n, int k,
                                     int kp, uint16_t* __restrict__ bt_hi, uint16_t* __restrict__ bt_lo) {
   const int64_t total = (int64_t)n * kp;
@@ -409,7 +410,8 @@ __global__ void prep_weights_kernel(const float* __restrict__ w, int c_in, int k
     if (kk < k) {
       if (mode == 0) v = w[(int64_t)kk * c_out + nn];
       else if (mode == 1) v = w[(int64_t)nn * c_out + kk];
-      else v = w[((int64_t)nn * kb + (kk % kb)) * c_out + kk / kb];
+      else if (mode == 2) v = w[((int64_t)nn * kb + (kk % kb)) * c_out + kk / kb];
+      else v = w[((int64_t)kk * kb + (nn % kb)) * c_out + nn / kb];
     }
     const uint32_t pk = split_pack(v);
     bt_hi[idx] = (uint16_t)(pk >> 16);
@@ -424,7 +426,8 @@ int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, u
   int n, k;
   if (mode == 0) n = c_out, k = c_in * kb;
   else if (mode == 1) n = c_in * kb, k = c_out;
-  else n = c_in, k = c_out * kb;
+  else if (mode == 2) n = c_in, k = c_out * kb;
+  else n = c_out * kb, k = c_in;
   const int kp = (k + 31) / 32 * 32;
   const int64_t total = (int64_t)n * kp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
