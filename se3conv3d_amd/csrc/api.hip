@@ -516,10 +516,14 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     uint32_t* ubuf = (uint32_t*)(ws + l.big_u);
     if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
     // H[(p,b)][o,k] = alpha * sum_i f[(p,b),i] W[i,k,o]
-    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 3, bt_hi, bt_lo, stream)) return rc;
-    if (int rc = launch_gemm_nn_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, true, rows_in, s->c_out * kb, s->c_in,
-                                     (float*)(ws + l.split), nu, inv_fin, stream))
+    const bool strip = gemm_strip_bf16_applicable(rows_in, s->c_out * kb, s->c_in);
+    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 3, bt_hi, bt_lo, stream, nu, inv_fin, strip)) return rc;
+    if (strip) {
+      if (int rc = launch_gemm_strip_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, rows_in, s->c_out * kb, s->c_in, stream)) return rc;
+    } else if (int rc = launch_gemm_nn_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, true, rows_in, s->c_out * kb, s->c_in,
+                                            (float*)(ws + l.split), nullptr, 1.0f, stream)) {
       return rc;
+    }
     int n_part = 0;
     if (int rc = launch_edge_bwd_pair_bf16("edge_bwd", gt, gpk, rows_out, axes_ext, rho, bigw, ubuf, partials, &n_part,
                                            stream))
@@ -573,10 +577,15 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   if (want_params) {
     uint32_t* featpk = (uint32_t*)(ws + l.featpk);
     if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
-    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, stream)) return rc;
-    if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
-                                     (float*)(ws + l.split), nu, inv_fin, stream))
+    // alpha = nu/F_in is folded into the prepared weights (one multiply per weight instead of one per grad_T element)
+    const bool strip = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);
+    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, stream, nu, inv_fin, strip)) return rc;
+    if (strip) {
+      if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream)) return rc;
+    } else if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
+                                            (float*)(ws + l.split), nullptr, 1.0f, stream)) {
       return rc;
+    }
     if (grad_axes || grad_biases) {
       if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
                                                l.n_param_partials, stream))

@@ -253,7 +253,11 @@ int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* f
                            int co, float* out, uint32_t* t_save, const float* alpha_num, float alpha_scale,
                            hipStream_t stream);
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
-                        hipStream_t stream);
+                        hipStream_t stream, const float* scale_num = nullptr, float scale = 1.0f,
+                        bool frag_layout = false);
+bool gemm_strip_bf16_applicable(int64_t m, int n, int k);
+int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, uint32_t* c,
+                           int64_t m, int n, int k, hipStream_t stream);
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
                         float alpha_scale, hipStream_t stream);

@@ -175,21 +175,28 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   }
 }
 
-// Row-strip variant for a short k (kp <= 64) and a wide N, packed output -- the grad_T GEMM
-// (grad_T[rows, C_in*K] = g[rows, C_out] @ W^T).  A wavefront keeps the A fragments of its 32 rows in
-// registers and walks all N columns, so every output row is written front to back (the generic kernel's
-// 64-column blocks write 256-byte pieces 8 KB apart); the weight planes stream from L2.
+// Row-strip GEMM for the wide, write-dominated products with a short k (grad_T = g W^T, H = f W''):
+//   C[m, n] (packed words) = A[m, k] (packed words) * Bt[n, k]^T,   k <= 64, n large (C_in*K or C_out*K = 2048)
+// A wavefront keeps its 32 rows of A as MFMA fragments for the whole kernel and walks the n range 32 columns
+// at a time: 3*KS MFMAs, then 16 results per lane are split to hi/lo and stored (128 contiguous bytes per
+// row and half-wave).  The next tile's weight fragments (L1/L2-resident, 0.5 MB in all) are requested as soon
+// as the MFMAs have issued and land during the epilogue.  Everything fits 128 VGPRs, so 4 wavefronts share a
+// SIMD and the 4096 strips of the headline shape are resident at once (the previous 64-column version needed
+// ~150 VGPRs: 3 per SIMD, i.e. a second, mostly empty round).  alpha is folded into the prepared weights.
+#ifndef SE3_STRIP_ROT
+#define SE3_STRIP_ROT 17
+#endif
 template <int KS>  // kp / 16
-__global__ __launch_bounds__(256) void gemm_strip_bf16_kernel(const uint32_t* __restrict__ a,
-                                                              const uint16_t* __restrict__ bt_hi,
-                                                              const uint16_t* __restrict__ bt_lo,
-                                                              uint32_t* __restrict__ c, int64_t m, int n, int k,
-                                                              const float* __restrict__ alpha_num, float alpha_scale) {
+__global__ __launch_bounds__(256, 4) void gemm_strip_bf16_kernel(const uint32_t* __restrict__ a,
+                                                                 const uint16_t* __restrict__ bt_hi,
+                                                                 const uint16_t* __restrict__ bt_lo,
+                                                                 uint32_t* __restrict__ c, int64_t m, int n, int k) {
   constexpr int KP = KS * 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform: feeds a buffer descriptor
   const int rl = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
-  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+  if (row0 >= m) return;
   const __amdgpu_buffer_rsrc_t a_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a), (short)0, (int)(uint32_t)(m * k * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t bh_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -216,43 +223,76 @@ __global__ __launch_bounds__(256) void gemm_strip_bf16_kernel(const uint32_t* __
     frags_from_words(w, a_hi[ks], a_lo[ks]);
   }
 
-  u32x4 bh[2][KS], bl[2][KS];
+  // Weight fragments of the next 32 columns.  The loads are issued through inline asm and waited for with an
+  // explicit counted s_waitcnt: vmcnt retires loads and stores in order on this chip, so "at most 16 outstanding"
+  // after the 16 stores of a tile means the 2*KS older loads have landed while the stores are still in flight.
+  // (The compiler's own wait insertion treats mixed loads/stores as unordered and emits vmcnt(0): every tile
+  // then waits for its stores to retire, which is what bounded the first version of this kernel.)
+  u32x4 bh[KS], bl[KS];
   auto load_b = [&](int n0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const uint32_t off = (uint32_t)(((int64_t)(n0 + 32 * j + rl) * KP + 16 * ks + 8 * h) * 2);  // cols >= n: out of range -> 0
-        bh[j][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, off, 0, 0));
-        bl[j][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, off, 0, 0));
-      }
-  };
-  load_b(0);
-  for (int n0 = 0; n0 < n; n0 += 64) {
-    f32x16 acc0 = zero16(), acc1 = zero16();
+    const uint32_t off = (uint32_t)(((n0 / 32) * KS * 64 + lane) * 16);  // fragment-ordered planes, 1 KB per k-step
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      acc0 = mfma_bf16x3(a_hi[ks], a_lo[ks], bh[0][ks], bl[0][ks], acc0);
-      acc1 = mfma_bf16x3(a_hi[ks], a_lo[ks], bh[1][ks], bl[1][ks], acc1);
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
+                   : "+v"(bh[ks])
+                   : "v"(off), "s"(bh_rs), "n"(1024 * ks)
+                   : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
+                   : "+v"(bl[ks])
+                   : "v"(off), "s"(bl_rs), "n"(1024 * ks)
+                   : "memory");
     }
-    if (n0 + 64 < n) load_b(n0 + 64);  // in flight during the epilogue below
+  };
+  static_assert(KS == 2 || KS == 4, "operand lists of SE3_WAIT_B");
+#define SE3_WAIT_B(CNT)                                                                                           \
+  do {                                                                                                            \
+    if constexpr (KS == 2)                                                                                        \
+      asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bl[0]), "+v"(bl[1])::"memory");   \
+    else                                                                                                          \
+      asm volatile("s_waitcnt vmcnt(" #CNT ")"                                                                    \
+                   : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[KS - 2]), "+v"(bh[KS - 1]), "+v"(bl[0]), "+v"(bl[1]),      \
+                     "+v"(bl[KS - 2]), "+v"(bl[KS - 1])::"memory");                                               \
+  } while (0)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bh[ks] = bl[ks] = u32x4{0u, 0u, 0u, 0u};
+  // Output through a buffer descriptor based at the strip: rows >= m fall outside num_records and are dropped by
+  // the hardware, the uniform part of every address ((row-of-register * n + n0) * 4) rides in the scalar offset, so
+  // a store costs no VALU.  Straight-line loop body: the wait in front of the MFMAs must cover only the weight
+  // loads, not the 16 younger stores (vmcnt counts both, in order) -- with per-store branches the compiler fell
+  // back to vmcnt(0) and every tile waited for its stores to retire.
+  const int64_t c_bytes = (m - row0) * (int64_t)n * 4;
+  const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
+      c + row0 * n, (short)0, (int)(uint32_t)(c_bytes > 0xffffffffll ? 0xffffffffll : c_bytes), 0x00020000);
+  const int voff = (4 * h * n + rl) * 4;
+  const bool cols_full = n % 32 == 0;  // uniform
+  // Column order rotated per strip: with a power-of-two row pitch (n * 4 = 8 KB) every wavefront of the chip would
+  // otherwise write the same 128-byte column window of its rows at the same time, i.e. all traffic of a moment
+  // lands on a handful of L2 / HBM channels.
+  const int n_tiles = (n + 31) / 32;
+  int n0 = (int)(((blockIdx.x * 4 + wave) * (unsigned)SE3_STRIP_ROT) % (unsigned)n_tiles) * 32;
+  load_b(n0);
+  SE3_WAIT_B(0);
+  for (int it = 0; it < n_tiles; ++it) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = mfma_bf16x3(a_hi[ks], a_lo[ks], bh[ks], bl[ks], acc);
+    const int n_next = n0 + 32 < n ? n0 + 32 : 0;
+    load_b(n_next);  // in flight during the epilogue below (after the last tile: one unused fetch)
+    const int lane_off = (cols_full || n0 + rl < n) ? voff : (int)0x7fffff00;  // columns >= n: dropped
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      const int64_t g0 = row0 + acc_row(r, h), g1 = row0 + acc_row(r + 1, h);
-      uint32_t w00, w01, w10, w11;
-      split_pack2(alpha * acc0[r], alpha * acc0[r + 1], w00, w01);
-      split_pack2(alpha * acc1[r], alpha * acc1[r + 1], w10, w11);
-      const int c0 = n0 + rl, c1 = n0 + 32 + rl;
-      if (g0 < m) {
-        if (c0 < n) c[g0 * n + c0] = w00;
-        if (c1 < n) c[g0 * n + c1] = w10;
-      }
-      if (g1 < m) {
-        if (c0 < n) c[g1 * n + c0] = w01;
-        if (c1 < n) c[g1 * n + c1] = w11;
-      }
+      uint32_t w0, w1;
+      split_pack2(acc[r], acc[r + 1], w0, w1);
+#ifdef SE3_STRIP_NOSTORE
+      if ((w0 ^ w1) != 0x12345678u) continue;
+#endif
+      __builtin_amdgcn_raw_buffer_store_b32(w0, c_rs, lane_off, (acc_row(r, 0) * n + n0) * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(w1, c_rs, lane_off, (acc_row(r + 1, 0) * n + n0) * 4, 0);
     }
+    SE3_WAIT_B(16);  // the loads are older than the 16 stores
+    n0 = n_next;
   }
+#undef SE3_WAIT_B
 }
 
 // out = alpha * sum_z partials[z]  (fp32 or packed words)
@@ -401,8 +441,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
 //   mode 2 (dX = U W')      : nn = i,          kk = o*K + k     value W[i,k,o]
 //   mode 3 (H = f W'')      : nn = o*K + k,    kk = i           value W[i,k,o]
 __global__ void prep_weights_kernel(const float* __restrict__ w, int c_in, int kb, int c_out, int mode, int n, int k,
-                                    int kp, uint16_t* __restrict__ bt_hi, uint16_t* __restrict__ bt_lo) {
+                                    int kp, uint16_t* __restrict__ bt_hi, uint16_t* __restrict__ bt_lo,
+                                    const float* __restrict__ scale_num, float scale, int frag) {
   const int64_t total = (int64_t)n * kp;
+  const float sc = (scale_num ? *scale_num : 1.0f) * scale;  // the GEMM's alpha, applied to the weights once
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int nn = (int)(idx / kp), kk = (int)(idx % kp);
@@ -413,16 +455,21 @@ __global__ void prep_weights_kernel(const float* __restrict__ w, int c_in, int k
       else if (mode == 2) v = w[((int64_t)nn * kb + (kk % kb)) * c_out + kk / kb];
       else v = w[((int64_t)kk * kb + (nn % kb)) * c_out + nn / kb];
     }
-    const uint32_t pk = split_pack(v);
-    bt_hi[idx] = (uint16_t)(pk >> 16);
-    bt_lo[idx] = (uint16_t)(pk & 0xffffu);
+    const uint32_t pk = split_pack(v * sc);
+    // frag layout (gemm_strip_bf16_kernel): the 16 bytes lane (nn % 32, (kk % 16) / 8) needs for k-step kk / 16 of
+    // column tile nn / 32 sit at [tile][k-step][lane][8], so one load instruction reads 1 KB of consecutive bytes
+    // (row-major planes make it touch 32 cache lines for the same 1 KB)
+    const int64_t o = frag ? ((((int64_t)(nn / 32) * (kp / 16) + kk / 16) * 64 + ((kk % 16) / 8) * 32 + nn % 32) * 8 + kk % 8)
+                           : idx;
+    bt_hi[o] = (uint16_t)(pk >> 16);
+    bt_lo[o] = (uint16_t)(pk & 0xffffu);
   }
 }
 
 }  // namespace
 
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
-                        hipStream_t stream) {
+                        hipStream_t stream, const float* scale_num, float scale, bool frag_layout) {
   int n, k;
   if (mode == 0) n = c_out, k = c_in * kb;
   else if (mode == 1) n = c_in * kb, k = c_out;
@@ -432,7 +479,7 @@ int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, u
   const int64_t total = (int64_t)n * kp;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, c_in, kb, c_out, mode, n, k, kp, bt_hi,
-                     bt_lo);
+                     bt_lo, scale_num, scale, frag_layout ? 1 : 0);
   return check_launch();
 }
 
@@ -447,6 +494,26 @@ int gemm_nn_bf16_splits(int64_t m, int n, int k) {
   return (int)(s < 1 ? 1 : s);
 }
 
+// Row-strip kernel: packed output, k <= 64, n a multiple of 32, weights prepared with frag_layout and alpha folded in.
+bool gemm_strip_bf16_applicable(int64_t m, int n, int k) {
+  const int kp = (k + 31) / 32 * 32;
+  return kp <= 64 && n >= 512 && n % 32 == 0 && n <= (1 << 22) && m >= 128 * 256 &&
+         (m + 128) * (int64_t)k * 4 < (1ll << 32) - 64 && (int64_t)(n + 64) * kp * 2 < (1ll << 32) - 64;
+}
+
+int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, uint32_t* c,
+                           int64_t m, int n, int k, hipStream_t stream) {
+  if (m == 0 || n == 0) return SE3_OK;
+  if (!gemm_strip_bf16_applicable(m, n, k)) return SE3_ERR_UNSUPPORTED;
+  ProfScope prof(tag, stream);
+  const dim3 sgrid((unsigned)((m + 127) / 128));
+  if ((k + 31) / 32 * 32 == 32)
+    hipLaunchKernelGGL(gemm_strip_bf16_kernel<2>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k);
+  else
+    hipLaunchKernelGGL(gemm_strip_bf16_kernel<4>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k);
+  return check_launch();
+}
+
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
                         float alpha_scale, hipStream_t stream) {
@@ -454,17 +521,6 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
   ProfScope prof(tag, stream);
   const int kp = (k + 31) / 32 * 32;
   const int nkt = kp / BK;
-  if (out_packed && kp <= 64 && n >= 512 && m >= 128 * 256 && (m + 128) * (int64_t)k * 4 < (1ll << 32) - 64 &&
-      (int64_t)(n + 64) * kp * 2 < (1ll << 32) - 64) {
-    const dim3 sgrid((unsigned)((m + 127) / 128));
-    if (kp == 32)
-      hipLaunchKernelGGL(gemm_strip_bf16_kernel<2>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, (uint32_t*)c, m, n, k,
-                         alpha_num, alpha_scale);
-    else
-      hipLaunchKernelGGL(gemm_strip_bf16_kernel<4>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, (uint32_t*)c, m, n, k,
-                         alpha_num, alpha_scale);
-    return check_launch();
-  }
   int splits = split_ws ? gemm_nn_bf16_splits(m, n, k) : 1;
   const int per = (nkt + splits - 1) / splits;
   splits = (nkt + per - 1) / per;
