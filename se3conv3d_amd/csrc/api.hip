@@ -192,7 +192,7 @@ int shape_supported(const se3conv_shape* s) {
   return SE3_OK;
 }
 
-struct FwdLayout { size_t axes_ext, t, featpk, bt_hi, bt_lo, split, total; };
+struct FwdLayout { size_t axes_ext, t, featpk, bt_hi, bt_lo, split, geom_in, geom_out, total; };
 FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
   FwdLayout l{};
   size_t off = 0;
@@ -206,13 +206,15 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
     l.bt_hi = take(plane);
     l.bt_lo = take(plane);
     l.split = take(gemm_nn_bf16_split_bytes((int64_t)s->n_out * s->f_out, s->c_out, s->c_in * (int)kb));
+    l.geom_in = take((size_t)s->n_in * s->f_in * 64);
+    l.geom_out = take((size_t)s->n_out * s->f_out * 64);
   }
   l.total = off;
   return l;
 }
 
 struct BwdLayout {
-  size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, split, total;
+  size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, split, geom_in, geom_out, total;
   size_t big_u, bt2_hi, bt2_lo, split2;  // feature-gradient branch when it runs beside the parameter branch
   int n_param_partials, tn_splits;
 };
@@ -239,6 +241,8 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     l.bt_lo = take(plane);
     l.featpk = want_params ? take(rows_in * s->c_in * 4) : 0;
     l.gpk = take(rows_out * s->c_out * 4);
+    l.geom_in = take(rows_in * 64);
+    l.geom_out = take(rows_out * 64);
     size_t sp = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_out, s->c_in * (int)kb, s->c_out) : 0;
     const size_t sp3 = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_out * (int)kb, s->c_in) : 0;
     if (sp3 > sp) sp = sp3;
@@ -295,6 +299,7 @@ EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* fr
   g.ctr_pts = pts_out, g.ctr_frames = frames_out, g.nb_pts = pts_in, g.nb_frames = frames_in;
   g.nbr = neighbors, g.nbr_stride = 2, g.nbr_offset = 1, g.ends = ends;
   g.n_ctr = s->n_out, g.f_ctr = s->f_out, g.f_nb = s->f_in, g.transposed = 0;
+  g.n_nb = s->n_in;
   return g;
 }
 
@@ -396,7 +401,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   float* t = t_save ? t_save : (float*)(ws + l.t);
 
   hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
-  const EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
+  EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
   const int64_t rows_out = s->n_out * s->f_out;
   const int ck = s->c_in * s->num_basis;
   const float inv_fin = 1.0f / (float)s->f_in;
@@ -408,6 +413,13 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   uint32_t* featpk = (uint32_t*)(ws + l.featpk);
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
+  {  // packed geometry records for the gathers of the edge kernels
+    float* geom_in = (float*)(ws + l.geom_in);
+    float* geom_out = (float*)(ws + l.geom_out);
+    if (int rc = launch_pack_geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in, stream)) return rc;
+    if (int rc = launch_pack_geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out, stream)) return rc;
+    g.ctr_geom = geom_out, g.nb_geom = geom_in;
+  }
   if (int rc = launch_split_pack(feat, featpk, s->n_in * s->f_in * s->c_in, stream)) return rc;
   if (int rc = launch_prep_weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, stream)) return rc;
   if (conv_fused_bf16_supported(g, s->c_in))  // edge phase + contraction in one launch; T only if the caller wants it
@@ -451,12 +463,13 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   const float inv_fin = 1.0f / (float)s->f_in;
 
   hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
-  const EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
+  EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
   // transposed graph: centre = input point, edges lead to output points (feature gradient)
   EdgeGeom gt{};
   gt.ctr_pts = pts_in, gt.ctr_frames = frames_in, gt.nb_pts = pts_out, gt.nb_frames = frames_out;
   gt.nbr = t_samples, gt.nbr_stride = 1, gt.nbr_offset = 0, gt.ends = t_ends;
   gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.transposed = 1;
+  gt.n_nb = s->n_out;
   float* partials = (float*)(ws + l.param_partials);
   float* tn_partials = (float*)(ws + l.tn_partials);
 
@@ -505,6 +518,14 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   uint32_t* gpk = (uint32_t*)(ws + l.gpk);
   uint32_t* bigw = (uint32_t*)big;
+  {  // packed geometry records for the gathers of the edge kernels
+    float* geom_in = (float*)(ws + l.geom_in);
+    float* geom_out = (float*)(ws + l.geom_out);
+    if (int rc = launch_pack_geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in, stream)) return rc;
+    if (int rc = launch_pack_geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out, stream)) return rc;
+    g.ctr_geom = geom_out, g.nb_geom = geom_in;
+    gt.ctr_geom = geom_in, gt.nb_geom = geom_out;
+  }
   if (int rc = launch_split_pack(grad_out, gpk, rows_out * s->c_out, stream)) return rc;
   bool branch_forked = false;
   SideStream& side = side_stream();

@@ -212,6 +212,9 @@ struct EdgeGeom {            // one side-agnostic view of the geometry for the e
   const float* ctr_frames;   // [Nc,Fc,9]
   const float* nb_pts;       // [Nn,3]   points the edges lead to
   const float* nb_frames;    // [Nn,Fn,9]
+  const float* ctr_geom;     // packed 64-byte records per (point, frame) row (pack_geometry_kernel); bf16 kernels
+  const float* nb_geom;
+  int64_t n_nb;              // number of points on the neighbour side
   const int32_t* nbr;        // neighbour id of edge e at nbr[e*nbr_stride + nbr_offset]
   int nbr_stride, nbr_offset;
   const int32_t* ends;       // [Nc] inclusive end offsets of every centre's edge group
@@ -255,6 +258,7 @@ int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* f
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream, const float* scale_num = nullptr, float scale = 1.0f,
                         bool frag_layout = false);
+int launch_pack_geometry(const float* pts, const float* frames, int64_t n, int f, float* records, hipStream_t stream);
 bool gemm_strip_bf16_applicable(int64_t m, int n, int k);
 int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, uint32_t* c,
                            int64_t m, int n, int k, hipStream_t stream);

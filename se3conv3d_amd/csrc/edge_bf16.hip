@@ -38,10 +38,7 @@ __device__ __forceinline__ void lane_descriptor(const EdgeGeom& g, const RowInfo
   const int nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
   q = nb * g.f_nb + fn;
   float xn[3], rn[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+  load_geom_record(buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64), q, xn, rn);
   if (!g.transposed)
     edge_descriptor(xn, rn, yc, rc, rho, d);
   else
@@ -134,73 +131,64 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(E
   const int a0 = (int)(item - ctr * groups) * 2;
   const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
   const int n_total = (g.ends[ctr] - start) * g.f_nb;
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
   float yc[3], rc[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[(ctr * g.f_ctr + a0 + wv) * 9 + i];  // this wavefront's frame
+  load_geom_record(buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64), (int)(ctr * g.f_ctr + a0 + wv), yc, rc);  // this wavefront's frame
   const int hb = 16 * h;
   const int cb4 = (32 * wv + kcol) * 4;  // this wavefront aggregates channels 32*wv .. 32*wv+31
 
-  auto edge_of = [&](int c0, int& nb, int& q) {
+  // Neighbour ids are fetched two chunks ahead and the geometry records one chunk ahead, so that no load result is
+  // needed in the chunk that issues it (the dependent chain ids -> record/feature rows costs one memory latency
+  // per link; a wavefront lives for ~2.5 chunks only).  Frame-edge indices past the end clamp to the last one.
+  auto nbr_of = [&](int c0) {
     const int fe = min(c0 + kcol, n_total - 1);
-    int e, fn;
-    if (fnb_shift >= 0) {
-      e = start + (fe >> fnb_shift);
-      fn = fe & ((1 << fnb_shift) - 1);
-    } else {
-      e = start + fe / g.f_nb;
-      fn = fe % g.f_nb;
-    }
-    nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-    q = nb * g.f_nb + fn;
+    const int e = start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+    return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
   };
-  auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+  auto row_of = [&](int nb, int c0) {
+    const int fe = min(c0 + kcol, n_total - 1);
+    return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
   };
 
   f32x16 acc[2] = {zero16(), zero16()};  // [frame]
-  int nb_nx = 0, q_nx = 0;
+  int nb_b = 0, q_a = 0;
   float xn_nx[3], rn_nx[9];
   if (n_total > 0) {
-    edge_of(0, nb_nx, q_nx);
-    geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+    const int nb_a = nbr_of(0);
+    nb_b = nbr_of(32);
+    q_a = row_of(nb_a, 0);
+    load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
   }
   int buf = 0;
   for (int c0 = 0; c0 < n_total; c0 += 32, buf ^= 1) {
     const int cnt = min(32, n_total - c0);
     // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
-    const int qoff = c0 + kcol < n_total ? q_nx * (C * 4) : kOobOffset;
+    const int qoff = c0 + kcol < n_total ? q_a * (C * 4) : kOobOffset;
     float xn[3], rn[9], d[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
 #pragma unroll
     for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-    const bool more = c0 + 32 < n_total;
-    if (more) edge_of(c0 + 32, nb_nx, q_nx);
+    const int q_b = row_of(nb_b, c0 + 32);
+    nb_b = nbr_of(c0 + 64);
+
+    // gathered feature words for this wavefront's 32 channels (shared by both frames): all 16 loads go out now and
+    // are only turned into MFMA fragments after the barrier below
+    uint32_t fw[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+        fw[s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + cb4, 0, 0);
+      }
+    load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+    q_a = q_b;
+
     if (!g.transposed)
       edge_descriptor(xn, rn, yc, rc, rho, d);
     else
       edge_descriptor(yc, rc, xn, rn, rho, d);
-
-    // gathered feature fragments for this wavefront's 32 channels (shared by both frames)
-    u32x4 fa_hi[2], fa_lo[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s * 16 < cnt) {
-        uint32_t w[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
-          w[j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + cb4, 0, 0);
-        }
-        frags_from_words(w, fa_hi[s], fa_lo[s]);
-      }
-    }
-    if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
 
     // kernel MLP + GELU for this wavefront's frame; both lane halves hold the same descriptor: half 0 feeds
     // dims 0..7, half 1 dims 8, 9
@@ -218,10 +206,7 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(E
         if (s * 16 < cnt) {
           float pv[8];
 #pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            const f32x2 y = gelu_erf2(f32x2{phi[8 * s + j], phi[8 * s + j + 1]});
-            pv[j] = y[0], pv[j + 1] = y[1];
-          }
+          for (int j = 0; j < 8; ++j) pv[j] = gelu_erf(phi[8 * s + j]);
           u32x4 b_hi, b_lo;
           frags_from_floats(pv, b_hi, b_lo);
           *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
@@ -233,11 +218,13 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(E
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (s * 16 < cnt) {
+        u32x4 fa_hi, fa_lo;
+        frags_from_words(fw[s], fa_hi, fa_lo);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           const u32x4 b_hi = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
           const u32x4 b_lo = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
-          acc[a] = mfma_bf16x3(fa_hi[s], fa_lo[s], b_hi, b_lo, acc[a]);
+          acc[a] = mfma_bf16x3(fa_hi, fa_lo, b_hi, b_lo, acc[a]);
         }
       }
     }
@@ -415,6 +402,8 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
   __syncthreads();
   const float rho = *rho_p;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * C * 4);
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const __amdgpu_buffer_rsrc_t ctrg_rs = buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64);
   f32x16 dacc = zero16();  // lane (j = kcol, h), register r: d[A;beta][j][k = acc_row(r,h)]
 
   for (int64_t item = (int64_t)blockIdx.x * NW + wave; item < n_items; item += (int64_t)gridDim.x * NW) {
@@ -425,10 +414,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
     const int n_total = (g.ends[ctr] - start) * g.f_nb;
     if (n_total == 0) continue;
     float yc[3], rc[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[(ctr * g.f_ctr + a0 + h) * 9 + i];
+    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + h), yc, rc);
 
     // gT fragments (MFMA B operand) of the item's two rows: lane (k = kcol, h) holds channels 16*st + 8h + j
 #pragma unroll
@@ -460,10 +446,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
       q = nb * g.f_nb + fn;
     };
     auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+      load_geom_record(nbg_rs, q, xn, rn);
     };
     int nb_nx, q_nx;
     float xn_nx[3], rn_nx[9];
@@ -585,6 +568,20 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
   }
 }
 
+// [N,3] points + [N,F,9] frames -> one 64-byte record per (point, frame) row, see load_geom_record
+__global__ void pack_geometry_kernel(const float* __restrict__ pts, const float* __restrict__ frames, int64_t rows,
+                                     int f, float* __restrict__ records) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const int64_t pt = row / f;
+  const float* r = frames + row * 9;
+  float4* dst = reinterpret_cast<float4*>(records + row * 16);
+  dst[0] = make_float4(pts[pt * 3], pts[pt * 3 + 1], pts[pt * 3 + 2], r[8]);
+  dst[1] = make_float4(r[0], r[1], r[2], r[3]);
+  dst[2] = make_float4(r[4], r[5], r[6], r[7]);
+  dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ void split_pack_kernel(const float* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) {
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 + 3 < n) {
@@ -596,6 +593,15 @@ __global__ void split_pack_kernel(const float* __restrict__ src, uint32_t* __res
 }
 
 }  // namespace
+
+int launch_pack_geometry(const float* pts, const float* frames, int64_t n, int f, float* records, hipStream_t stream) {
+  const int64_t rows = n * f;
+  if (rows == 0) return SE3_OK;
+  if (rows * 64 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;  // 32-bit record offsets in the kernels
+  hipLaunchKernelGGL(pack_geometry_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, pts, frames, rows, f,
+                     records);
+  return check_launch();
+}
 
 int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream) {
   if (n == 0) return SE3_OK;

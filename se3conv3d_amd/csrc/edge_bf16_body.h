@@ -22,6 +22,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, int64
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)n, 0x00020000);
 }
 
+// Packed geometry record of one (point, frame) row: 16 floats = [x, y, z, R8 | R0..R3 | R4..R7 | pad] (64 bytes, built
+// by pack_geometry_kernel).  A lane fetches its row with three 16-byte loads out of ONE cache line; from the
+// reference's separate [N,3] / [N,F,9] arrays it took 12 dword loads, and a gather instruction costs the L1 one
+// cycle per distinct line it touches -- that alone (12 x 32..64 lines per 32 frame-edges) bounded the edge kernels.
+__device__ __forceinline__ void load_geom_record(const __amdgpu_buffer_rsrc_t rs, int row, float x[3], float r[9]) {
+  const int off = row * 64;
+  const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+  const auto v2 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, 0);
+  x[0] = __uint_as_float(v0[0]), x[1] = __uint_as_float(v0[1]), x[2] = __uint_as_float(v0[2]);
+  r[8] = __uint_as_float(v0[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __uint_as_float(v1[i]), r[4 + i] = __uint_as_float(v2[i]);
+}
+
 // MLP weights [A; beta] as MFMA B fragments in LDS: arrangement a has descriptor dims 0..7 in the lane
 // half that builds row a's descriptors.  Called by the first wavefront of a block.
 template <int FC>
@@ -61,14 +76,10 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 
   const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
   const int n_total = (g.ends[ctr] - start) * g.f_nb;
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
   float yc[3], rc[9];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
-  {
-    const int64_t fr = ctr * g.f_ctr + a0 + (FC == 2 ? h : 0);  // the centre frame this lane builds descriptors for
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[fr * 9 + i];
-  }
+  // the centre frame this lane builds descriptors for
+  load_geom_record(buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64), (int)(ctr * g.f_ctr + a0 + (FC == 2 ? h : 0)), yc, rc);
   const int row_bytes = channels * 4;
   const int hb = 16 * h;  // ds_bpermute byte address of lane 4h
 
@@ -103,10 +114,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 #pragma unroll
       for (int i = 0; i < 9; ++i) rn[i] = (float)(q & 127) * 0.002f - i;
 #else
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+      load_geom_record(nbg_rs, q, xn, rn);
 #endif
     };
     // software pipeline: the neighbour ids and geometry of chunk c0+32 are fetched while chunk c0 computes
@@ -262,6 +270,8 @@ __device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdg
   const int cb = VW * kcol;
   const bool ch_ok = FULL || cb < channels;
   const int cb4 = (ch_ok ? cb : 0) * 4;
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const __amdgpu_buffer_rsrc_t ctrg_rs = buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64);
 
   struct Header {
     int e0, e1;  // ends[ctr-1] (0 for the first point), ends[ctr]
@@ -273,11 +283,7 @@ __device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdg
     hd.e0 = g.ends[ctr > 0 ? ctr - 1 : 0];
     if (ctr == 0) hd.e0 = 0;
     hd.e1 = g.ends[ctr];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) hd.yc[i] = g.ctr_pts[ctr * 3 + i];
-    const int64_t fr = ctr * g.f_ctr + a0 + (FC == 2 ? h : 0);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) hd.rc[i] = g.ctr_frames[fr * 9 + i];
+    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (FC == 2 ? h : 0)), hd.yc, hd.rc);
   };
   auto edge_of = [&](int start, int n_total, int c0, int& nb, int& q) {
     const int fe = min(c0 + kcol, n_total - 1);
@@ -293,10 +299,7 @@ __device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdg
     q = nb * g.f_nb + fn;
   };
   auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+    load_geom_record(nbg_rs, q, xn, rn);
   };
 
   int64_t item = first;

@@ -51,6 +51,8 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
   __syncthreads();
   const float rho = *rho_p;
   const __amdgpu_buffer_rsrc_t g_rs = buffer_of(gpk, g_rows * C * 4);
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const __amdgpu_buffer_rsrc_t ctrg_rs = buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64);
   const int groups = g.f_ctr / 2;
   const int hb = 16 * h;
   const int cb4 = (32 * wv + kcol) * 4;  // this wavefront aggregates channels 32*wv .. 32*wv+31 of U
@@ -64,10 +66,7 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
     const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
     const int n_total = (g.ends[ctr] - start) * g.f_nb;
     float yc[3], rc[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) yc[i] = g.ctr_pts[ctr * 3 + i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rc[i] = g.ctr_frames[(ctr * g.f_ctr + a0 + wv) * 9 + i];
+    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + wv), yc, rc);
 
     auto edge_of = [&](int c0, int& nb, int& q) {
       const int fe = min(c0 + kcol, n_total - 1);
@@ -83,10 +82,7 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
       q = nb * g.f_nb + fn;
     };
     auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = g.nb_pts[(int64_t)nb * 3 + i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = g.nb_frames[(int64_t)q * 9 + i];
+      load_geom_record(nbg_rs, q, xn, rn);
     };
 
     f32x16 acc[2] = {zero16(), zero16()};  // [frame] of U
