@@ -416,70 +416,72 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
     float yc[3], rc[9];
     load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + h), yc, rc);
 
+    // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
+    auto nbr_of = [&](int c0) {
+      const int fe = min(c0 + kcol, n_total - 1);
+      const int e = start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+      return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+    };
+    auto row_of = [&](int nb, int c0) {
+      const int fe = min(c0 + kcol, n_total - 1);
+      return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
+    };
+    const int nb_a = nbr_of(0);
+    int nb_b = nbr_of(32);
+
     // gT fragments (MFMA B operand) of the item's two rows: lane (k = kcol, h) holds channels 16*st + 8h + j
+    uint32_t gw[2][CH16][8];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const uint32_t* gt_row = grad_t + (item * 2 + a) * (int64_t)C * kBasis;
 #pragma unroll
-      for (int st = 0; st < CH16; ++st) {
-        uint32_t w[8];
+      for (int st = 0; st < CH16; ++st)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = gt_row[(16 * st + 8 * h + j) * kBasis + kcol];
+        for (int j = 0; j < 8; ++j) gw[a][st][j] = gt_row[(16 * st + 8 * h + j) * kBasis + kcol];
+    }
+    int q_a = row_of(nb_a, 0);
+    float xn_nx[3], rn_nx[9];
+    load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int st = 0; st < CH16; ++st) {
         u32x4 f_hi, f_lo;
-        frags_from_words(w, f_hi, f_lo);
+        frags_from_words(gw[a][st], f_hi, f_lo);
         *reinterpret_cast<u32x4*>(&lds_gt[wave][a][st][0][lane][0]) = f_hi;
         *reinterpret_cast<u32x4*>(&lds_gt[wave][a][st][1][lane][0]) = f_lo;
       }
-    }
-
-    auto edge_of = [&](int c0, int& nb, int& q) {
-      const int fe = min(c0 + kcol, n_total - 1);
-      int e, fn;
-      if (fnb_shift >= 0) {
-        e = start + (fe >> fnb_shift);
-        fn = fe & ((1 << fnb_shift) - 1);
-      } else {
-        e = start + fe / g.f_nb;
-        fn = fe % g.f_nb;
-      }
-      nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-      q = nb * g.f_nb + fn;
-    };
-    auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-      load_geom_record(nbg_rs, q, xn, rn);
-    };
-    int nb_nx, q_nx;
-    float xn_nx[3], rn_nx[9];
-    edge_of(0, nb_nx, q_nx);
-    geom_of(nb_nx, q_nx, xn_nx, rn_nx);
 
     for (int c0 = 0; c0 < n_total; c0 += 32) {
       const int cnt = min(32, n_total - c0);
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
-      const int qoff = c0 + kcol < n_total ? q_nx * (C * 4) : kOobOffset;
+      const int qoff = c0 + kcol < n_total ? q_a * (C * 4) : kOobOffset;
       float xn[3], rn[9], d[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
 #pragma unroll
       for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-      const bool more = c0 + 32 < n_total;
-      if (more) edge_of(c0 + 32, nb_nx, q_nx);
-      if (!g.transposed)
-        edge_descriptor(xn, rn, yc, rc, rho, d);
-      else
-        edge_descriptor(yc, rc, xn, rn, rho, d);
+      const int q_b = row_of(nb_b, c0 + 32);
+      nb_b = nbr_of(c0 + 64);
 
-      // gathered feature fragments (MFMA A operand of gphi): lane (n = kcol, h) reads its own source row
-      u32x4 fa_hi[CH16], fa_lo[CH16];
+      // gathered feature rows (MFMA A operand of gphi): lane (n = kcol, h) reads its own source row; the words are
+      // turned into fragments only after the GELU' work below
+      uint32_t fw[CH16][8];
 #pragma unroll
       for (int st = 0; st < CH16; ++st) {
         const int voff = qoff + (16 * st + 8 * h) * 4;
         const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
         const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff + 16, 0, 0);
-        const uint32_t w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        frags_from_words(w, fa_hi[st], fa_lo[st]);
+        fw[st][0] = v0[0], fw[st][1] = v0[1], fw[st][2] = v0[2], fw[st][3] = v0[3];
+        fw[st][4] = v1[0], fw[st][5] = v1[1], fw[st][6] = v1[2], fw[st][7] = v1[3];
       }
-      if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+      load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      q_a = q_b;
+
+      if (!g.transposed)
+        edge_descriptor(xn, rn, yc, rc, rho, d);
+      else
+        edge_descriptor(yc, rc, xn, rn, rho, d);
 
       // descriptor image for the d[A;beta] product: half h writes the rows of frame a0+h
       {
@@ -508,6 +510,8 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+      // GELU' of both frames first (pure VALU, covers the gather latency) ...
+      float dyv[2][16];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const bool dims07 = h == a;
@@ -520,6 +524,19 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
         const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[a][0][lane][0]);
         const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[a][1][lane][0]);
         const f32x16 pre = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float y;
+          gelu_erf_grad(pre[r], y, dyv[a][r]);
+        }
+      }
+      // ... then gphi = F gT on the gathered rows, gpre = gphi * GELU', and the d[A;beta] product
+      u32x4 fa_hi[CH16], fa_lo[CH16];
+#pragma unroll
+      for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
+      const int jcol = min(kcol, 11);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
         f32x16 gphi = zero16();
 #pragma unroll
         for (int st = 0; st < CH16; ++st) {
@@ -532,12 +549,9 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
           if (s * 16 < cnt) {
             float gp[8];
             uint32_t wd[8];
-            const int jcol = min(kcol, 11);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              float y, dy;
-              gelu_erf_grad(pre[8 * s + j], y, dy);
-              gp[j] = gphi[8 * s + j] * dy;
+              gp[j] = gphi[8 * s + j] * dyv[a][8 * s + j];
               wd[j] = lds_desc[wave][a][acc_row(8 * s + j, h)][jcol];
             }
             u32x4 ga_hi, ga_lo, db_hi, db_lo;
