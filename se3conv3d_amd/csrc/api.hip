@@ -254,11 +254,13 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   if (want_params) big = rows_out * s->c_in * kb * 4;
   if (want_feat && rows_in * s->c_out * kb * 4 > big) big = rows_in * s->c_out * kb * 4;
   l.big = take(big);
-  if (fast && want_feat && want_params) {
-    l.big_u = take(rows_in * s->c_out * kb * 4);
+  if (fast && want_feat) {
     const size_t p2 = (size_t)s->c_in * align_up((size_t)s->c_out * kb, 32) * 2;
     l.bt2_hi = take(p2);
     l.bt2_lo = take(p2);
+  }
+  if (fast && want_feat && want_params) {
+    l.big_u = take(rows_in * s->c_out * kb * 4);
     l.split2 = take(gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb));
   }
   l.t = (want_params && !have_t) ? take(rows_out * s->c_in * kb * 4) : 0;
@@ -400,28 +402,31 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   float* axes_ext = (float*)(ws + l.axes_ext);
   float* t = t_save ? t_save : (float*)(ws + l.t);
 
-  hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
   EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
   const int64_t rows_out = s->n_out * s->f_out;
   const int ck = s->c_in * s->num_basis;
   const float inv_fin = 1.0f / (float)s->f_in;
   // einsum('nik,iko->no') :210, /F_in :213, *norm_num_neighs_ :216 are the GEMM + its alpha
   if (s->precision == SE3_PRECISION_FP32) {
+    hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
     if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, axes_ext, rho, t, stream)) return rc;
     return launch_gemm_nn("gemm_out", t, conv_weights, out, rows_out, s->c_out, ck, nu, inv_fin, stream);
   }
   uint32_t* featpk = (uint32_t*)(ws + l.featpk);
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
-  {  // packed geometry records for the gathers of the edge kernels
+  {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
-    if (int rc = launch_pack_geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in, stream)) return rc;
-    if (int rc = launch_pack_geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out, stream)) return rc;
+    PrepBatch pb;
+    pb.axes(proj_axes, proj_biases, axes_ext);
+    pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+    pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    pb.split(feat, featpk, s->n_in * s->f_in * s->c_in);
+    pb.weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo);
+    if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
   }
-  if (int rc = launch_split_pack(feat, featpk, s->n_in * s->f_in * s->c_in, stream)) return rc;
-  if (int rc = launch_prep_weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, stream)) return rc;
   if (conv_fused_bf16_supported(g, s->c_in))  // edge phase + contraction in one launch; T only if the caller wants it
     return launch_conv_fused_bf16("conv_fused_fwd", g, featpk, s->n_in * s->f_in, axes_ext, rho, bt_hi, bt_lo, s->c_out,
                                   out, (uint32_t*)t_save, nu, inv_fin, stream);
@@ -462,7 +467,6 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   const int64_t rows_out = s->n_out * s->f_out, rows_in = s->n_in * s->f_in;
   const float inv_fin = 1.0f / (float)s->f_in;
 
-  hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
   EdgeGeom g = forward_geom(pts_in, pts_out, frames_in, frames_out, neighbors, ends, s);
   // transposed graph: centre = input point, edges lead to output points (feature gradient)
   EdgeGeom gt{};
@@ -474,6 +478,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   float* tn_partials = (float*)(ws + l.tn_partials);
 
   if (s->precision == SE3_PRECISION_FP32) {
+    hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
     if (want_params) {
       // gT[m,(i,k)] = alpha * sum_o g[m,o] W[i,k,o]
       float* wt = (float*)(ws + l.wt);
@@ -514,32 +519,55 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   }
 
   // ---- split-bf16 path: same stages, operands as packed words -----------------------------------------
-  uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
+  uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);    // parameter branch: grad_T (or H) weights
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
+  uint16_t* bx_hi = (uint16_t*)(ws + l.bt2_hi);   // feature branch: grad_X weights
+  uint16_t* bx_lo = (uint16_t*)(ws + l.bt2_lo);
   uint32_t* gpk = (uint32_t*)(ws + l.gpk);
+  uint32_t* featpk = (uint32_t*)(ws + l.featpk);
   uint32_t* bigw = (uint32_t*)big;
-  {  // packed geometry records for the gathers of the edge kernels
+  const bool feat_branch = want_feat && rows_in > 0;
+  const bool merged = feat_branch && want_params && (grad_axes || grad_biases) && rows_out > 0 && l.big_u != 0 &&
+                      edge_bwd_pair_bf16_supported(s->f_in, s->c_out);
+  const bool strip_t = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);            // grad_T = g W^T
+  const bool strip_h = gemm_strip_bf16_applicable(rows_in, s->c_out * kb, s->c_in);   // H = f W''
+  {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
-    if (int rc = launch_pack_geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in, stream)) return rc;
-    if (int rc = launch_pack_geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out, stream)) return rc;
+    PrepBatch pb;
+    pb.axes(proj_axes, proj_biases, axes_ext);
+    pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+    pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    pb.split(grad_out, gpk, rows_out * s->c_out);
+    if (feat_branch) pb.weights(conv_weights, s->c_in, kb, s->c_out, 2, bx_hi, bx_lo);
+    if (want_params) {
+      pb.split(feat, featpk, rows_in * s->c_in);
+      // alpha = nu/F_in is folded into these weights (one multiply per weight instead of one per grad_T element)
+      if (merged) pb.weights(conv_weights, s->c_in, kb, s->c_out, 3, bt_hi, bt_lo, nu, inv_fin, strip_h);
+      else pb.weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, nu, inv_fin, strip_t);
+    }
+    if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
     gt.ctr_geom = geom_in, gt.nb_geom = geom_out;
   }
-  if (int rc = launch_split_pack(grad_out, gpk, rows_out * s->c_out, stream)) return rc;
-  bool branch_forked = false;
-  SideStream& side = side_stream();
-  // Both gradients wanted and the shape fits the wave-pair kernel: one walk over the transposed graph yields U
-  // (feature gradient) and d[A;beta]; grad_T and the output-major parameter pass are not needed.
-  if (want_feat && want_params && (grad_axes || grad_biases) && rows_in > 0 && rows_out > 0 && l.big_u != 0 &&
-      edge_bwd_pair_bf16_supported(s->f_in, s->c_out)) {
-    uint32_t* featpk = (uint32_t*)(ws + l.featpk);
+  auto weight_gradient = [&]() -> int {
+    if (!grad_weights) return SE3_OK;
+    const uint32_t* t = (const uint32_t*)t_save;
+    if (!t) {
+      uint32_t* tt = (uint32_t*)(ws + l.t);
+      if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, rows_in, axes_ext, rho, tt, stream)) return rc;
+      t = tt;
+    }
+    return launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck, s->c_out, nu,
+                               inv_fin, stream);
+  };
+
+  // Opt-in (SE3_BWD_MERGE): one walk over the transposed graph yields U (feature gradient) and d[A;beta]; grad_T and
+  // the output-major parameter pass are not needed.
+  if (merged) {
     uint32_t* ubuf = (uint32_t*)(ws + l.big_u);
-    if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
     // H[(p,b)][o,k] = alpha * sum_i f[(p,b),i] W[i,k,o]
-    const bool strip = gemm_strip_bf16_applicable(rows_in, s->c_out * kb, s->c_in);
-    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 3, bt_hi, bt_lo, stream, nu, inv_fin, strip)) return rc;
-    if (strip) {
+    if (strip_h) {
       if (int rc = launch_gemm_strip_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, rows_in, s->c_out * kb, s->c_in, stream)) return rc;
     } else if (int rc = launch_gemm_nn_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, true, rows_in, s->c_out * kb, s->c_in,
                                             (float*)(ws + l.split), nullptr, 1.0f, stream)) {
@@ -551,57 +579,41 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       return rc;
     hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
                        grad_axes, grad_biases);
-    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, bt_hi, bt_lo, stream)) return rc;
-    if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bt_hi, bt_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
+    if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
                                      (float*)(ws + l.split), nu, inv_fin, stream))
       return rc;
-    if (grad_weights) {
-      const uint32_t* t = (const uint32_t*)t_save;
-      if (!t) {
-        uint32_t* tt = (uint32_t*)(ws + l.t);
-        if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, rows_in, axes_ext, rho, tt, stream)) return rc;
-        t = tt;
-      }
-      if (int rc = launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck,
-                                       s->c_out, nu, inv_fin, stream))
-        return rc;
-    }
+    if (int rc = weight_gradient()) return rc;
     return check_launch();
   }
-  if (want_feat && rows_in > 0) {
-    // feature branch: on the side stream when there is a parameter branch to overlap with
+
+  bool branch_forked = false;
+  SideStream& side = side_stream();
+  if (feat_branch) {
+    // feature branch: on the side stream when there is a parameter branch to overlap with (SE3_OVERLAP)
     hipStream_t fs = stream;
-    uint16_t *fbh = bt_hi, *fbl = bt_lo;
     uint32_t* ubuf = bigw;
     float* fsplit = (float*)(ws + l.split);
     if (want_params && l.big_u != 0 && side.ok && getenv("SE3_OVERLAP") != nullptr) {
       if (hipEventRecord(side.fork, stream) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess)
         return SE3_ERR_LAUNCH;
       fs = side.stream;
-      fbh = (uint16_t*)(ws + l.bt2_hi), fbl = (uint16_t*)(ws + l.bt2_lo);
       ubuf = (uint32_t*)(ws + l.big_u);
       fsplit = (float*)(ws + l.split2);
       branch_forked = true;
     }
-    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 2, fbh, fbl, fs)) return rc;
     if (conv_fused_bf16_supported(gt, s->c_out)) {
-      if (int rc = launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, fbh, fbl, s->c_in, grad_feat,
+      if (int rc = launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, bx_hi, bx_lo, s->c_in, grad_feat,
                                           nullptr, nu, inv_fin, fs))
         return rc;
     } else {
       if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs)) return rc;
-      if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, fbh, fbl, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
+      if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
                                        fsplit, nu, inv_fin, fs))
         return rc;
     }
   }
   if (want_params) {
-    uint32_t* featpk = (uint32_t*)(ws + l.featpk);
-    if (int rc = launch_split_pack(feat, featpk, rows_in * s->c_in, stream)) return rc;
-    // alpha = nu/F_in is folded into the prepared weights (one multiply per weight instead of one per grad_T element)
-    const bool strip = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);
-    if (int rc = launch_prep_weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, stream, nu, inv_fin, strip)) return rc;
-    if (strip) {
+    if (strip_t) {
       if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream)) return rc;
     } else if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
                                             (float*)(ws + l.split), nullptr, 1.0f, stream)) {
@@ -614,17 +626,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
                          l.n_param_partials, grad_axes, grad_biases);
     }
-    if (grad_weights) {
-      const uint32_t* t = (const uint32_t*)t_save;
-      if (!t) {
-        uint32_t* tt = (uint32_t*)(ws + l.t);
-        if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, rows_in, axes_ext, rho, tt, stream)) return rc;
-        t = tt;
-      }
-      if (int rc = launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck,
-                                       s->c_out, nu, inv_fin, stream))
-        return rc;
-    }
+    if (int rc = weight_gradient()) return rc;
   }
   if (branch_forked) {
     if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(stream, side.join, 0) != hipSuccess)

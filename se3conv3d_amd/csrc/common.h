@@ -258,6 +258,30 @@ int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* f
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream, const float* scale_num = nullptr, float scale = 1.0f,
                         bool frag_layout = false);
+// Batched operand preparation (prep.hip): collect the jobs of one call, launch them as one kernel.
+struct PrepJob {
+  int type, blocks;
+  const void *a, *b;
+  void *o0, *o1;
+  int64_t n;
+  int p[8];
+  float scale;
+};
+struct PrepJobs {
+  int count;
+  PrepJob job[8];
+};
+struct PrepBatch {
+  PrepJobs jobs{};
+  int status = SE3_OK;
+  void axes(const float* axes, const float* biases, float* ext);
+  void geometry(const float* pts, const float* frames, int64_t n, int f, float* records);
+  void split(const float* src, uint32_t* dst, int64_t n);
+  void weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
+               const float* scale_num = nullptr, float scale = 1.0f, bool frag_layout = false);
+  int launch(hipStream_t stream);
+};
+
 int launch_pack_geometry(const float* pts, const float* frames, int64_t n, int f, float* records, hipStream_t stream);
 bool gemm_strip_bf16_applicable(int64_t m, int n, int k);
 int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, uint32_t* c,

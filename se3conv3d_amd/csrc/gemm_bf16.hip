@@ -268,15 +268,21 @@ __global__ __launch_bounds__(256, 4) void gemm_strip_bf16_kernel(const uint32_t*
   // Column order rotated per strip: with a power-of-two row pitch (n * 4 = 8 KB) every wavefront of the chip would
   // otherwise write the same 128-byte column window of its rows at the same time, i.e. all traffic of a moment
   // lands on a handful of L2 / HBM channels.
-  const int n_tiles = (n + 31) / 32;
-  int n0 = (int)(((blockIdx.x * 4 + wave) * (unsigned)SE3_STRIP_ROT) % (unsigned)n_tiles) * 32;
+  // blockIdx.y selects a contiguous range of column tiles (small M: the row strips alone cannot fill the chip)
+  const int n_tiles_all = (n + 31) / 32;
+  const int per = (n_tiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int tile_lo = (int)blockIdx.y * per;
+  const int n_tiles = min(per, n_tiles_all - tile_lo);
+  if (n_tiles <= 0) return;
+  const int n_lo = tile_lo * 32, n_hi = min(n, (tile_lo + n_tiles) * 32);
+  int n0 = n_lo + (int)(((blockIdx.x * 4 + wave) * (unsigned)SE3_STRIP_ROT) % (unsigned)n_tiles) * 32;
   load_b(n0);
   SE3_WAIT_B(0);
   for (int it = 0; it < n_tiles; ++it) {
     f32x16 acc = zero16();
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) acc = mfma_bf16x3(a_hi[ks], a_lo[ks], bh[ks], bl[ks], acc);
-    const int n_next = n0 + 32 < n ? n0 + 32 : 0;
+    const int n_next = n0 + 32 < n_hi ? n0 + 32 : n_lo;
     load_b(n_next);  // in flight during the epilogue below (after the last tile: one unused fetch)
     const int lane_off = (cols_full || n0 + rl < n) ? voff : (int)0x7fffff00;  // columns >= n: dropped
 #pragma unroll
@@ -497,7 +503,7 @@ int gemm_nn_bf16_splits(int64_t m, int n, int k) {
 // Row-strip kernel: packed output, k <= 64, n a multiple of 32, weights prepared with frag_layout and alpha folded in.
 bool gemm_strip_bf16_applicable(int64_t m, int n, int k) {
   const int kp = (k + 31) / 32 * 32;
-  return kp <= 64 && n >= 512 && n % 32 == 0 && n <= (1 << 22) && m >= 128 * 256 &&
+  return kp <= 64 && n >= 512 && n % 32 == 0 && n <= (1 << 22) && m >= 128 * 16 &&
          (m + 128) * (int64_t)k * 4 < (1ll << 32) - 64 && (int64_t)(n + 64) * kp * 2 < (1ll << 32) - 64;
 }
 
@@ -506,7 +512,11 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
   if (m == 0 || n == 0) return SE3_OK;
   if (!gemm_strip_bf16_applicable(m, n, k)) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
-  const dim3 sgrid((unsigned)((m + 127) / 128));
+  const int64_t row_blocks = (m + 127) / 128;
+  int n_split = row_blocks >= 1024 ? 1 : (int)((1024 + row_blocks - 1) / row_blocks);
+  const int n_tiles = n / 32;
+  if (n_split > n_tiles / 4) n_split = n_tiles / 4 > 0 ? n_tiles / 4 : 1;  // >= 4 column tiles per block
+  const dim3 sgrid((unsigned)row_blocks, (unsigned)n_split);
   if ((k + 31) / 32 * 32 == 32)
     hipLaunchKernelGGL(gemm_strip_bf16_kernel<2>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k);
   else
