@@ -15,6 +15,12 @@ namespace se3 {
 
 namespace {
 
+#ifndef SE3_GEMM_ABLATE
+#define SE3_GEMM_ABLATE 0  // diagnostic builds: 1 no MFMA stage, 2 no LDS staging, 4 no barriers
+#endif
+#ifndef SE3_GEMM_DEPTH
+#define SE3_GEMM_DEPTH 4
+#endif
 constexpr int BM = 128, BN = 64, BK = 32;
 constexpr int A_LD = BK + 4;   // words; 144-byte pitch keeps 16-byte alignment and spreads ds_read_b128 over all banks
 constexpr int B_LD = BK + 8;   // bf16;  80-byte pitch, same properties
@@ -75,6 +81,10 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
       t.a1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + rstep, 0, 0));
       t.a2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + 2 * rstep, 0, 0));
       t.a3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + 3 * rstep, 0, 0));
+#if SE3_GEMM_ABLATE & 8
+      t.bh = t.bl = zero4;
+      return;
+#endif
       const uint32_t boff = (uint32_t)((((int64_t)(n0 + (tid >> 2))) * kp + k0 + (tid & 3) * 8) * 2);
       t.bh = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, boff, 0, 0));
       t.bl = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, boff, 0, 0));
@@ -93,7 +103,12 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
     t.bh = ok ? vh : zero4;
     t.bl = ok ? vl : zero4;
   };
+  f32x16 acc0 = zero16(), acc1 = zero16();
   auto store_tile = [&](const Tile& t, int buf) {
+#if SE3_GEMM_ABLATE & 2
+    acc0[0] += __uint_as_float(t.a0[0] ^ t.a1[1] ^ t.a2[2] ^ t.a3[3] ^ t.bh[0] ^ t.bl[1]);
+    return;
+#endif
     const int row = tid >> 3, kq = (tid & 7) * 4;
     *reinterpret_cast<u32x4*>(&as[buf][row][kq]) = t.a0;
     *reinterpret_cast<u32x4*>(&as[buf][row + 32][kq]) = t.a1;
@@ -104,8 +119,10 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
     *reinterpret_cast<u32x4*>(&bsl[buf][nl][kq8]) = t.bl;
   };
 
-  f32x16 acc0 = zero16(), acc1 = zero16();
   auto compute = [&](int buf) {
+#if SE3_GEMM_ABLATE & 1
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int kk = 16 * s + 8 * h;
@@ -121,40 +138,46 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
       acc1 = mfma_bf16x3(a_hi, a_lo, b1h, b1l, acc1);
     }
   };
-  // k-tile kt lives in register set (kt mod 3) until it is written to LDS buffer (kt & 1)
-  Tile t0, t1, t2;
-  load_tile(t0, 0);
-  if (1 < nk) load_tile(t1, 1);
-  if (2 < nk) load_tile(t2, 2);
-  store_tile(t0, 0);
+  // k-tile kt lives in register set (kt mod DEPTH) until it is written to LDS buffer (kt & 1).  The kernel's
+  // occupancy is set by its LDS tiles (2 blocks per CU), which leaves 256 VGPRs per wavefront: they hold DEPTH
+  // tiles in flight.  Measured on MI355X: 3, 4, 6 and 8 tiles give the same time, and so does the kernel with
+  // everything but the A loads removed (SE3_GEMM_ABLATE=15): 0.245 ms for 1.07 GB = 4.4 TB/s, while the same walk
+  // over a buffer that was not just written by the previous kernel reads at 5.8-6.3 TB/s (tools/probes/): the
+  // producer's dirty lines are still draining from L2 / the memory-side cache into HBM while this kernel reads.
+  constexpr int DEPTH = SE3_GEMM_DEPTH;
+  static_assert(DEPTH % 2 == 0, "the LDS buffer parity of a step must be a compile-time constant");
+  Tile t[DEPTH];
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u)
+    if (u < nk) load_tile(t[u], u);
+  store_tile(t[0], 0);
   __syncthreads();
   // steady state without any condition around the loads (conditional loads make the compiler drain
-  // vmcnt(0) every step), then a checked tail of at most 5 k-tiles
-#define SE3_GEMM_STEP_FULL(KT, CUR, NEXT)  \
-  load_tile(CUR, (KT) + 3);                \
-  compute((KT) & 1);                       \
-  store_tile(NEXT, ((KT) & 1) ^ 1);        \
-  __syncthreads();
-#define SE3_GEMM_STEP(KT, CUR, NEXT)                                  \
-  if ((KT) < nk) {                                                    \
-    if ((KT) + 3 < nk) load_tile(CUR, (KT) + 3);                      \
-    compute((KT) & 1);                                                \
-    if ((KT) + 1 < nk) store_tile(NEXT, ((KT) & 1) ^ 1);              \
-    __syncthreads();                                                  \
-  }
+  // vmcnt(0) every step), then a checked tail
   int kt0 = 0;
-  for (; kt0 + 6 <= nk; kt0 += 3) {
-    SE3_GEMM_STEP_FULL(kt0, t0, t1)
-    SE3_GEMM_STEP_FULL(kt0 + 1, t1, t2)
-    SE3_GEMM_STEP_FULL(kt0 + 2, t2, t0)
+  for (; kt0 + 2 * DEPTH <= nk; kt0 += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      load_tile(t[u], kt0 + u + DEPTH);
+      compute(u & 1);
+      store_tile(t[(u + 1) % DEPTH], (u & 1) ^ 1);
+#if !(SE3_GEMM_ABLATE & 4)
+      __syncthreads();
+#endif
+    }
   }
-  for (; kt0 < nk; kt0 += 3) {
-    SE3_GEMM_STEP(kt0, t0, t1)
-    SE3_GEMM_STEP(kt0 + 1, t1, t2)
-    SE3_GEMM_STEP(kt0 + 2, t2, t0)
+  for (; kt0 < nk; kt0 += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const int kt = kt0 + u;
+      if (kt < nk) {
+        if (kt + DEPTH < nk) load_tile(t[u], kt + DEPTH);
+        compute(u & 1);
+        if (kt + 1 < nk) store_tile(t[(u + 1) % DEPTH], (u & 1) ^ 1);
+        __syncthreads();
+      }
+    }
   }
-#undef SE3_GEMM_STEP
-#undef SE3_GEMM_STEP_FULL
 
   const float alpha = OUT_MODE == 2 ? 1.0f : (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
 #pragma unroll
@@ -379,6 +402,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
 
   f32x16 acc0 = zero16(), acc1 = zero16();
   auto compute = [&](int buf) {
+#if SE3_GEMM_ABLATE & 1
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint32_t wa[8], wb0[8], wb1[8];
