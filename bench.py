@@ -94,8 +94,9 @@ def layer_flops(n, e):
     rows = n * FRAMES
     dense = rows * 2 * CH * KB * CH
     edge = ep * (2 * 10 * KB + 2 * CH * KB)
+    pg = ep * (2 * 10 * KB + 2 * CH * KB + 2 * 10 * KB)
     return {"edge_t_fwd": edge, "gemm_out": dense, "gemm_gradT": dense, "gemm_gradW": dense, "gemm_gradX": dense,
-            "edge_t_transposed": edge, "edge_param_grad": ep * (2 * 10 * KB + 2 * CH * KB + 2 * 10 * KB)}
+            "gemm_H": dense, "edge_t_transposed": edge, "edge_param_grad": pg, "edge_bwd": pg + ep * 2 * CH * KB}
 
 
 def stage_bytes(n, e):
@@ -111,7 +112,8 @@ def stage_bytes(n, e):
     return {"edge_t_fwd": edge, "edge_t_transposed": edge, "edge_param_grad": edge,
             "gemm_out": t_bytes + w + 4 * rows * CH, "gemm_gradT": t_bytes + w + 4 * rows * CH,
             "gemm_gradX": t_bytes + w + 4 * rows * CH, "gemm_gradW": t_bytes + 4 * rows * CH + w,
-            "split_pack": 8 * rows * CH}
+            "gemm_H": t_bytes + w + 4 * rows * CH, "edge_bwd": edge + t_bytes,
+            "prep": 3 * 8 * rows * CH + 2 * (48 + 64) * rows + 6 * w}
 
 
 def layer_bytes(n, e):

@@ -68,38 +68,36 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
     float yc[3], rc[9];
     load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + wv), yc, rc);
 
-    auto edge_of = [&](int c0, int& nb, int& q) {
+    // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
+    auto nbr_of = [&](int c0) {
       const int fe = min(c0 + kcol, n_total - 1);
-      int e, fn;
-      if (fnb_shift >= 0) {
-        e = start + (fe >> fnb_shift);
-        fn = fe & ((1 << fnb_shift) - 1);
-      } else {
-        e = start + fe / g.f_nb;
-        fn = fe % g.f_nb;
-      }
-      nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-      q = nb * g.f_nb + fn;
+      const int e = start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+      return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
     };
-    auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-      load_geom_record(nbg_rs, q, xn, rn);
+    auto row_of = [&](int nb, int c0) {
+      const int fe = min(c0 + kcol, n_total - 1);
+      return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
     };
 
     f32x16 acc[2] = {zero16(), zero16()};  // [frame] of U
-    int nb_nx = 0, q_nx = 0;
+    int nb_b = 0, q_a = 0;
     float xn_nx[3], rn_nx[9];
     if (n_total > 0) {
-      edge_of(0, nb_nx, q_nx);
-      geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+      const int nb_a = nbr_of(0);
+      nb_b = nbr_of(32);
       // H fragments (MFMA B operand of gphi) of row (item, wv): lane (k = kcol, h) holds channels 16*st + 8h + j
       const uint32_t* hrow = h_rows + (item * 2 + wv) * (int64_t)C * kBasis;
+      uint32_t hw[4][8];
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hw[st][j] = hrow[(16 * st + 8 * h + j) * kBasis + kcol];
+      q_a = row_of(nb_a, 0);
+      load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        uint32_t w[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = hrow[(16 * st + 8 * h + j) * kBasis + kcol];
         u32x4 f_hi, f_lo;
-        frags_from_words(w, f_hi, f_lo);
+        frags_from_words(hw[st], f_hi, f_lo);
         *reinterpret_cast<u32x4*>(&lds_h[wv][st][0][lane][0]) = f_hi;
         *reinterpret_cast<u32x4*>(&lds_h[wv][st][1][lane][0]) = f_lo;
       }
@@ -108,41 +106,39 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
     for (int c0 = 0; c0 < n_total; c0 += 32, buf ^= 1) {
       const int cnt = min(32, n_total - c0);
       // rows past the end of the edge list read out of bounds (buffer loads return 0): no masks needed below
-      const int qoff = c0 + kcol < n_total ? q_nx * (C * 4) : kOobOffset;
+      const int qoff = c0 + kcol < n_total ? q_a * (C * 4) : kOobOffset;
       float xn[3], rn[9], d[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
 #pragma unroll
       for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-      const bool more = c0 + 32 < n_total;
-      if (more) edge_of(c0 + 32, nb_nx, q_nx);
-      edge_descriptor(yc, rc, xn, rn, rho, d);  // centre is the source side of the edge
+      const int q_b = row_of(nb_b, c0 + 32);
+      nb_b = nbr_of(c0 + 64);
 
-      // gathered grad_out rows, row layout (A operand of gphi): lane (n = kcol, h), 8 channels per k-step
-      u32x4 ra_hi[4], ra_lo[4];
+      // all gathers of the chunk go out now; fragments are built where they are consumed
+      // grad_out rows, row layout (A operand of gphi): lane (n = kcol, h), 8 channels per k-step
+      uint32_t rw[4][8];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         const int voff = qoff + (16 * st + 8 * h) * 4;
         const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(g_rs, voff, 0, 0);
         const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(g_rs, voff + 16, 0, 0);
-        const uint32_t w[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        frags_from_words(w, ra_hi[st], ra_lo[st]);
+        rw[st][0] = v0[0], rw[st][1] = v0[1], rw[st][2] = v0[2], rw[st][3] = v0[3];
+        rw[st][4] = v1[0], rw[st][5] = v1[1], rw[st][6] = v1[2], rw[st][7] = v1[3];
       }
       // the same rows, channel layout (A operand of U): channels 32*wv + kcol of rows acc_row(8s+j, h)
-      u32x4 fa_hi[2], fa_lo[2];
+      uint32_t fw[2][8];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (s * 16 < cnt) {
-          uint32_t w[8];
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
-            w[j] = __builtin_amdgcn_raw_buffer_load_b32(g_rs, src_off + cb4, 0, 0);
-          }
-          frags_from_words(w, fa_hi[s], fa_lo[s]);
+        for (int j = 0; j < 8; ++j) {
+          const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+          fw[s][j] = __builtin_amdgcn_raw_buffer_load_b32(g_rs, src_off + cb4, 0, 0);
         }
-      }
-      if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+      load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      q_a = q_b;
+
+      edge_descriptor(yc, rc, xn, rn, rho, d);  // centre is the source side of the edge
 
       // descriptor image for the d[A;beta] product (both lane halves hold the same descriptor)
       if (h == 0) {
@@ -160,15 +156,9 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      f32x16 gphi = zero16();
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const u32x4 bh_hi = *reinterpret_cast<const u32x4*>(&lds_h[wv][st][0][lane][0]);
-        const u32x4 bh_lo = *reinterpret_cast<const u32x4*>(&lds_h[wv][st][1][lane][0]);
-        gphi = mfma_bf16x3(ra_hi[st], ra_lo[st], bh_hi, bh_lo, gphi);
-      }
-
-      // kernel MLP for this wavefront's frame: half 0 feeds descriptor dims 0..7, half 1 dims 8, 9
+      // kernel MLP, GELU and GELU' for this wavefront's frame (half 0 feeds descriptor dims 0..7, half 1 dims 8, 9);
+      // phi is published for the partner wavefront, GELU' stays in registers
+      float dyv[16];
       {
         float v[8];
 #pragma unroll
@@ -181,22 +171,38 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s * 16 < cnt) {
-            float pv[8], gp[8];
-            uint32_t wd[8];
+            float pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-              f32x2 y, dy;
-              gelu_erf_grad2(f32x2{pre[8 * s + j], pre[8 * s + j + 1]}, y, dy);
-              const f32x2 gy = f32x2{gphi[8 * s + j], gphi[8 * s + j + 1]} * dy;
-              pv[j] = y[0], pv[j + 1] = y[1];
-              gp[j] = gy[0], gp[j + 1] = gy[1];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) wd[j] = lds_desc[wv][acc_row(8 * s + j, h)][jcol];
+            for (int j = 0; j < 8; ++j) gelu_erf_grad(pre[8 * s + j], pv[j], dyv[8 * s + j]);
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);
             *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
             *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
+          }
+        }
+      }
+
+      // gphi = G H on the gathered rows, gpre = gphi * GELU', d[A;beta]^T += gpre^T desc
+      {
+        f32x16 gphi = zero16();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          u32x4 ra_hi, ra_lo;
+          frags_from_words(rw[st], ra_hi, ra_lo);
+          const u32x4 bh_hi = *reinterpret_cast<const u32x4*>(&lds_h[wv][st][0][lane][0]);
+          const u32x4 bh_lo = *reinterpret_cast<const u32x4*>(&lds_h[wv][st][1][lane][0]);
+          gphi = mfma_bf16x3(ra_hi, ra_lo, bh_hi, bh_lo, gphi);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s * 16 < cnt) {
+            float gp[8];
+            uint32_t wd[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              gp[j] = gphi[8 * s + j] * dyv[8 * s + j];
+              wd[j] = lds_desc[wv][acc_row(8 * s + j, h)][jcol];
+            }
             u32x4 ga_hi, ga_lo, db_hi, db_lo;
             frags_from_floats(gp, ga_hi, ga_lo);
             frags_from_words(wd, db_hi, db_lo);
@@ -208,11 +214,13 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s * 16 < cnt) {
+          u32x4 fa_hi, fa_lo;
+          frags_from_words(fw[s], fa_hi, fa_lo);
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
             const u32x4 b_hi = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
             const u32x4 b_lo = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
-            acc[a] = mfma_bf16x3(fa_hi[s], fa_lo[s], b_hi, b_lo, acc[a]);
+            acc[a] = mfma_bf16x3(fa_hi, fa_lo, b_hi, b_lo, acc[a]);
           }
         }
       }

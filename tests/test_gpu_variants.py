@@ -1,0 +1,32 @@
+"""Kernel variants that are selected by environment variables (read once per process) are exercised by
+re-running a slice of the parity suite in a child process with the variable set:
+
+  SE3_BWD_MERGE=1   merged transposed-convolution + parameter-gradient kernel (edge_bwd_bf16.hip)
+  SE3_NO_PAIR=1     single-wavefront edge kernel instead of the wave-pair kernel for C = 64
+  SE3CONV_FUSED=1   fused edge + contraction kernel (fused_bf16.hip)
+
+One child at a time; each child is an ordinary `pytest -m gpu` run over the golden / random-shape / headline
+tests of tests/test_gpu_parity.py.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SLICE = "golden or random_shapes or headline_subset or features_only or empty_rows"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var", ["SE3_BWD_MERGE", "SE3_NO_PAIR", "SE3CONV_FUSED"])
+def test_variant_passes_parity_slice(var):
+    env = dict(os.environ)
+    env[var] = "1"
+    proc = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+         "-k", SLICE, "-p", "no:cacheprovider"],
+        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    tail = (proc.stdout + proc.stderr)[-2000:]
+    assert proc.returncode == 0, f"{var}=1: parity slice failed\n{tail}"
+    assert " passed" in proc.stdout, tail
