@@ -204,6 +204,15 @@ int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_i
  * ------------------------------------------------------------------------------------------- */
 int se3_knn_query(const float* pts, const int32_t* batch_ids, int64_t n, int32_t k, int32_t* out,
                   void* stream);
+/* Same result through a cell grid (the role of the reference's sorted sweep, knn_query.cu:52-128: prune the
+ * candidates, stay exact): cells of size cell_size[0] (device scalar, same value in [0..2]) over the per-batch
+ * boxes aabb_min [B,3] / num_cells [3] (device, as for se3_compute_keys); a query whose k-th candidate inside its
+ * 27 cells is farther than one cell is recomputed by the all-pairs scan, so any cell size gives the exact
+ * answer and a good one (about the expected k-NN distance) gives it ~100x faster on large clouds. */
+size_t se3_knn_query_grid_workspace_bytes(int64_t n);
+int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, const float* aabb_min, const int32_t* num_cells,
+                       const float* cell_size, int64_t n, int32_t k, int32_t* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
 int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, int32_t axis_fixed,
                    float* frames, void* stream);
 

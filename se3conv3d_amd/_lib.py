@@ -54,6 +54,8 @@ SIGNATURES = {
     "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
     "se3conv_bwd": (C.c_int, [_P] * 16 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
     "se3_knn_query": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "se3_knn_query_grid_workspace_bytes": (C.c_size_t, [_I64]),
+    "se3_knn_query_grid": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_size_t, _P]),
     "se3_pca_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_profile_enable": (C.c_int, [C.c_int]),
     "se3_profile_reset": (C.c_int, []),

@@ -258,6 +258,62 @@ int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* f
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream, const float* scale_num = nullptr, float scale = 1.0f,
                         bool frag_layout = false);
+// squared distance of the kNN kernels: one expression for the all-pairs scan and the grid search, so that both
+// order equal-looking candidates identically
+__device__ __forceinline__ float knn_dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
+int launch_knn_bruteforce(const float* pts, const int32_t* batch_ids, int64_t n, int k, int32_t* out,
+                          hipStream_t stream);
+int launch_knn_listed(const float* pts, const int32_t* batch_ids, int64_t n, int k, int32_t* out, const int32_t* list,
+                      const int32_t* list_count, hipStream_t stream);
+
+// The K best (distance, index) pairs of a stream of candidates, ascending in (distance, index) -- the order of the
+// reference's sweep (knn_query.cu:68, strict '<' while scanning ascending indices).  Lists live in registers (K is a
+// power of two, all indices compile-time); lanes that scanned disjoint candidate sets combine their lists with a
+// bitonic merge through shuffles: c[e] = min(a[e], b[K-1-e]) holds the K smallest of both lists as a bitonic
+// sequence, log2(K) compare-exchange stages sort it.
+template <int K>
+struct TopK {
+  float d[K];
+  int i[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int e = 0; e < K; ++e) d[e] = 3.0e38f, i[e] = 0x7fffffff;
+  }
+  static __device__ __forceinline__ bool less(float da, int ia, float db, int ib) {
+    return da < db || (da == db && ia < ib);
+  }
+  __device__ __forceinline__ void cas(int a, int b) {  // afterwards entry a <= entry b
+    const bool sw = less(d[b], i[b], d[a], i[a]);
+    const float dl = sw ? d[b] : d[a], dh = sw ? d[a] : d[b];
+    const int il = sw ? i[b] : i[a], ih = sw ? i[a] : i[b];
+    d[a] = dl, d[b] = dh, i[a] = il, i[b] = ih;
+  }
+  __device__ __forceinline__ void insert(float dd, int jj) {
+    if (!less(dd, jj, d[K - 1], i[K - 1])) return;
+    d[K - 1] = dd, i[K - 1] = jj;
+#pragma unroll
+    for (int e = K - 1; e > 0; --e) cas(e - 1, e);
+  }
+  __device__ __forceinline__ void merge_xor(int mask) {  // both partner lanes end up with the merged list
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+      const float pd = __shfl_xor(d[K - 1 - e], mask);
+      const int pi = __shfl_xor(i[K - 1 - e], mask);
+      tmp_d[e] = pd, tmp_i[e] = pi;
+    }
+#pragma unroll
+    for (int e = 0; e < K; ++e)
+      if (less(tmp_d[e], tmp_i[e], d[e], i[e])) d[e] = tmp_d[e], i[e] = tmp_i[e];
+#pragma unroll
+    for (int s = K / 2; s > 0; s >>= 1)
+#pragma unroll
+      for (int e = 0; e < K; ++e)
+        if ((e & s) == 0) cas(e, e + s);
+  }
+  float tmp_d[K];
+  int tmp_i[K];
+};
+
 // Batched operand preparation (prep.hip): collect the jobs of one call, launch them as one kernel.
 struct PrepJob {
   int type, blocks;

@@ -81,8 +81,7 @@ __global__ __launch_bounds__(kKnnQueries* kKnnSlices) void knn_kernel(const floa
 #pragma unroll 4
     for (int c = 0; c < cnt; ++c) {
       const float4 p = tile[wave][c];
-      const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-      const float d = dx * dx + dy * dy + dz * dz;
+      const float d = knn_dist2(p.x - qx, p.y - qy, p.z - qz);
       if (d < best_d[K - 1] && __float_as_int(p.w) == qb) insert(d, (int)(t0 + c));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -234,18 +233,97 @@ __global__ void pca_frames_kernel(const float* __restrict__ pts, const int32_t* 
 
 using namespace se3;
 
+namespace se3 {
+namespace {
+// One 1024-thread block per listed query: the threads stride over the points of the query's batch element, each
+// keeps its K best in registers; six bitonic shuffle merges per wavefront, then the 16 wavefront lists meet in LDS
+// and four more merges finish.  Exact fallback behind the grid search (se3_knn_query_grid) for the few queries
+// its 27 cells could not settle (typically a few dozen: a single wavefront per query spent ~1 ms in load latency).
+constexpr int kListedWaves = 16;
+template <int K>
+__global__ __launch_bounds__(64 * kListedWaves) void knn_listed_kernel(const float* __restrict__ pts,
+                                                                       const int32_t* __restrict__ batch_ids,
+                                                                       int64_t n, int k_out, int32_t* __restrict__ out,
+                                                                       const int32_t* __restrict__ list,
+                                                                       const int32_t* __restrict__ list_count) {
+  __shared__ float w_d[kListedWaves][K];
+  __shared__ int w_i[kListedWaves][K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_q = *list_count;
+  for (int64_t qi = blockIdx.x; qi < n_q; qi += gridDim.x) {
+    const int64_t i = list[qi];
+    const float qx = pts[i * 3], qy = pts[i * 3 + 1], qz = pts[i * 3 + 2];
+    const int qb = batch_ids[i];
+    int64_t lo = 0, hi = i;  // batch ids are sorted: [first, last] point of the query's batch element
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] < qb) lo = mid + 1; else hi = mid; }
+    const int64_t first = lo;
+    lo = i, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] <= qb) lo = mid + 1; else hi = mid; }
+    const int64_t end = lo;
+    TopK<K> best;
+    best.init();
+    constexpr int kStride = 64 * kListedWaves;
+    int64_t j = first + threadIdx.x;
+    for (; j + kStride < end; j += 2 * kStride) {  // two independent loads per trip
+      const int64_t j2 = j + kStride;
+      const float ax = pts[j * 3], ay = pts[j * 3 + 1], az = pts[j * 3 + 2];
+      const float bx = pts[j2 * 3], by = pts[j2 * 3 + 1], bz = pts[j2 * 3 + 2];
+      best.insert(knn_dist2(ax - qx, ay - qy, az - qz), (int)j);
+      best.insert(knn_dist2(bx - qx, by - qy, bz - qz), (int)j2);
+    }
+    if (j < end) best.insert(knn_dist2(pts[j * 3] - qx, pts[j * 3 + 1] - qy, pts[j * 3 + 2] - qz), (int)j);
+#pragma unroll 1
+    for (int m = 1; m < 64; m <<= 1) best.merge_xor(m);  // runtime mask: one copy of the merge network
+    __syncthreads();  // previous query's LDS lists are consumed
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < K; ++e) w_d[wave][e] = best.d[e], w_i[wave][e] = best.i[e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      best.init();
+      if (lane < kListedWaves) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) best.d[e] = w_d[lane][e], best.i[e] = w_i[lane][e];
+      }
+#pragma unroll 1
+      for (int m = 1; m < kListedWaves; m <<= 1) best.merge_xor(m);
+      if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < K; ++e)
+          if (e < k_out) out[i * k_out + e] = best.i[e] == 0x7fffffff ? -1 : best.i[e];
+      }
+    }
+  }
+}
+}  // namespace
+
+int launch_knn_bruteforce(const float* pts, const int32_t* batch_ids, int64_t n, int k, int32_t* out, hipStream_t s) {
+  const dim3 grid((unsigned)((n + kKnnQueries - 1) / kKnnQueries)), block(kKnnQueries * kKnnSlices);
+  if (k <= 8) hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, pts, batch_ids, n, k, out);
+  else if (k <= 16) hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, s, pts, batch_ids, n, k, out);
+  else hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, pts, batch_ids, n, k, out);
+  return check_launch();
+}
+
+int launch_knn_listed(const float* pts, const int32_t* batch_ids, int64_t n, int k, int32_t* out, const int32_t* list,
+                      const int32_t* list_count, hipStream_t s) {
+  // the list length lives on the device: a fixed grid of blocks strides over it
+  const dim3 grid((unsigned)(n < 512 ? (n > 0 ? n : 1) : 512)), block(64 * kListedWaves);
+  if (k <= 8) hipLaunchKernelGGL(knn_listed_kernel<8>, grid, block, 0, s, pts, batch_ids, n, k, out, list, list_count);
+  else if (k <= 16) hipLaunchKernelGGL(knn_listed_kernel<16>, grid, block, 0, s, pts, batch_ids, n, k, out, list, list_count);
+  else hipLaunchKernelGGL(knn_listed_kernel<32>, grid, block, 0, s, pts, batch_ids, n, k, out, list, list_count);
+  return check_launch();
+}
+}  // namespace se3
+
 extern "C" int se3_knn_query(const float* pts, const int32_t* batch_ids, int64_t n, int32_t k, int32_t* out,
                              void* stream) {
   if (n < 0 || k < 1) return SE3_ERR_INVALID_ARGUMENT;
   if (k > 32 || n >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
   if (n == 0) return SE3_OK;
   if (!pts || !batch_ids || !out) return SE3_ERR_INVALID_ARGUMENT;
-  const dim3 grid((unsigned)((n + kKnnQueries - 1) / kKnnQueries)), block(kKnnQueries * kKnnSlices);
-  hipStream_t s = (hipStream_t)stream;
-  if (k <= 8) hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, pts, batch_ids, n, (int)k, out);
-  else if (k <= 16) hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, s, pts, batch_ids, n, (int)k, out);
-  else hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, pts, batch_ids, n, (int)k, out);
-  return check_launch();
+  return launch_knn_bruteforce(pts, batch_ids, n, (int)k, out, (hipStream_t)stream);
 }
 
 extern "C" int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, int32_t axis_fixed,

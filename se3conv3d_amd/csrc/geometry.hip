@@ -218,6 +218,106 @@ inline unsigned blocks_for(int64_t n, int per = 256) {
   return (unsigned)b;
 }
 
+// ---- exact kNN through the cell grid (scope row f-1) -------------------------------------------------------
+// One thread per query, taken in cell order (neighbouring threads walk the same candidates).  The 3x3x3 block of
+// cells around the query covers every point closer than one cell size c, so the k best of the block are the true
+// k nearest iff the k-th of them is closer than c; otherwise the query goes on a list that the all-pairs
+// kernel recomputes (launch_knn_bruteforce).  Order: ascending (distance, index), as the all-pairs kernel and the reference's
+// sweep (knn_query.cu:68) produce.
+constexpr int kKnnGroup = 4;  // lanes that share one query
+template <int K>
+__global__ __launch_bounds__(256) void knn_grid_kernel(const float4* __restrict__ spts,
+                                                       const int64_t* __restrict__ skeys,
+                                                       const int32_t* __restrict__ num_cells,
+                                                       const float* __restrict__ cell_size, int n, int k_out,
+                                                       int32_t* __restrict__ out, int32_t* __restrict__ list,
+                                                       int32_t* __restrict__ list_count) {
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = gtid & (kKnnGroup - 1);
+  const int t = min(gtid / kKnnGroup, n - 1);  // whole groups stay together (shuffles below); extras repeat the last query
+  const bool writer = g == 0 && gtid / kKnnGroup < n;
+  const int nc[3] = {num_cells[0], num_cells[1], num_cells[2]};
+  const float4 q = spts[t];
+  const int qid = __float_as_int(q.w);
+  int64_t key = skeys[t];
+  const int iz = (int)(key % nc[2]);
+  key /= nc[2];
+  const int iy = (int)(key % nc[1]);
+  key /= nc[1];
+  const int ix = (int)(key % nc[0]);
+  const int64_t b = key / nc[0];
+  // the 9 (x, y) pencils of the 27-cell block: lane g looks up pencils g, g+4, g+8, the group shares the ranges
+  int my_lo[3], my_hi[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int o = g + kKnnGroup * u;
+    my_lo[u] = my_hi[u] = 0;
+    const int x = ix + o / 3 - 1, y = iy + o % 3 - 1;
+    if (o < 9 && x >= 0 && x < nc[0] && y >= 0 && y < nc[1]) {
+      const int z0 = max(iz - 1, 0), z1 = min(iz + 1, nc[2] - 1);
+      const int64_t base = ((b * nc[0] + x) * nc[1] + y) * nc[2];
+      my_lo[u] = lower_bound_key(skeys, n, base + z0);
+      my_hi[u] = lower_bound_key(skeys, n, base + z1 + 1);
+    }
+  }
+  TopK<K> best;
+  best.init();
+  int found = 0;
+  const int lane = threadIdx.x & 63, lane0 = lane & ~(kKnnGroup - 1);
+#pragma unroll
+  for (int o = 0; o < 9; ++o) {
+    const int src = lane0 + o % kKnnGroup;
+    const int lo = __shfl(o / kKnnGroup == 0 ? my_lo[0] : (o / kKnnGroup == 1 ? my_lo[1] : my_lo[2]), src);
+    const int hi = __shfl(o / kKnnGroup == 0 ? my_hi[0] : (o / kKnnGroup == 1 ? my_hi[1] : my_hi[2]), src);
+    found += hi - lo;
+    for (int pos = lo + g; pos < hi; pos += kKnnGroup) {
+      const float4 p = spts[pos];
+      best.insert(knn_dist2(p.x - q.x, p.y - q.y, p.z - q.z), __float_as_int(p.w));
+    }
+  }
+  best.merge_xor(1);
+  best.merge_xor(2);
+  const float c = cell_size[0] * 0.999f;  // margin for the rounding of the cell assignment
+  float kth = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < K; ++e)
+    if (e == k_out - 1) kth = best.d[e];
+  const bool ok = found >= k_out && kth < c * c;
+  if (writer) {
+    if (!ok) list[atomicAdd(list_count, 1)] = qid;  // order of the list does not matter: each entry is recomputed alone
+    if (ok) {
+#pragma unroll
+      for (int e = 0; e < K; ++e)
+        if (e < k_out) out[(int64_t)qid * k_out + e] = best.i[e];
+    }
+  }
+}
+
+struct KnnLayout {
+  size_t keys, skeys, ids, sids, spts, list, count, temp, temp_bytes, total;
+};
+
+KnnLayout knn_layout(int64_t n) {
+  KnnLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t ns = (size_t)(n > 0 ? n : 1);
+  l.keys = take(ns * 8);
+  l.skeys = take(ns * 8);
+  l.ids = take(ns * 4);
+  l.sids = take(ns * 4);
+  l.spts = take(ns * 16);
+  l.list = take(ns * 4);
+  l.count = take(4);
+  size_t t_sort = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (const int64_t*)nullptr, (int64_t*)nullptr,
+                                           (const int32_t*)nullptr, (int32_t*)nullptr, (int)ns);
+  l.temp_bytes = t_sort;
+  l.temp = take(l.temp_bytes);
+  l.total = off;
+  return l;
+}
+
 struct BqLayout {
   size_t keys, skeys, ids, sids, spts, ranges, counts, temp, temp_bytes, total;
 };
@@ -275,6 +375,53 @@ extern "C" int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_
                        aabb_max);
   }
   return check_launch();
+}
+
+extern "C" size_t se3_knn_query_grid_workspace_bytes(int64_t n) { return knn_layout(n).total; }
+
+extern "C" int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, const float* aabb_min,
+                                  const int32_t* num_cells, const float* cell_size, int64_t n, int32_t k, int32_t* out,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  if (n < 0 || k < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (k > 32 || n >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  if (n == 0) return SE3_OK;
+  if (!pts || !batch_ids || !aabb_min || !num_cells || !cell_size || !out || !workspace) return SE3_ERR_INVALID_ARGUMENT;
+  const KnnLayout l = knn_layout(n);
+  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  int64_t* keys = (int64_t*)(ws + l.keys);
+  int64_t* skeys = (int64_t*)(ws + l.skeys);
+  int32_t* ids = (int32_t*)(ws + l.ids);
+  int32_t* sids = (int32_t*)(ws + l.sids);
+  float4* spts = (float4*)(ws + l.spts);
+  int32_t* list = (int32_t*)(ws + l.list);
+  int32_t* list_count = (int32_t*)(ws + l.count);
+  size_t temp_bytes = l.temp_bytes;
+  if (hipMemsetAsync(list_count, 0, 4, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+  {
+    ProfScope prof("knn_sort", stream);
+    hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, pts, batch_ids, aabb_min, num_cells,
+                       cell_size, 0.f, n, keys, ids);
+    if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n, 0, 64, stream) !=
+        hipSuccess)
+      return SE3_ERR_LAUNCH;
+    hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, pts, sids, n, spts);
+  }
+  {
+    ProfScope prof("knn_cells", stream);
+    const dim3 grid((unsigned)((n * kKnnGroup + 255) / 256));
+    if (k <= 8)
+      hipLaunchKernelGGL(knn_grid_kernel<8>, grid, dim3(256), 0, stream, spts, skeys, num_cells, cell_size, (int)n, (int)k, out, list, list_count);
+    else if (k <= 16)
+      hipLaunchKernelGGL(knn_grid_kernel<16>, grid, dim3(256), 0, stream, spts, skeys, num_cells, cell_size, (int)n, (int)k, out, list, list_count);
+    else
+      hipLaunchKernelGGL(knn_grid_kernel<32>, grid, dim3(256), 0, stream, spts, skeys, num_cells, cell_size, (int)n, (int)k, out, list, list_count);
+    if (int rc = check_launch()) return rc;
+  }
+  ProfScope prof("knn_fallback", stream);
+  // exact fallback for the queries the 27-cell block could not settle (sparse regions, cloud boundary)
+  return launch_knn_listed(pts, batch_ids, n, (int)k, out, list, list_count, stream);
 }
 
 extern "C" size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst) {

@@ -195,17 +195,53 @@ def csr_transpose(neighbors_i32: torch.Tensor, n_src: int) -> Tuple[torch.Tensor
 
 
 # ------------------------------------------------------------------------------- frames (row f-1)
-def knn_query(pts, batch_ids, k: int) -> torch.Tensor:
+KNN_GRID_MIN_POINTS = 8192  # below this the all-pairs scan is as fast as sorting into cells
+KNN_CELL_FACTOR = 1.6       # cell size / estimated k-NN distance (1.26 covers points on a face of the cloud)
+
+
+def _knn_cell_size(mn, mx, counts, k: int) -> torch.Tensor:
+    """Cell size (device scalar): KNN_CELL_FACTOR x the k-NN distance a uniformly filled box of each batch element's extent
+    would have -- the larger of the volume, area and length estimates, so flat and thin clouds are covered too.
+    Only a speed knob: se3_knn_query_grid is exact for any cell size."""
+    ext = (mx - mn).clamp_min(0).sort(dim=1, descending=True)[0]
+    cnt = counts.clamp_min(1).to(torch.float32)
+    e1, e2, e3 = ext[:, 0], ext[:, 1], ext[:, 2]
+    c_vol = (k * e1 * e2 * e3 / (4.19 * cnt)).pow(1.0 / 3.0)
+    c_area = (k * e1 * e2 / (3.14 * cnt)).sqrt()
+    c_len = k * e1 / (2.0 * cnt)
+    c = KNN_CELL_FACTOR * torch.stack([c_vol, c_area, c_len]).max()
+    return torch.maximum(c, (e1.max() * 1e-6).clamp_min(1e-30))
+
+
+def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: str = "auto") -> torch.Tensor:
     """``point_cloud_lib_ops.knn_query``: self-kNN inside each batch element, ``[N,k]`` int32 (self first,
-    ascending distance, -1 padded)."""
+    ascending distance, ties to the lower index, -1 padded).  ``method``: "grid" (cell grid + exact fallback),
+    "scan" (all pairs inside the batch element) or "auto" (grid from KNN_GRID_MIN_POINTS points on)."""
     lib = _lib.load()
     pts = _as(pts, torch.float32)
     b = _as(batch_ids, torch.int32)
     if pts.dim() != 2 or pts.shape[1] != 3:
         raise ValueError("knn_query: only [N,3] point sets are supported")
-    out = torch.empty((pts.shape[0], int(k)), dtype=torch.int32, device=pts.device)
-    _lib.check(lib.se3_knn_query(_ptr(pts, torch.float32, "pts"), _ptr(b, torch.int32, "batch_ids", pts.device),
-                                 pts.shape[0], int(k), _ptr(out, torch.int32, "out"), _stream()), "se3_knn_query")
+    if method not in ("auto", "grid", "scan"):
+        raise ValueError(f"knn_query: unknown method {method!r}")
+    n, dev = pts.shape[0], pts.device
+    out = torch.empty((n, int(k)), dtype=torch.int32, device=dev)
+    f32, i32 = torch.float32, torch.int32
+    if method == "scan" or (method == "auto" and n < KNN_GRID_MIN_POINTS) or n == 0:
+        _lib.check(lib.se3_knn_query(_ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), n, int(k),
+                                     _ptr(out, i32, "out"), _stream()), "se3_knn_query")
+        return out
+    mn, mx = batch_aabb(pts, b, n_batches)
+    counts = torch.bincount(b.to(torch.int64), minlength=mn.shape[0])
+    cell = _knn_cell_size(mn, mx, counts, int(k))
+    mn = (mn - 1e-6).contiguous()
+    num_cells = (((mx - mn) / cell).clamp_max(2.0 ** 20).to(i32) + 1).max(dim=0)[0].to(i32).contiguous()
+    cell3 = cell.to(f32).reshape(1).expand(3).contiguous()
+    ws = _workspace(lib.se3_knn_query_grid_workspace_bytes(n), dev)
+    _lib.check(lib.se3_knn_query_grid(
+        _ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), _ptr(mn, f32, "aabb_min"), _ptr(num_cells, i32, "num_cells"),
+        _ptr(cell3, f32, "cell_size"), n, int(k), _ptr(out, i32, "out"), C.c_void_p(ws.data_ptr()), ws.numel(),
+        _stream()), "se3_knn_query_grid")
     return out
 
 

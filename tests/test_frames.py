@@ -69,6 +69,43 @@ def test_gpu_knn_matches_oracle(built_library):
 
 
 @pytest.mark.gpu
+def test_gpu_knn_grid_equals_scan(built_library):
+    """The cell-grid search must return exactly what the all-pairs scan returns (same order, same ties, same -1
+    padding), whatever the cloud looks like: the cell size is only a speed knob."""
+    import se3conv3d_amd as amd
+
+    g = torch.Generator().manual_seed(11)
+    clouds = {}
+    clouds["cube"] = (torch.rand(20000, 3, generator=g), torch.zeros(20000, dtype=torch.int32))
+    v = torch.randn(15000, 3, generator=g)
+    clouds["sphere_shell"] = (v / v.norm(dim=1, keepdim=True), torch.zeros(15000, dtype=torch.int32))
+    flat = torch.rand(12000, 3, generator=g)
+    flat[:, 2] = 0.25
+    clouds["plane"] = (flat, torch.zeros(12000, dtype=torch.int32))
+    line = torch.zeros(9000, 3)
+    line[:, 0] = torch.rand(9000, generator=g)
+    clouds["line"] = (line, torch.zeros(9000, dtype=torch.int32))
+    # batch elements of very different size and density, the last one smaller than k
+    sizes = [9000, 300, 4000, 7]
+    pts = torch.cat([torch.rand(m, 3, generator=g) * (1.0 + 3.0 * i) for i, m in enumerate(sizes)])
+    bid = torch.cat([torch.full((m,), i, dtype=torch.int32) for i, m in enumerate(sizes)])
+    clouds["ragged_batches"] = (pts, bid)
+    dup = torch.rand(5000, 3, generator=g)
+    dup = torch.cat([dup, dup[:3000]])  # exact duplicates: ties at distance 0 and beyond
+    clouds["duplicates"] = (dup, torch.zeros(8000, dtype=torch.int32))
+    clumps = torch.cat([torch.rand(50, 3, generator=g) * 100.0,  # sparse far-away points force the fallback
+                        torch.rand(9000, 3, generator=g) * 0.01])
+    clouds["clumped"] = (clumps, torch.zeros(9050, dtype=torch.int32))
+    for name, (p, b) in clouds.items():
+        for k in (8, 16):
+            scan = amd.ops.knn_query(p.to(DEV), b.to(DEV), k, method="scan")
+            grid = amd.ops.knn_query(p.to(DEV), b.to(DEV), k, method="grid")
+            assert torch.equal(scan, grid), f"{name}, k={k}: {int((scan != grid).any(dim=1).sum())} rows differ"
+    ref = O.knn_query(clouds["ragged_batches"][0], clouds["ragged_batches"][1], 16)
+    assert torch.equal(amd.ops.knn_query(pts.to(DEV), bid.to(DEV), 16, method="grid").cpu(), ref)
+
+
+@pytest.mark.gpu
 def test_gpu_pca_frames_match_reference_fixture(built_library):
     import se3conv3d_amd as amd
 
