@@ -41,7 +41,7 @@ __global__ void permute_weights_oki_kernel(const float* __restrict__ w, float* _
 // one block per output element: 256 threads stride over the per-block partials, then tree-reduce
 __global__ __launch_bounds__(256) void reduce_param_partials_kernel(const float* __restrict__ partials, int n_partials,
                                                                     float* __restrict__ grad_axes,
-                                                                    float* __restrict__ grad_biases) {
+                                                                    float* __restrict__ grad_biases, float scale) {
   __shared__ float red[256];
   const int i = blockIdx.x;
   float s = 0.f;
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void reduce_param_partials_kernel(const float*
   }
   if (threadIdx.x == 0) {
     if (i < SE3_DESC_DIMS * kBasis) {
-      if (grad_axes) grad_axes[i] = red[0];
+      if (grad_axes) grad_axes[i] = red[0] * scale;
     } else if (grad_biases) {
-      grad_biases[i - SE3_DESC_DIMS * kBasis] = red[0];
+      grad_biases[i - SE3_DESC_DIMS * kBasis] = red[0] * scale;
     }
   }
 }
@@ -415,6 +415,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   uint32_t* featpk = (uint32_t*)(ws + l.featpk);
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
+  const float inv_phi = inv_fin / kGeluOut;  // the bf16 edge kernels produce kGeluOut * phi (gelu_scaled)
   {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
@@ -429,10 +430,10 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   }
   if (conv_fused_bf16_supported(g, s->c_in))  // edge phase + contraction in one launch; T only if the caller wants it
     return launch_conv_fused_bf16("conv_fused_fwd", g, featpk, s->n_in * s->f_in, axes_ext, rho, bt_hi, bt_lo, s->c_out,
-                                  out, (uint32_t*)t_save, nu, inv_fin, stream);
+                                  out, (uint32_t*)t_save, nu, inv_phi, stream);
   if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream)) return rc;
   return launch_gemm_nn_bf16("gemm_out", (const uint32_t*)t, bt_hi, bt_lo, out, false, rows_out, s->c_out, ck,
-                             (float*)(ws + l.split), nu, inv_fin, stream);
+                             (float*)(ws + l.split), nu, inv_phi, stream);
 }
 
 extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
@@ -490,7 +491,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                                             l.n_param_partials, stream))
           return rc;
         hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
-                           l.n_param_partials, grad_axes, grad_biases);
+                           l.n_param_partials, grad_axes, grad_biases, 1.0f);
       }
       if (grad_weights) {
         const float* t = t_save;
@@ -526,6 +527,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   uint32_t* gpk = (uint32_t*)(ws + l.gpk);
   uint32_t* featpk = (uint32_t*)(ws + l.featpk);
   uint32_t* bigw = (uint32_t*)big;
+  const float inv_phi = inv_fin / kGeluOut;  // T and U hold kGeluOut * (the reference's values), see gelu_scaled
   const bool feat_branch = want_feat && rows_in > 0;
   const bool merged = feat_branch && want_params && (grad_axes || grad_biases) && rows_out > 0 && l.big_u != 0 &&
                       edge_bwd_pair_bf16_supported(s->f_in, s->c_out);
@@ -559,7 +561,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       t = tt;
     }
     return launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck, s->c_out, nu,
-                               inv_fin, stream);
+                               inv_phi, stream);
   };
 
   // Opt-in (SE3_BWD_MERGE): one walk over the transposed graph yields U (feature gradient) and d[A;beta]; grad_T and
@@ -578,9 +580,9 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                                            stream))
       return rc;
     hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
-                       grad_axes, grad_biases);
+                       grad_axes, grad_biases, 0.5f);  // the kernels accumulate with 2 GELU' (gelu_scaled_grad)
     if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
-                                     (float*)(ws + l.split), nu, inv_fin, stream))
+                                     (float*)(ws + l.split), nu, inv_phi, stream))
       return rc;
     if (int rc = weight_gradient()) return rc;
     return check_launch();
@@ -603,12 +605,12 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     }
     if (conv_fused_bf16_supported(gt, s->c_out)) {
       if (int rc = launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, bx_hi, bx_lo, s->c_in, grad_feat,
-                                          nullptr, nu, inv_fin, fs))
+                                          nullptr, nu, inv_phi, fs))
         return rc;
     } else {
       if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs)) return rc;
       if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
-                                       fsplit, nu, inv_fin, fs))
+                                       fsplit, nu, inv_phi, fs))
         return rc;
     }
   }
@@ -624,7 +626,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                                                l.n_param_partials, stream))
         return rc;
       hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
-                         l.n_param_partials, grad_axes, grad_biases);
+                         l.n_param_partials, grad_axes, grad_biases, 0.5f);  // 2 GELU' in the kernel (gelu_scaled_grad)
     }
     if (int rc = weight_gradient()) return rc;
   }

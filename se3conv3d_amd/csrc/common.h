@@ -126,6 +126,34 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaf(a, hq, 0.5f * x);  // == x * (0.5 + s hq), without needing s
 }
 
+// Scaled form used by the split-bf16 edge kernels.  The kernel MLP hands over x' = kGeluIn * x (the factor is folded
+// into [A; beta] when the weights are staged), so exp(-x^2/2) = exp2(-x'^2) needs no constant multiply; the result
+// is y'' = kGeluOut * GELU(x) = |x'| (1 - 2q) + x', which needs no 0.5 x either (kGeluOut is divided out in the
+// alpha of the GEMM that consumes T / U).  dy2 = 2 GELU'(x).  14 / 18 issue slots per value instead of 16 / 20.
+constexpr float kGeluIn = 0.84932180028801904272f;   // sqrt(0.5 * log2(e))
+constexpr float kGeluOut = 2.0f * kGeluIn;
+__device__ __forceinline__ void gelu_scaled_core(float xp, float& a, float& e, float& hq2) {
+  a = fabsf(xp);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f / kGeluIn, a, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  e = __builtin_amdgcn_exp2f(-(xp * xp));  // exp(-x^2/2)
+  hq2 = fmaf(-(p * t), e, 1.0f);           // 1 - 2 Phi(-|x|)
+}
+__device__ __forceinline__ float gelu_scaled(float xp) {
+  float a, e, hq2;
+  gelu_scaled_core(xp, a, e, hq2);
+  return fmaf(a, hq2, xp);
+}
+__device__ __forceinline__ void gelu_scaled_grad(float xp, float& y2, float& dy2) {
+  float a, e, hq2;
+  gelu_scaled_core(xp, a, e, hq2);
+  y2 = fmaf(a, hq2, xp);
+  dy2 = fmaf(__builtin_copysignf(1.0f, xp), fmaf(a * e, 0.79788456080286535588f / kGeluIn, hq2), 1.0f);
+}
+
 // Pairwise entry points used by the bf16 edge kernels.  SE3_GELU_PK=1 builds evaluate the pair on the packed
 // fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32); the default evaluates the two values with scalar VALU ops.
 #ifndef SE3_GELU_PK

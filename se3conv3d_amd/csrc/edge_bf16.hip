@@ -53,7 +53,7 @@ __device__ __forceinline__ void load_mlp_weights(const float* __restrict__ axes_
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = 8 * h + j;
-    v[j] = k < kDescExt ? axes_ext[k * kBasis + kcol] : 0.f;
+    v[j] = k < kDescExt ? kGeluIn * axes_ext[k * kBasis + kcol] : 0.f;  // kGeluIn * pre, see gelu_scaled
   }
   frags_from_floats(v, b_hi, b_lo);
 }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(E
         if (s * 16 < cnt) {
           float pv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pv[j] = gelu_erf(phi[8 * s + j]);
+          for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
           u32x4 b_hi, b_lo;
           frags_from_floats(pv, b_hi, b_lo);
           *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
       for (int r = 0; r < 16; ++r) {
         const int n = acc_row(r, h);
         float y, dy;
-        gelu_erf_grad(pre[r], y, dy);
+        gelu_scaled_grad(pre[r], y, dy);  // dy = 2 GELU': the factor 0.5 is applied where the partials are reduced
         const float gp = n < cnt ? gphi[r] * dy : 0.f;
         const float4* src = reinterpret_cast<const float4*>(&lds_desc[wave][n][0]);
         const float4 d0 = src[0], d1 = src[1];
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float y;
-          gelu_erf_grad(pre[r], y, dyv[a][r]);
+          gelu_scaled_grad(pre[r], y, dyv[a][r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
         }
       }
       // ... then gphi = F gT on the gathered rows, gpre = gphi * GELU', and the d[A;beta] product

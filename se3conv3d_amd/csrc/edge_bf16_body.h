@@ -46,8 +46,8 @@ __device__ __forceinline__ void mlp_weights_to_lds(uint32_t (*lds_w)[2][64][4], 
   float v07[8], v89[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    v07[j] = axes_ext[j * kBasis + kcol];
-    v89[j] = j < 2 ? axes_ext[(8 + j) * kBasis + kcol] : 0.f;
+    v07[j] = kGeluIn * axes_ext[j * kBasis + kcol];  // the MLP delivers kGeluIn * pre (gelu_scaled)
+    v89[j] = j < 2 ? kGeluIn * axes_ext[(8 + j) * kBasis + kcol] : 0.f;
   }
 #pragma unroll
   for (int a = 0; a < FC; ++a) {
@@ -215,7 +215,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 #if SE3_ABLATE_MASK & 1
               float y = phi[8 * s + j];
 #else
-              float y = gelu_erf(phi[8 * s + j]);
+              float y = gelu_scaled(phi[8 * s + j]);
 #endif
               pv[j] = y;
             }
@@ -410,7 +410,7 @@ __device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdg
             float pv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              pv[j] = gelu_erf(phi[8 * s + j]);
+              pv[j] = gelu_scaled(phi[8 * s + j]);
             }
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(128, 2) void edge_bwd_pair_bf16_kernel(EdgeGeom g, 
           if (s * 16 < cnt) {
             float pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) gelu_erf_grad(pre[8 * s + j], pv[j], dyv[8 * s + j]);
+            for (int j = 0; j < 8; ++j) gelu_scaled_grad(pre[8 * s + j], pv[j], dyv[8 * s + j]);
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);
             *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
