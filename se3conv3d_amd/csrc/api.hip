@@ -267,7 +267,8 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
   if (fast && edge_bwd_pair_bf16_blocks((int64_t)rows_in / 2) > l.n_param_partials)
     l.n_param_partials = edge_bwd_pair_bf16_blocks((int64_t)rows_in / 2);
-  l.param_partials = want_params ? take((size_t)l.n_param_partials * kDescExt * kBasis * 4) : 0;
+  l.param_partials = want_params ? take((size_t)l.n_param_partials * edge_param_grad_bf16_channel_blocks(s->c_in) *
+                                         kDescExt * kBasis * 4) : 0;
   l.tn_splits = gemm_tn_splits((int64_t)rows_out, s->c_in * (int)kb, s->c_out);
   l.tn_partials = want_params ? take((size_t)l.tn_splits * wsz) : 0;
   l.total = off;
@@ -622,11 +623,12 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       return rc;
     }
     if (grad_axes || grad_biases) {
+      int n_part = 0;
       if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
-                                               l.n_param_partials, stream))
+                                               l.n_param_partials, &n_part, stream))
         return rc;
-      hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
-                         l.n_param_partials, grad_axes, grad_biases, 0.5f);  // 2 GELU' in the kernel (gelu_scaled_grad)
+      hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
+                         grad_axes, grad_biases, 0.5f);  // 2 GELU' in the kernel (gelu_scaled_grad)
     }
     if (int rc = weight_gradient()) return rc;
   }

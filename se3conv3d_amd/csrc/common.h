@@ -270,9 +270,10 @@ int launch_reduce_partials(const float* partials, float* out, int64_t count, int
 int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream);
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream);
+int edge_param_grad_bf16_channel_blocks(int channels);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
-                                float* partials, int n_partials, hipStream_t stream);
+                                float* partials, int n_partials, int* n_used, hipStream_t stream);
 bool conv_fused_bf16_supported(const EdgeGeom& g, int gathered_channels);
 bool edge_bwd_pair_bf16_supported(int f_ctr, int gathered_channels);
 int edge_bwd_pair_bf16_blocks(int64_t items);

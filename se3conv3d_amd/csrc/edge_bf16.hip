@@ -100,22 +100,22 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 }
 
 // ------------------------------------------------------------------------------------------------
-// Wave-pair variant for 64 channels and two frames: the two output rows of an item are produced by a
-// 128-thread workgroup.  Wavefront v builds the descriptors, kernel MLP, GELU and hi/lo split for frame
-// a0+v only and publishes those B fragments through LDS (double buffered, one barrier per chunk); it then
-// aggregates channels 32v..32v+31 for BOTH frames.  No value is computed twice, and each wavefront
-// carries 32 accumulator registers instead of 64, which is what lets 3-4 wavefronts share a SIMD (the
-// single-wavefront kernel needs ~240 VGPRs: 2 per SIMD, 44 % of their life parked in s_waitcnt).
+// Wave-pair variant (two frames, C >= 64): the two output rows of an item are produced by a 128-thread
+// workgroup.  Wavefront v builds the descriptors, kernel MLP, GELU and hi/lo split for frame a0+v only and
+// publishes those B fragments through LDS (double buffered, one barrier per chunk); it then aggregates CT
+// tiles of 32 channels for BOTH frames.  No value is computed twice, and each wavefront carries 32*CT
+// accumulator registers, which is what lets 3-4 wavefronts share a SIMD (the single-wavefront kernel needs
+// ~240 VGPRs: 2 per SIMD, 44 % of their life parked in s_waitcnt).  CT = 1: 64 channels per pass (128 VGPRs,
+// 4 waves/SIMD); CT = 2: 128 channels per pass.  Wider rows take several passes, each recomputing phi (the MFMA
+// work per pass grows with CT, the GELU work does not).  FULL: C is a multiple of 64*CT.
 // ------------------------------------------------------------------------------------------------
 #ifndef SE3_PAIR_WAVES
 #define SE3_PAIR_WAVES 4
 #endif
-__global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
-                                                                  int64_t feat_rows, const float* __restrict__ axes_ext,
-                                                                  const float* __restrict__ rho_p,
-                                                                  uint32_t* __restrict__ t_out, int64_t n_items,
-                                                                  int fnb_shift) {
-  constexpr int C = 64;
+template <int CT, bool FULL>
+__global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
+    EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
+    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t n_items, int fnb_shift) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
   __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(E
   const int64_t item = blockIdx.x;
   if (item >= n_items) return;
   const float rho = *rho_p;
-  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * C * 4);
+  const int row_bytes = C * 4;
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
   const int groups = g.f_ctr / 2;
   const int64_t ctr = item / groups;
   const int a0 = (int)(item - ctr * groups) * 2;
@@ -135,7 +136,6 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(E
   float yc[3], rc[9];
   load_geom_record(buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64), (int)(ctr * g.f_ctr + a0 + wv), yc, rc);  // this wavefront's frame
   const int hb = 16 * h;
-  const int cb4 = (32 * wv + kcol) * 4;  // this wavefront aggregates channels 32*wv .. 32*wv+31
 
   // Neighbour ids are fetched two chunks ahead and the geometry records one chunk ahead, so that no load result is
   // needed in the chunk that issues it (the dependent chain ids -> record/feature rows costs one memory latency
@@ -150,96 +150,122 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_bf16_kernel(E
     return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
   };
 
-  f32x16 acc[2] = {zero16(), zero16()};  // [frame]
-  int nb_b = 0, q_a = 0;
-  float xn_nx[3], rn_nx[9];
-  if (n_total > 0) {
-    const int nb_a = nbr_of(0);
-    nb_b = nbr_of(32);
-    q_a = row_of(nb_a, 0);
-    load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
-  }
   int buf = 0;
-  for (int c0 = 0; c0 < n_total; c0 += 32, buf ^= 1) {
-    const int cnt = min(32, n_total - c0);
-    // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
-    const int qoff = c0 + kcol < n_total ? q_a * (C * 4) : kOobOffset;
-    float xn[3], rn[9], d[9];
+  for (int cbase = 0; cbase < C; cbase += 64 * CT) {
+    // this wavefront aggregates channels cbase + 32*(CT*wv + t) + kcol, t = 0..CT-1
+    int cb4[CT];
+    bool ch_ok[CT];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+    for (int t = 0; t < CT; ++t) {
+      const int ch = cbase + 32 * (CT * wv + t) + kcol;
+      ch_ok[t] = FULL || ch < C;
+      cb4[t] = ch * 4;
+    }
+    f32x16 acc[2][CT];  // [frame][tile]
 #pragma unroll
-    for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-    const int q_b = row_of(nb_b, c0 + 32);
-    nb_b = nbr_of(c0 + 64);
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[a][t] = zero16();
+    int nb_b = 0, q_a = 0;
+    float xn_nx[3], rn_nx[9];
+    if (n_total > 0) {
+      const int nb_a = nbr_of(0);
+      nb_b = nbr_of(32);
+      q_a = row_of(nb_a, 0);
+      load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
+    }
+    for (int c0 = 0; c0 < n_total; c0 += 32, buf ^= 1) {
+      const int cnt = min(32, n_total - c0);
+      // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
+      const int qoff = c0 + kcol < n_total ? q_a * row_bytes : kOobOffset;
+      float xn[3], rn[9], d[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+      const int q_b = row_of(nb_b, c0 + 32);
+      nb_b = nbr_of(c0 + 64);
 
-    // gathered feature words for this wavefront's 32 channels (shared by both frames): all 16 loads go out now and
-    // are only turned into MFMA fragments after the barrier below
-    uint32_t fw[2][8];
+      // gathered feature words for this wavefront's channels (shared by both frames): all loads go out now and are
+      // only turned into MFMA fragments after the barrier below
+      uint32_t fw[CT][2][8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
-        fw[s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + cb4, 0, 0);
+        for (int j = 0; j < 8; ++j) {
+          const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+#pragma unroll
+          for (int t = 0; t < CT; ++t)
+            fw[t][s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, ch_ok[t] ? src_off + cb4[t] : kOobOffset, 0, 0);
+        }
+      load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      q_a = q_b;
+
+      if (!g.transposed)
+        edge_descriptor(xn, rn, yc, rc, rho, d);
+      else
+        edge_descriptor(yc, rc, xn, rn, rho, d);
+
+      // kernel MLP + GELU for this wavefront's frame; both lane halves hold the same descriptor: half 0 feeds
+      // dims 0..7, half 1 dims 8, 9
+      {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
+        u32x4 a_hi, a_lo;
+        frags_from_floats(v, a_hi, a_lo);
+        const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
+        const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
+        const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s * 16 < cnt) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
+            u32x4 b_hi, b_lo;
+            frags_from_floats(pv, b_hi, b_lo);
+            *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
+            *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
+          }
+        }
       }
-    load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
-    q_a = q_b;
-
-    if (!g.transposed)
-      edge_descriptor(xn, rn, yc, rc, rho, d);
-    else
-      edge_descriptor(yc, rc, xn, rn, rho, d);
-
-    // kernel MLP + GELU for this wavefront's frame; both lane halves hold the same descriptor: half 0 feeds
-    // dims 0..7, half 1 dims 8, 9
-    {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
-      u32x4 a_hi, a_lo;
-      frags_from_floats(v, a_hi, a_lo);
-      const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
-      const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
-      const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+      __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s * 16 < cnt) {
-          float pv[8];
+          u32x4 b_hi[2], b_lo[2];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
-          u32x4 b_hi, b_lo;
-          frags_from_floats(pv, b_hi, b_lo);
-          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
-          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
+          for (int a = 0; a < 2; ++a) {
+            b_hi[a] = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
+            b_lo[a] = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
+          }
+#pragma unroll
+          for (int t = 0; t < CT; ++t) {
+            u32x4 fa_hi, fa_lo;
+            frags_from_words(fw[t][s], fa_hi, fa_lo);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a][t] = mfma_bf16x3(fa_hi, fa_lo, b_hi[a], b_lo[a], acc[a][t]);
+          }
         }
       }
     }
-    __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
+    // acc[a][t] register r, lane (kcol, h) = T[row 2*item + a][cbase + 32*(CT*wv + t) + acc_row(r,h)][kcol]
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s * 16 < cnt) {
-        u32x4 fa_hi, fa_lo;
-        frags_from_words(fw[s], fa_hi, fa_lo);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const u32x4 b_hi = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
-          const u32x4 b_lo = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
-          acc[a] = mfma_bf16x3(fa_hi, fa_lo, b_hi, b_lo, acc[a]);
+      for (int t = 0; t < CT; ++t) {
+        const int ch0 = cbase + 32 * (CT * wv + t);
+        uint32_t* t_row = t_out + ((item * 2 + a) * (int64_t)C + ch0) * kBasis;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          uint32_t w0, w1;
+          split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
+          if (FULL || ch0 + acc_row(r, h) < C) t_row[acc_row(r, h) * kBasis + kcol] = w0;
+          if (FULL || ch0 + acc_row(r + 1, h) < C) t_row[acc_row(r + 1, h) * kBasis + kcol] = w1;
         }
       }
-    }
-  }
-  // acc[a] register r, lane (kcol, h) = T[row 2*item + a][32*wv + acc_row(r,h)][kcol]
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    uint32_t* t_row = t_out + ((item * 2 + a) * (int64_t)C + 32 * wv) * kBasis;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      uint32_t w0, w1;
-      split_pack2(acc[a][r], acc[a][r + 1], w0, w1);
-      t_row[acc_row(r, h) * kBasis + kcol] = w0;
-      t_row[acc_row(r + 1, h) * kBasis + kcol] = w1;
-    }
+    if (cbase + 64 * CT < C) __syncthreads();  // the next pass reuses the phi buffers from their start
   }
 }
 
@@ -383,14 +409,18 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // ------------------------------------------------------------------------------------------------
 template <int CH16>
 __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
-                                                                         int64_t feat_rows,
+                                                                         int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
                                                                          const float* __restrict__ rho_p,
                                                                          const uint32_t* __restrict__ grad_t,
                                                                          float* __restrict__ partials, int64_t n_items,
                                                                          int fnb_shift) {
-  constexpr int C = CH16 * 16;
+  // Rows wider than 64 channels are covered by blockIdx.y: block row y handles channels 64y .. 64y+63 (gphi, hence
+  // d[A;beta], is linear in the channel sum, so every channel block contributes an independent partial; each block
+  // row recomputes the descriptors and GELU').  row_ch = channels per row (a multiple of 16).
   constexpr int NW = 8;  // wavefronts per block
+  const int c_off = 64 * (int)blockIdx.y;
+  const int row_bytes = row_ch * 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][2][64][4];
   __shared__ __attribute__((aligned(16))) uint32_t lds_desc[NW][2][32][12];
   __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NW][2][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
@@ -401,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
   if (threadIdx.x < 64) mlp_weights_to_lds<2>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
   const float rho = *rho_p;
-  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * C * 4);
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
   const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
   const __amdgpu_buffer_rsrc_t ctrg_rs = buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64);
   f32x16 dacc = zero16();  // lane (j = kcol, h), register r: d[A;beta][j][k = acc_row(r,h)]
@@ -433,11 +463,12 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
     uint32_t gw[2][CH16][8];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const uint32_t* gt_row = grad_t + (item * 2 + a) * (int64_t)C * kBasis;
+      const uint32_t* gt_row = grad_t + ((item * 2 + a) * (int64_t)row_ch + c_off) * kBasis;
 #pragma unroll
       for (int st = 0; st < CH16; ++st)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gw[a][st][j] = gt_row[(16 * st + 8 * h + j) * kBasis + kcol];
+        for (int j = 0; j < 8; ++j)
+          gw[a][st][j] = c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u;
     }
     int q_a = row_of(nb_a, 0);
     float xn_nx[3], rn_nx[9];
@@ -455,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
     for (int c0 = 0; c0 < n_total; c0 += 32) {
       const int cnt = min(32, n_total - c0);
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
-      const int qoff = c0 + kcol < n_total ? q_a * (C * 4) : kOobOffset;
+      const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;
       float xn[3], rn[9], d[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
@@ -469,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
       uint32_t fw[CH16][8];
 #pragma unroll
       for (int st = 0; st < CH16; ++st) {
-        const int voff = qoff + (16 * st + 8 * h) * 4;
+        const int voff = c_off + 16 * st < row_ch ? qoff + (16 * st + 8 * h) * 4 : kOobOffset;  // past the row: zeros
         const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
         const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff + 16, 0, 0);
         fw[st][0] = v0[0], fw[st][1] = v0[1], fw[st][2] = v0[2], fw[st][3] = v0[3];
@@ -578,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
     float sum = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) sum += lds_red[w][j][k];
-    partials[(int64_t)blockIdx.x * kDescExt * kBasis + i] = sum;
+    partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kDescExt * kBasis + i] = sum;
   }
 }
 
@@ -639,9 +670,16 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   for (int sft = 0; sft < 8; ++sft)
     if ((1 << sft) == g.f_nb) shift = sft;
   const dim3 block(256);
-  if (channels == 64 && fc == 2 && getenv("SE3_NO_PAIR") == nullptr) {
-    hipLaunchKernelGGL(edge_t_pair_bf16_kernel, dim3((unsigned)items), dim3(128), 0, stream, g, feat, feat_rows, axes_ext,
-                       rho, t_out, items, shift);
+  if (channels >= 64 && g.f_ctr % 2 == 0 && getenv("SE3_NO_PAIR") == nullptr) {
+    const int64_t pair_items = rows / 2;
+    const dim3 pgrid((unsigned)pair_items), pblock(128);
+#define SE3_PAIR(CT, FULL)                                                                                            \
+  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, axes_ext, \
+                     rho, t_out, pair_items, shift)
+    if (channels == 64) SE3_PAIR(1, true);
+    else if (channels % 128 == 0) SE3_PAIR(2, true);
+    else SE3_PAIR(2, false);
+#undef SE3_PAIR
     return check_launch();
   }
   if (channels <= 128 && getenv("SE3_STREAM") != nullptr) {
@@ -685,21 +723,28 @@ per_item:
   return check_launch();
 }
 
+// partials: room for n_partials x edge_param_grad_bf16_channel_blocks(channels) slots of 320 floats; *n_used = slots written
+int edge_param_grad_bf16_channel_blocks(int channels) { return channels > 64 && channels % 16 == 0 ? (channels + 63) / 64 : 1; }
+
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
-                                float* partials, int n_partials, hipStream_t stream) {
+                                float* partials, int n_partials, int* n_used, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
-  if (g.f_ctr % 2 == 0 && channels % 16 == 0 && channels <= 64 && channels > 0) {
+  *n_used = n_partials;
+  if (g.f_ctr % 2 == 0 && channels % 16 == 0 && channels > 0) {
     int shift = -1;
     for (int sft = 0; sft < 8; ++sft)
       if ((1 << sft) == g.f_nb) shift = sft;
     const int64_t items = rows / 2;
-#define SE3_PG(CH16)                                                                                                  \
-  hipLaunchKernelGGL(edge_param_grad_bf16_v2_kernel<CH16>, dim3(n_partials), dim3(512), 0, stream, g, feat, feat_rows, \
-                     axes_ext, rho, grad_t, partials, items, shift)
-    switch (channels / 16) {
+    const int blocks_y = edge_param_grad_bf16_channel_blocks(channels);
+    *n_used = n_partials * blocks_y;
+    const dim3 grid((unsigned)n_partials, (unsigned)blocks_y);
+#define SE3_PG(CH16)                                                                                                   \
+  hipLaunchKernelGGL(edge_param_grad_bf16_v2_kernel<CH16>, grid, dim3(512), 0, stream, g, feat, channels, feat_rows, axes_ext, \
+                     rho, grad_t, partials, items, shift)
+    switch (channels >= 64 ? 4 : channels / 16) {
       case 1: SE3_PG(1); break;
       case 2: SE3_PG(2); break;
       case 3: SE3_PG(3); break;

@@ -141,6 +141,10 @@ CASES = [
     (15, 300, 500, 2, 2, 3, 13, 6, 1),        # odd channel counts (ScanNet colours -> classes)
     (16, 256, None, 3, 3, 32, 32, 8, 1),      # F = 3 (not a power of two)
     (17, 2000, None, 2, 2, 64, 64, 70, 1),    # very dense: ~70 neighbours, 5 chunks
+    (18, 400, None, 2, 2, 128, 128, 20, 1),   # wide rows: wave-pair kernel with two channel tiles, two param-grad blocks
+    (19, 300, 200, 2, 2, 192, 64, 16, 2),     # C_in = 192 = 128 + 64: partial last channel pass; gathers 64 ch in bwd
+    (20, 200, None, 2, 2, 320, 320, 12, 1),   # widest ScanNet level (3 passes fwd and bwd, 5 param-grad blocks)
+    (21, 300, None, 4, 2, 80, 144, 12, 1),    # C % 16 == 0 but not % 32 / % 64; F_in = 4 gathered by 2 centre frames
 ]
 
 
