@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #ifndef SE3_PAIR_WAVES
 #define SE3_PAIR_WAVES 4
 #endif
-template <int CT, bool FULL>
+template <int CT, bool FULL, int NF>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t n_items, int fnb_shift) {
@@ -127,14 +127,16 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   const float rho = *rho_p;
   const int row_bytes = C * 4;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
-  const int groups = g.f_ctr / 2;
+  // NF = 2: item = two consecutive frames of a point, wavefront v owns frame a0 + v.  NF = 1: item = one row (any
+  // F); both wavefronts hold that frame, wavefront v does the GELU of k-step v only (16 of the 32 frame-edges).
+  const int groups = g.f_ctr / NF;
   const int64_t ctr = item / groups;
-  const int a0 = (int)(item - ctr * groups) * 2;
+  const int a0 = (int)(item - ctr * groups) * NF;
   const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
   const int n_total = (g.ends[ctr] - start) * g.f_nb;
   const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
   float yc[3], rc[9];
-  load_geom_record(buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64), (int)(ctr * g.f_ctr + a0 + wv), yc, rc);  // this wavefront's frame
+  load_geom_record(buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64), (int)(ctr * g.f_ctr + a0 + (NF == 2 ? wv : 0)), yc, rc);  // this wavefront's frame
   const int hb = 16 * h;
 
   // Neighbour ids are fetched two chunks ahead and the geometry records one chunk ahead, so that no load result is
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       ch_ok[t] = FULL || ch < C;
       cb4[t] = ch * 4;
     }
-    f32x16 acc[2][CT];  // [frame][tile]
+    f32x16 acc[NF][CT];  // [frame][tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NF; ++a)
 #pragma unroll
       for (int t = 0; t < CT; ++t) acc[a][t] = zero16();
     int nb_b = 0, q_a = 0;
@@ -219,14 +221,14 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
         const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          if (s * 16 < cnt) {
+          if (s * 16 < cnt && (NF == 2 || s == wv)) {
             float pv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);
-            *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
-            *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
+            *reinterpret_cast<u32x4*>(&lds_phi[buf][NF == 2 ? wv : 0][s][0][lane][0]) = b_hi;
+            *reinterpret_cast<u32x4*>(&lds_phi[buf][NF == 2 ? wv : 0][s][1][lane][0]) = b_lo;
           }
         }
       }
@@ -234,9 +236,9 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s * 16 < cnt) {
-          u32x4 b_hi[2], b_lo[2];
+          u32x4 b_hi[NF], b_lo[NF];
 #pragma unroll
-          for (int a = 0; a < 2; ++a) {
+          for (int a = 0; a < NF; ++a) {
             b_hi[a] = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
             b_lo[a] = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
           }
@@ -245,18 +247,18 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
             u32x4 fa_hi, fa_lo;
             frags_from_words(fw[t][s], fa_hi, fa_lo);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) acc[a][t] = mfma_bf16x3(fa_hi, fa_lo, b_hi[a], b_lo[a], acc[a][t]);
+            for (int a = 0; a < NF; ++a) acc[a][t] = mfma_bf16x3(fa_hi, fa_lo, b_hi[a], b_lo[a], acc[a][t]);
           }
         }
       }
     }
-    // acc[a][t] register r, lane (kcol, h) = T[row 2*item + a][cbase + 32*(CT*wv + t) + acc_row(r,h)][kcol]
+    // acc[a][t] register r, lane (kcol, h) = T[row NF*item + a][cbase + 32*(CT*wv + t) + acc_row(r,h)][kcol]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NF; ++a)
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int ch0 = cbase + 32 * (CT * wv + t);
-        uint32_t* t_row = t_out + ((item * 2 + a) * (int64_t)C + ch0) * kBasis;
+        uint32_t* t_row = t_out + ((item * NF + a) * (int64_t)C + ch0) * kBasis;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           uint32_t w0, w1;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // a wave-private LDS image (CH16 * 4 KB per wavefront; in registers they cost CH16 * 16 VGPRs and spilled),
 // hence 512-thread blocks: 8 wavefronts share the CU's LDS at the same 2 waves/SIMD as before.
 // ------------------------------------------------------------------------------------------------
-template <int CH16>
+template <int CH16, int NFR>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
 __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                          int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
@@ -422,13 +424,13 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
   const int c_off = 64 * (int)blockIdx.y;
   const int row_bytes = row_ch * 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][2][64][4];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_desc[NW][2][32][12];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NW][2][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
+  __shared__ __attribute__((aligned(16))) uint32_t lds_desc[NW][NFR][32][12];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NW][NFR][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
   // the final block reduction reuses the gT image (NW * 10 * 32 floats <= NW * CH16 * 1024 words)
   float(*lds_red)[kDescExt][kBasis] = reinterpret_cast<float(*)[kDescExt][kBasis]>(&lds_gt[0][0][0][0][0][0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kcol = lane & 31, h = lane >> 5;
-  if (threadIdx.x < 64) mlp_weights_to_lds<2>(lds_w, axes_ext, threadIdx.x);
+  if (threadIdx.x < 64) mlp_weights_to_lds<NFR>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
   const float rho = *rho_p;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
@@ -437,14 +439,14 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
   f32x16 dacc = zero16();  // lane (j = kcol, h), register r: d[A;beta][j][k = acc_row(r,h)]
 
   for (int64_t item = (int64_t)blockIdx.x * NW + wave; item < n_items; item += (int64_t)gridDim.x * NW) {
-    const int groups = g.f_ctr / 2;
+    const int groups = g.f_ctr / NFR;
     const int64_t ctr = item / groups;
-    const int a0 = (int)(item - ctr * groups) * 2;
+    const int a0 = (int)(item - ctr * groups) * NFR;
     const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
     const int n_total = (g.ends[ctr] - start) * g.f_nb;
     if (n_total == 0) continue;
     float yc[3], rc[9];
-    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + h), yc, rc);
+    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (NFR == 2 ? h : 0)), yc, rc);
 
     // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
     auto nbr_of = [&](int c0) {
@@ -460,10 +462,10 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
     int nb_b = nbr_of(32);
 
     // gT fragments (MFMA B operand) of the item's two rows: lane (k = kcol, h) holds channels 16*st + 8h + j
-    uint32_t gw[2][CH16][8];
+    uint32_t gw[NFR][CH16][8];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const uint32_t* gt_row = grad_t + ((item * 2 + a) * (int64_t)row_ch + c_off) * kBasis;
+    for (int a = 0; a < NFR; ++a) {
+      const uint32_t* gt_row = grad_t + ((item * NFR + a) * (int64_t)row_ch + c_off) * kBasis;
 #pragma unroll
       for (int st = 0; st < CH16; ++st)
 #pragma unroll
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
     float xn_nx[3], rn_nx[9];
     load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NFR; ++a)
 #pragma unroll
       for (int st = 0; st < CH16; ++st) {
         u32x4 f_hi, f_lo;
@@ -515,8 +517,8 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
         edge_descriptor(yc, rc, xn, rn, rho, d);
 
       // descriptor image for the d[A;beta] product: half h writes the rows of frame a0+h
-      {
-        uint32_t* dst = &lds_desc[wave][h][kcol][0];
+      if (NFR == 2 || h == 0) {
+        uint32_t* dst = &lds_desc[wave][NFR == 2 ? h : 0][kcol][0];
         uint32_t pw[12];
 #pragma unroll
         for (int i = 0; i < 8; i += 2) split_pack2(d[i], d[i + 1], pw[i], pw[i + 1]);
@@ -530,8 +532,10 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
       frags_from_floats(d, own_hi, own_lo);
       {
         float d8 = d[8];
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
-        d8 = __uint_as_float(h ? sw[0] : sw[1]);
+        if (NFR == 2) {  // dims 8, 9 of frame a come from the half that did not build frame a's descriptor
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
+          d8 = __uint_as_float(h ? sw[0] : sw[1]);
+        }
         uint32_t p_hi, p_lo;
         split2(d8, 1.0f, p_hi, p_lo);
         oth_hi = u32x4{p_hi, 0u, 0u, 0u};
@@ -542,10 +546,10 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
       // GELU' of both frames first (pure VALU, covers the gather latency) ...
-      float dyv[2][16];
+      float dyv[NFR][16];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const bool dims07 = h == a;
+      for (int a = 0; a < NFR; ++a) {
+        const bool dims07 = NFR == 2 ? h == a : h == 0;
         u32x4 a_hi, a_lo;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
       for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
       const int jcol = min(kcol, 11);
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+      for (int a = 0; a < NFR; ++a) {
         f32x16 gphi = zero16();
 #pragma unroll
         for (int st = 0; st < CH16; ++st) {
@@ -670,12 +674,20 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   for (int sft = 0; sft < 8; ++sft)
     if ((1 << sft) == g.f_nb) shift = sft;
   const dim3 block(256);
-  if (channels >= 64 && g.f_ctr % 2 == 0 && getenv("SE3_NO_PAIR") == nullptr) {
-    const int64_t pair_items = rows / 2;
+  if (channels >= 64 && getenv("SE3_NO_PAIR") == nullptr) {
+    // a 128-thread workgroup per two frames of a point (even F) or per single row (odd F, e.g. ScanNet's F = 1)
+    const bool two = g.f_ctr % 2 == 0;
+    const int64_t pair_items = two ? rows / 2 : rows;
     const dim3 pgrid((unsigned)pair_items), pblock(128);
-#define SE3_PAIR(CT, FULL)                                                                                            \
-  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, axes_ext, \
-                     rho, t_out, pair_items, shift)
+#define SE3_PAIR(CT, FULL)                                                                                              \
+  do {                                                                                                                  \
+    if (two)                                                                                                            \
+      hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 2>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
+                         axes_ext, rho, t_out, pair_items, shift);                                                      \
+    else                                                                                                                \
+      hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 1>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
+                         axes_ext, rho, t_out, pair_items, shift);                                                      \
+  } while (0)
     if (channels == 64) SE3_PAIR(1, true);
     else if (channels % 128 == 0) SE3_PAIR(2, true);
     else SE3_PAIR(2, false);
@@ -733,17 +745,24 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
   *n_used = n_partials;
-  if (g.f_ctr % 2 == 0 && channels % 16 == 0 && channels > 0) {
+  if (channels % 16 == 0 && channels > 0) {
     int shift = -1;
     for (int sft = 0; sft < 8; ++sft)
       if ((1 << sft) == g.f_nb) shift = sft;
-    const int64_t items = rows / 2;
+    const bool two = g.f_ctr % 2 == 0;  // two frames per wavefront share the gather; odd F: one row per wavefront
+    const int64_t items = two ? rows / 2 : rows;
     const int blocks_y = edge_param_grad_bf16_channel_blocks(channels);
     *n_used = n_partials * blocks_y;
     const dim3 grid((unsigned)n_partials, (unsigned)blocks_y);
-#define SE3_PG(CH16)                                                                                                   \
-  hipLaunchKernelGGL(edge_param_grad_bf16_v2_kernel<CH16>, grid, dim3(512), 0, stream, g, feat, channels, feat_rows, axes_ext, \
-                     rho, grad_t, partials, items, shift)
+#define SE3_PG(CH16)                                                                                                      \
+  do {                                                                                                                    \
+    if (two)                                                                                                              \
+      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, 2>), grid, dim3(512), 0, stream, g, feat, channels, feat_rows, \
+                         axes_ext, rho, grad_t, partials, items, shift);                                                  \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, 1>), grid, dim3(512), 0, stream, g, feat, channels, feat_rows, \
+                         axes_ext, rho, grad_t, partials, items, shift);                                                  \
+  } while (0)
     switch (channels >= 64 ? 4 : channels / 16) {
       case 1: SE3_PG(1); break;
       case 2: SE3_PG(2); break;
