@@ -440,3 +440,33 @@ def init_parameters(dims: int, c_in: int, c_out: int, num_basis: int, generator=
 def radius_for_degree(n: int, k: float) -> float:
     """r = (3k / (4 pi N))^(1/3): expected interior degree k for N uniform points in [0,1)^3."""
     return (3.0 * k / (4.0 * math.pi * n)) ** (1.0 / 3.0)
+
+
+def pne_conv_forward_backward(pts_in, pts_out, neighbors, ends, x, proj_axes, proj_biases, conv_weights, rho, nu,
+                              grad_out, dtype=torch.float64):
+    """The reference's NON-equivariant ``PNEConvLayer`` ('mlp_gelu', 'add'; scope row f-4), restated from
+    ``layers/PNEConvLayer.py:161-229`` and ``custom_ops/PNE.py:36-40``:
+
+        basis[e]  = GELU(rho * (x_src(e) - y_smp(e)) @ A + beta)                       (LinearPNE + torch.nn.GELU())
+        T[m,i,k]  = sum_{e in seg m} f[src(e), i] * basis[e, k]                         (FeatBasisProj)
+        out       = einsum('nik,iko->no', T, W) * nu
+
+    Returns out and the gradients (dx, dA, dbeta, dW) for ``grad_out`` by autograd on the restated forward."""
+    t = lambda v: torch.as_tensor(v).to(dtype)  # noqa: E731
+    x = t(x).clone().requires_grad_(True)
+    a = t(proj_axes).clone().requires_grad_(True)
+    b = t(proj_biases).clone().requires_grad_(True)
+    w = t(conv_weights).clone().requires_grad_(True)
+    nb = torch.as_tensor(neighbors).long()
+    ends = torch.as_tensor(ends).long()
+    m = ends.shape[0]
+    rel = (t(pts_in)[nb[:, 1]] - t(pts_out)[nb[:, 0]]) * t(rho)
+    basis = torch.nn.functional.gelu(rel @ a + b.reshape(1, -1))
+    counts = torch.diff(ends, prepend=ends.new_zeros(1))
+    seg = torch.repeat_interleave(torch.arange(m), counts)
+    outer = x[nb[:, 1]].unsqueeze(2) * basis.unsqueeze(1)  # [E, C, K]
+    tt = torch.zeros((m, x.shape[1], basis.shape[1]), dtype=dtype).index_add(0, seg, outer)
+    out = torch.einsum("nik,iko->no", tt, w) * t(nu)
+    out.backward(t(grad_out))
+    return out.detach(), x.grad, a.grad, b.grad, w.grad
+

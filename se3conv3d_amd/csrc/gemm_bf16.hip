@@ -18,6 +18,9 @@ namespace {
 #ifndef SE3_GEMM_ABLATE
 #define SE3_GEMM_ABLATE 0  // diagnostic builds: 1 no MFMA stage, 2 no LDS staging, 4 no barriers
 #endif
+#ifndef SE3_GEMM_REVERSE
+#define SE3_GEMM_REVERSE 0  // measured: no difference (0.245 ms either way)
+#endif
 #ifndef SE3_GEMM_DEPTH
 #define SE3_GEMM_DEPTH 4
 #endif
@@ -51,7 +54,14 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BN][B_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
+  // Row blocks are taken last-to-first: A was written front-to-back by the kernel just before this one, so its tail
+  // (up to the 256 MB of the memory-side cache) is still on chip when this kernel starts; reading it first turns
+  // that part of the stream into cache hits instead of letting the front-to-back walk evict it unread.
+#if SE3_GEMM_REVERSE
+  const int64_t m0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * BM;
+#else
   const int64_t m0 = (int64_t)blockIdx.x * BM;
+#endif
   const int n0 = blockIdx.y * BN;
   const bool a_vec = (k % 4) == 0;
   const int kt_begin = blockIdx.z * kt_per_split;

@@ -180,6 +180,89 @@ class PNEConvLayerRotEquiv(IConvLayer):
         raise Exception(f"unknown pne type {self.pne_type_}")
 
 
+def _identity_frames(pc) -> torch.Tensor:
+    """``[N,1,9]`` identity frames of a plain Pointcloud, cached on it."""
+    fr = getattr(pc, "_se3_identity_frames", None)
+    if fr is None or fr.shape[0] != pc.pts_.shape[0] or fr.device != pc.pts_.device:
+        fr = torch.eye(3, dtype=torch.float32, device=pc.pts_.device).reshape(1, 1, 9).repeat(pc.pts_.shape[0], 1, 1)
+        try:
+            pc._se3_identity_frames = fr
+        except AttributeError:
+            pass
+    return fr
+
+
+class _IdentityFramed(object):
+    """View of a plain Pointcloud with one identity frame per point (what the fused operator reads)."""
+
+    def __init__(self, pc):
+        self.pts_ = pc.pts_
+        self.local_frames_ = _identity_frames(pc)
+        self.n_frames_ = 1
+
+
+class PNEConvLayer(IConvLayer):
+    """The reference's non-equivariant continuous convolution (``layers/PNEConvLayer.py:47-229``, scope row f-4),
+    ``mlp_gelu`` embedding with ``add`` aggregation:
+
+        out[s,o] = nu * sum_{(s,p) in E} sum_k sum_i GELU(rho (x_p - y_s) . A + beta)_k * f[p,i] * W[i,k,o]
+
+    It runs through the same HIP operator as the equivariant layer: with one identity frame per point the
+    9-D descriptor of the fused kernel is ``[rho (x_p - y_s), 1,0,0, 0,1,0]``, so the ``[3,K]`` projection axes
+    are padded with six zero rows (whose gradient rows are dropped by autograd's ``cat``).  Parameter / buffer
+    names and shapes are the reference's (``proj_axes_ [3,K]``, ``proj_biases_ [K]``, ``conv_weights_ [C_in,K,C_out]``).
+    """
+
+    def __init__(self, p_dims, p_in_features, p_out_features, p_num_basis, p_pne_type, p_aggregation="add"):
+        super().__init__(p_dims, p_in_features, p_out_features)
+        self.num_basis_ = p_num_basis
+        self.pne_type_ = p_pne_type
+        self.aggregation_ = p_aggregation
+        if p_pne_type != "mlp_gelu" or p_aggregation != "add" or p_dims != 3:
+            raise NotImplementedError("PNEConvLayer on the HIP operator: 'mlp_gelu' embedding, 'add' aggregation, 3-D points")
+        bound = math.sqrt(1.0 / p_dims)
+        self.proj_axes_ = torch.nn.Parameter(torch.empty(p_dims, p_num_basis).uniform_(-bound, bound))
+        self.proj_biases_ = torch.nn.Parameter(torch.zeros((p_num_basis,), dtype=torch.float32))
+        bound = math.sqrt(1.0 / (p_in_features * p_num_basis))
+        self.conv_weights_ = torch.nn.Parameter(
+            torch.empty(p_in_features, p_num_basis, p_out_features).uniform_(-bound, bound))
+
+    def __compute_convolution__(self, p_pc_in, p_pc_out, p_in_features, p_neighborhood):
+        pc_in = _IdentityFramed(p_pc_in)
+        pc_out = pc_in if p_pc_out is p_pc_in else _IdentityFramed(p_pc_out)
+        cache = getattr(p_neighborhood, "_se3_geom_plain", None)
+        key = (p_pc_in.pts_.data_ptr(), p_pc_out.pts_.data_ptr(), p_neighborhood.neighbors_.data_ptr())
+        if cache is not None and cache[0] == key:
+            geom = cache[1]
+        else:
+            geom = ops.ConvGeometry.build(pc_in.pts_, pc_out.pts_, pc_in.local_frames_, pc_out.local_frames_,
+                                          p_neighborhood.neighbors_, p_neighborhood.start_ids_)
+            try:
+                p_neighborhood._se3_geom_plain = (key, geom)
+            except AttributeError:
+                pass
+        axes9 = torch.cat([self.proj_axes_, self.proj_axes_.new_zeros((6, self.num_basis_))], dim=0)
+        return ops.SE3ConvFunction.apply(p_in_features, axes9, self.proj_biases_, self.conv_weights_, geom,
+                                         self.norm_neigh_dist_, self.norm_num_neighs_)
+
+
+class PNEConvLayerFactory(IConvLayerFactory):
+    """``layers/PNEConvLayer.py:232-274``."""
+
+    def __init__(self, p_dims, p_num_basis, p_pne_type, p_aggregation="add"):
+        super().__init__(p_dims)
+        self.num_basis_ = p_num_basis
+        self.pne_type_ = p_pne_type
+        self.aggregation_ = p_aggregation
+
+    def update_parameters(self, **kwargs):
+        if "num_basis" in kwargs:
+            self.num_basis_ = kwargs["num_basis"]
+
+    def __create_conv_layer_imp__(self, p_in_features, p_out_features):
+        return PNEConvLayer(self.dims_, p_in_features, p_out_features, self.num_basis_, self.pne_type_, self.aggregation_)
+
+
 class PNEConvLayerRotEquivFactory(IConvLayerFactory):
     def __init__(self, p_dims, p_num_basis, p_pne_type, p_rel_rot="6D"):
         super().__init__(p_dims)

@@ -6,6 +6,7 @@ Integer results (edges, ends, keys, transposed lists) are compared bit-exactly (
 where the reference leaves the order undefined).
 """
 import math
+import glob
 import os
 
 import pytest
@@ -77,6 +78,41 @@ def test_layer_forward_backward_matches_golden(path, amd):
     amd.PNEConvLayerRotEquiv.empty_rot_tenors_cache()
     out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=nbh)
     assert out.shape == d["out"].shape and out.dtype == torch.float32 and out.is_cuda
+    out.backward(d["grad_out"].to(DEV))
+    assert rel_err(out, d["out"]) < tol(amd)
+    assert rel_err(x.grad, d["dx"]) < tol(amd)
+    assert rel_err(conv.proj_axes_.grad, d["dA"]) < tol(amd)
+    assert rel_err(conv.proj_biases_.grad, d["dbeta"]) < tol(amd)
+    assert rel_err(conv.conv_weights_.grad, d["dW"]) < tol(amd)
+
+
+PNE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "pne_*.npz")))
+
+
+@pytest.mark.parametrize("path", PNE_FILES, ids=[os.path.basename(f) for f in PNE_FILES])
+def test_non_equivariant_pne_layer_matches_reference_fixture(path, amd):
+    """Scope row f-4: the reference's PNEConvLayer (3-D offsets, no frames) through the same HIP operator, against
+    fixtures produced by the reference's own PNEConvLayer / LinearPNE / FeatBasisProj Python."""
+    d = load_npz(path)
+    pc_in = amd.pc.Pointcloud(d["pts_in"].to(DEV), d["batch_in"].to(DEV))
+    same = d["pts_in"].shape == d["pts_out"].shape and torch.equal(d["pts_in"], d["pts_out"])
+    pc_out = pc_in if same else amd.pc.Pointcloud(d["pts_out"].to(DEV), d["batch_out"].to(DEV))
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, float(d["radius"]))
+    assert torch.equal(nbh.start_ids_.cpu(), d["ends"])
+    c_in, kb, c_out = d["conv_weights"].shape
+    conv = amd.PNEConvLayerFactory(3, kb, "mlp_gelu").create_conv_layer(c_in, c_out)
+    assert sorted(conv.state_dict().keys()) == ["conv_weights_", "norm_neigh_dist_", "norm_num_neighs_", "proj_axes_",
+                                                "proj_biases_"]
+    assert tuple(conv.proj_axes_.shape) == (3, kb)
+    with torch.no_grad():
+        conv.proj_axes_.copy_(d["proj_axes"])
+        conv.proj_biases_.copy_(d["proj_biases"])
+        conv.conv_weights_.copy_(d["conv_weights"])
+        conv.norm_neigh_dist_.copy_(d["rho"])
+        conv.norm_num_neighs_.copy_(d["nu"])
+    conv = conv.to(DEV)
+    x = d["x"].to(DEV).requires_grad_(True)
+    out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=nbh)
     out.backward(d["grad_out"].to(DEV))
     assert rel_err(out, d["out"]) < tol(amd)
     assert rel_err(x.grad, d["dx"]) < tol(amd)

@@ -1,6 +1,8 @@
 """CPU: the oracle against the fixtures generated from the reference's Python (tools/gen_golden.py)."""
+import glob
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -129,3 +131,18 @@ def test_dropped_rows_quirk():
     assert float(full[ref_like.shape[0]:].abs().max()) == 0.0
     lean = O.conv_forward_edgewise(pts_in, pts_out, fi, fo, nb, x, a, b, w, torch.tensor(2.5), torch.tensor(0.1))
     assert rel_err(lean, full) < TOL
+
+
+PNE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "pne_*.npz")))
+
+
+@pytest.mark.parametrize("path", PNE_FILES, ids=[os.path.basename(f) for f in PNE_FILES])
+def test_oracle_pne_layer_matches_reference_fixture(path):
+    """Non-equivariant PNEConvLayer (scope row f-4): the restatement against the reference's own Python."""
+    d = np.load(path)
+    out, dx, da, db, dw = O.pne_conv_forward_backward(
+        d["pts_in"], d["pts_out"], d["neighbors"], d["ends"], d["x"], d["proj_axes"], d["proj_biases"],
+        d["conv_weights"], d["rho"], d["nu"], d["grad_out"])
+    for got, key in ((out, "out"), (dx, "dx"), (da, "dA"), (db, "dbeta"), (dw, "dW")):
+        ref = torch.as_tensor(d[key]).double()
+        assert float((got - ref).norm() / ref.norm()) < 2e-6, key

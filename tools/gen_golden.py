@@ -235,6 +235,50 @@ def pca_case(pclib, seed):
     return out
 
 
+def pne_case(pclib, seed, n_in, n_out, c_in, c_out, k_deg, batches):
+    """The reference's non-equivariant PNEConvLayer ('mlp_gelu', aggregation 'add', 3-D offsets; scope row f-4):
+    plain Pointcloud, BQNeighborhood, forward + backward through LinearPNE / FeatBasisProj / einsum."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    pts_in = torch.rand(n_in, 3)
+    bid_in = torch.sort(torch.randint(0, batches, (n_in,), dtype=torch.int32)).values
+    pc_in = pclib.pc.Pointcloud(pts_in, bid_in)
+    if n_out is None:
+        pc_out = pc_in
+    else:
+        pts_out = torch.rand(n_out, 3)
+        bid_out = torch.sort(torch.randint(0, batches, (n_out,), dtype=torch.int32)).values
+        pc_out = pclib.pc.Pointcloud(pts_out, bid_out)
+    r = _radius(n_in / batches, k_deg)
+    neigh = pclib.pc.BQNeighborhood(pc_in, pc_out, r)
+    conv = pclib.layers.PNEConvLayerFactory(3, 32, "mlp_gelu").create_conv_layer(c_in, c_out)
+    with torch.no_grad():
+        conv.proj_biases_.uniform_(-0.5, 0.5)
+    conv.norm_neigh_dist_ = torch.tensor(1.0 / r, dtype=torch.float32)
+    conv.norm_num_neighs_ = torch.tensor(neigh.start_ids_.shape[0] / neigh.neighbors_.shape[0], dtype=torch.float32)
+    x = torch.randn(n_in, c_in, requires_grad=True)
+    out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=neigh)
+    g = torch.randn_like(out)
+    out.backward(g)
+    return {
+        "pts_in": pc_in.pts_.numpy(), "pts_out": pc_out.pts_.numpy(),
+        "batch_in": pc_in.batch_ids_.numpy(), "batch_out": pc_out.batch_ids_.numpy(), "radius": np.float64(r),
+        "neighbors": neigh.neighbors_.numpy().astype(np.int32), "ends": neigh.start_ids_.numpy().astype(np.int32),
+        "proj_axes": conv.proj_axes_.detach().numpy(), "proj_biases": conv.proj_biases_.detach().numpy(),
+        "conv_weights": conv.conv_weights_.detach().numpy(),
+        "rho": conv.norm_neigh_dist_.numpy(), "nu": conv.norm_num_neighs_.numpy(),
+        "x": x.detach().numpy(), "out": out.detach().numpy(), "grad_out": g.numpy(),
+        "dx": x.grad.numpy(), "dA": conv.proj_axes_.grad.numpy(), "dbeta": conv.proj_biases_.grad.numpy(),
+        "dW": conv.conv_weights_.grad.numpy(),
+    }
+
+
+PNE_CASES = [
+    # name,              seed, n_in, n_out, c_in, c_out, k, batches
+    ("pne_n300_c32",       9, 300, None, 32, 32, 16, 1),
+    ("pne_down_n400_n150", 10, 400, 150, 3, 64, 20, 2),
+]
+
 CASES = [
     # name,             seed, n_in, n_out, F, c_in, c_out, k, batches
     ("cfg1_n1024_f1_c32", 0, 1024, None, 1, 32, 32, 16, 1),   # BASELINE.json configs[0]
@@ -250,6 +294,13 @@ CASES = [
 def main():
     pclib = _import_reference()
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    for name, seed, n_in, n_out, c_in, c_out, k, b in PNE_CASES:
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **pne_case(pclib, seed, n_in, n_out, c_in, c_out, k, b))
+        print(f"{path}: size={os.path.getsize(path) / 1e6:.2f} MB")
+    if only == "pne":
+        return
     for name, seed, n_in, n_out, f, c_in, c_out, k, b in CASES:
         data = layer_case(pclib, seed, n_in, n_out, f, c_in, c_out, k, batches=b)
         path = os.path.join(OUT, f"layer_{name}.npz")
