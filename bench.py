@@ -263,6 +263,21 @@ def main():
             pass
         roofline.update({"avg_launch_ms": round(stages[dom][0], 4), "launches": stages[dom][1],
                          "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}})
+    # "end-to-end" number of SURVEY.md section 8d: the conv step plus the per-step neighbourhood work of the 4 levels
+    # (ball query, source-major edge list for backward); it needs one host sync per level for E, so it is timed
+    # eagerly beside the graph-replayed conv step
+    def build_neighbourhoods():
+        for lv in levels:
+            nb = amd.pc.BQNeighborhood(lv["pc"], lv["pc"], lv["r"])
+            amd.ops.csr_transpose(nb.neighbors_.to(torch.int32), lv["n"])
+    for _ in range(2):
+        build_neighbourhoods()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        build_neighbourhoods()
+    torch.cuda.synchronize(device)
+    ms_nbh = (time.perf_counter() - t0) / 5 * 1e3
     lb = layer_bytes(levels[0]["n"], levels[0]["e"])
     hbm = {"algorithmic_bytes_per_layer": lb, "achieved": round(lb / (ms_layer * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS,
            "unit": "GB/s", "frac": round(lb / (ms_layer * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
@@ -287,6 +302,9 @@ def main():
                    "launch": "eager" if args.no_graph else "hipGraph replay of the captured step", "sharding": "one scene per rank, no data-path collective"},
         "single_layer": {"ms_per_step": round(ms_layer, 4), "value": round(N0 * world / (ms_layer * 1e-3) / 1e6, 3),
                          "unit": "Mpoints/s", "hbm_roofline": hbm},
+        "end_to_end": {"neighbourhood_ms": round(ms_nbh, 4), "ms_per_step": round(ms_step + ms_nbh, 4),
+                       "value": round(N0 * world / ((ms_step + ms_nbh) * 1e-3) / 1e6, 3), "unit": "Mpoints/s",
+                       "note": "conv step + ball query and source-major edge lists of the 4 levels, rebuilt every step"},
         "roofline": roofline,
     }
     # the "trivial result gather": one checksum of the level-0 output per scene, to rank 0
