@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // hence 512-thread blocks: 8 wavefronts share the CU's LDS at the same 2 waves/SIMD as before.
 // ------------------------------------------------------------------------------------------------
 template <int CH16, int NFR>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
-__global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+__global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                          int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
                                                                          const float* __restrict__ rho_p,
@@ -420,7 +420,8 @@ __global__ __launch_bounds__(512, 2) void edge_param_grad_bf16_v2_kernel(EdgeGeo
   // Rows wider than 64 channels are covered by blockIdx.y: block row y handles channels 64y .. 64y+63 (gphi, hence
   // d[A;beta], is linear in the channel sum, so every channel block contributes an independent partial; each block
   // row recomputes the descriptors and GELU').  row_ch = channels per row (a multiple of 16).
-  constexpr int NW = 8;  // wavefronts per block
+  // wavefronts per block: the gT images (8 KB per frame and wavefront) bound the occupancy
+  constexpr int NW = NFR == 2 ? 8 : 4;
   const int c_off = 64 * (int)blockIdx.y;
   const int row_bytes = row_ch * 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][2][64][4];
@@ -749,7 +750,10 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
     int shift = -1;
     for (int sft = 0; sft < 8; ++sft)
       if ((1 << sft) == g.f_nb) shift = sft;
-    const bool two = g.f_ctr % 2 == 0;  // two frames per wavefront share the gather; odd F: one row per wavefront
+    // two frames per wavefront share the gather (2 waves/SIMD: 16 KB of gT fragments per wavefront); one row per
+    // wavefront (odd F, or SE3_PG_SINGLE for any F) gathers each neighbour row once per centre frame but runs at 3
+    static const bool force_single = getenv("SE3_PG_SINGLE") != nullptr;
+    const bool two = g.f_ctr % 2 == 0 && !force_single;
     const int64_t items = two ? rows / 2 : rows;
     const int blocks_y = edge_param_grad_bf16_channel_blocks(channels);
     *n_used = n_partials * blocks_y;
@@ -760,7 +764,7 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, 2>), grid, dim3(512), 0, stream, g, feat, channels, feat_rows, \
                          axes_ext, rho, grad_t, partials, items, shift);                                                  \
     else                                                                                                                  \
-      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, 1>), grid, dim3(512), 0, stream, g, feat, channels, feat_rows, \
+      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, 1>), grid, dim3(256), 0, stream, g, feat, channels, feat_rows, \
                          axes_ext, rho, grad_t, partials, items, shift);                                                  \
   } while (0)
     switch (channels >= 64 ? 4 : channels / 16) {

@@ -1,9 +1,10 @@
 """Kernel variants that are selected by environment variables (read once per process) are exercised by
 re-running a slice of the parity suite in a child process with the variable set:
 
-  SE3_BWD_MERGE=1   merged transposed-convolution + parameter-gradient kernel (edge_bwd_bf16.hip)
+  SE3_BWD_MERGE=1   merged transposed-convolution + parameter-gradient kernel, role-specialised wavefronts (edge_bwd_bf16.hip)
   SE3_NO_PAIR=1     single-wavefront edge kernel instead of the wave-pair kernel for C = 64
   SE3CONV_FUSED=1   fused edge + contraction kernel (fused_bf16.hip)
+  SE3_PG_SINGLE=1   one row per wavefront in the parameter-gradient kernel (what odd frame counts use)
 
 One child at a time; each child is an ordinary `pytest -m gpu` run over the golden / random-shape / headline
 tests of tests/test_gpu_parity.py.
@@ -19,7 +20,7 @@ SLICE = "golden or random_shapes or headline_subset or features_only or empty_ro
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("var", ["SE3_BWD_MERGE", "SE3_NO_PAIR", "SE3CONV_FUSED"])
+@pytest.mark.parametrize("var", ["SE3_BWD_MERGE", "SE3_NO_PAIR", "SE3CONV_FUSED", "SE3_PG_SINGLE"])
 def test_variant_passes_parity_slice(var):
     env = dict(os.environ)
     env[var] = "1"
