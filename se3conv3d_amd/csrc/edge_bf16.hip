@@ -112,16 +112,30 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #ifndef SE3_PAIR_WAVES
 #define SE3_PAIR_WAVES 4
 #endif
+#ifndef SE3_PAIR_MLP_FP32
+#define SE3_PAIR_MLP_FP32 0  // 1: kernel MLP on v_mfma_f32_32x32x2_f32 (fewer VALU ops, measured 14 % slower: 0.41 vs 0.36 ms)
+#endif
 template <int CT, bool FULL, int NF>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t n_items, int fnb_shift) {
+#if !SE3_PAIR_MLP_FP32
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
+#endif
   __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kcol = lane & 31, h = lane >> 5;
+#if SE3_PAIR_MLP_FP32
+  // kernel-MLP weights as the B operand of v_mfma_f32_32x32x2_f32: lane (k = kcol, h) holds rows 2t + h of
+  // kGeluIn * [A; beta].  Exact fp32 products, and the descriptor needs no hi/lo split (5 selects instead of ~32
+  // VALU ops per chunk); the fp32 MFMA is 16x slower than the bf16 one, which the idle MFMA pipe absorbs.
+  float bm[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) bm[t] = kGeluIn * axes_ext[(2 * t + h) * kBasis + kcol];
+#else
   if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
+#endif
   const int64_t item = blockIdx.x;
   if (item >= n_items) return;
   const float rho = *rho_p;
@@ -211,6 +225,14 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       // kernel MLP + GELU for this wavefront's frame; both lane halves hold the same descriptor: half 0 feeds
       // dims 0..7, half 1 dims 8, 9
       {
+#if SE3_PAIR_MLP_FP32
+        f32x16 phi = zero16();
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const float hi_k = t < 4 ? d[2 * t + 1] : 1.0f;  // descriptor dim 9 is the constant 1 that carries beta
+          phi = mfma32(h ? hi_k : d[2 * t], bm[t], phi);
+        }
+#else
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
@@ -219,6 +241,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
         const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
         const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
         const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s * 16 < cnt && (NF == 2 || s == wv)) {

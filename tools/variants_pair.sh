@@ -1,10 +1,10 @@
-# Codegen variants of the edge kernels (run on the GPU box): SLP vectorizer (packed fp32 VALU) on/off, packed GELU.
+# A/B of edge-kernel build variants on one box (run through gpurun): two bench runs per variant.
 set -u
 run() {
   SE3_CXXFLAGS="$1" python -m se3conv3d_amd.build --force > /dev/null 2>&1
-  echo "[$1]: $(timeout -k 10 200 python tools/profile_levels.py 2>&1 | grep -A1 'level 0' | tail -1)"
+  for i in 1 2; do
+  echo "[$1]: $(timeout -k 10 200 python bench.py --no-cpu-baseline --steps 10 2>&1 | python -c 'import sys,json; j=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); s=j["roofline"]["stages_ms"]; print(j["ms_per_step"], j["single_layer"]["ms_per_step"], {k:s[k] for k in s if k.startswith("edge")})')"
+  done
 }
-run "-fno-slp-vectorize"
-run ""
-run "-DSE3_GELU_PK=1 -DSE3_PAIR_WAVES=3"
+for v in "$@"; do run "$v"; done
 python -m se3conv3d_amd.build --force > /dev/null 2>&1
