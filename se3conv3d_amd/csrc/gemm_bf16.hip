@@ -43,15 +43,18 @@ __device__ __forceinline__ u32x4 ld4_words(const uint32_t* p, int64_t avail, boo
 // FAST (k % 32 == 0, operands < 4 GB): every load is an unconditional raw buffer load whose out-of-range
 // lanes return 0 -- no branches around the loads, so the compiler keeps all three tiles in flight (with
 // guarded loads it drained vmcnt(0) after every tile and the kernel ran at half the HBM rate).
-template <int OUT_MODE, bool FAST>
+// NB = 64-column blocks per workgroup: 1 for N <= 64; 2 (128 columns, 4 column tiles per wavefront) for wider
+// outputs, where the products turn MFMA-bound (24 instead of 12 MFMAs per A fragment set and k-tile).
+template <int OUT_MODE, bool FAST, int NB>
 __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __restrict__ a,
                                                            const uint16_t* __restrict__ bt_hi,
                                                            const uint16_t* __restrict__ bt_lo, void* __restrict__ c,
                                                            int64_t m, int n, int k, int kp, int kt_per_split,
                                                            const float* __restrict__ alpha_num, float alpha_scale) {
   __shared__ __attribute__((aligned(16))) uint32_t as[2][BM][A_LD];
-  __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BN][B_LD];
-  __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BN][B_LD];
+  constexpr int BNW = BN * NB;  // columns per workgroup
+  __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BNW][B_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
   // Row blocks are taken last-to-first: A was written front-to-back by the kernel just before this one, so its tail
@@ -62,12 +65,12 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
 #else
   const int64_t m0 = (int64_t)blockIdx.x * BM;
 #endif
-  const int n0 = blockIdx.y * BN;
+  const int n0 = blockIdx.y * BNW;
   const bool a_vec = (k % 4) == 0;
   const int kt_begin = blockIdx.z * kt_per_split;
   const int nk = min(kp / BK - kt_begin, kt_per_split);  // k-tiles of this block (> 0 by construction)
 
-  struct Tile { u32x4 a0, a1, a2, a3, bh, bl; };
+  struct Tile { u32x4 a0, a1, a2, a3, bh[NB], bl[NB]; };
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint32_t*>(a), (short)0, FAST ? (int)(uint32_t)(m * k * 4) : 0, 0x00020000);
@@ -92,12 +95,16 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
       t.a2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + 2 * rstep, 0, 0));
       t.a3 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, aoff + 3 * rstep, 0, 0));
 #if SE3_GEMM_ABLATE & 8
-      t.bh = t.bl = zero4;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) t.bh[nb] = t.bl[nb] = zero4;
       return;
 #endif
-      const uint32_t boff = (uint32_t)((((int64_t)(n0 + (tid >> 2))) * kp + k0 + (tid & 3) * 8) * 2);
-      t.bh = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, boff, 0, 0));
-      t.bl = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, boff, 0, 0));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const uint32_t boff = (uint32_t)((((int64_t)(n0 + 64 * nb + (tid >> 2))) * kp + k0 + (tid & 3) * 8) * 2);
+        t.bh[nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, boff, 0, 0));
+        t.bl[nb] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, boff, 0, 0));
+      }
       return;
     }
     const uint32_t* ap = a + (m0 + row) * k + k0 + kq;
@@ -106,17 +113,23 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
     t.a1 = ld4_words(ap + (int64_t)32 * k, m0 + row + 32 < m ? avail : 0, a_vec);
     t.a2 = ld4_words(ap + (int64_t)64 * k, m0 + row + 64 < m ? avail : 0, a_vec);
     t.a3 = ld4_words(ap + (int64_t)96 * k, m0 + row + 96 < m ? avail : 0, a_vec);
-    const int nl = tid >> 2, kq8 = (tid & 3) * 8;
-    const bool ok = n0 + nl < n;
-    const int64_t boff = (int64_t)(ok ? n0 + nl : 0) * kp + k0 + kq8;
-    const u32x4 vh = *reinterpret_cast<const u32x4*>(bt_hi + boff), vl = *reinterpret_cast<const u32x4*>(bt_lo + boff);
-    t.bh = ok ? vh : zero4;
-    t.bl = ok ? vl : zero4;
+    const int kq8 = (tid & 3) * 8;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int nl = 64 * nb + (tid >> 2);
+      const bool ok = n0 + nl < n;
+      const int64_t boff = (int64_t)(ok ? n0 + nl : 0) * kp + k0 + kq8;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(bt_hi + boff), vl = *reinterpret_cast<const u32x4*>(bt_lo + boff);
+      t.bh[nb] = ok ? vh : zero4;
+      t.bl[nb] = ok ? vl : zero4;
+    }
   };
-  f32x16 acc0 = zero16(), acc1 = zero16();
+  f32x16 acc[2 * NB];
+#pragma unroll
+  for (int c = 0; c < 2 * NB; ++c) acc[c] = zero16();
   auto store_tile = [&](const Tile& t, int buf) {
 #if SE3_GEMM_ABLATE & 2
-    acc0[0] += __uint_as_float(t.a0[0] ^ t.a1[1] ^ t.a2[2] ^ t.a3[3] ^ t.bh[0] ^ t.bl[1]);
+    acc[0][0] += __uint_as_float(t.a0[0] ^ t.a1[1] ^ t.a2[2] ^ t.a3[3] ^ t.bh[0][0] ^ t.bl[0][1]);
     return;
 #endif
     const int row = tid >> 3, kq = (tid & 7) * 4;
@@ -124,9 +137,12 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
     *reinterpret_cast<u32x4*>(&as[buf][row + 32][kq]) = t.a1;
     *reinterpret_cast<u32x4*>(&as[buf][row + 64][kq]) = t.a2;
     *reinterpret_cast<u32x4*>(&as[buf][row + 96][kq]) = t.a3;
-    const int nl = tid >> 2, kq8 = (tid & 3) * 8;
-    *reinterpret_cast<u32x4*>(&bsh[buf][nl][kq8]) = t.bh;
-    *reinterpret_cast<u32x4*>(&bsl[buf][nl][kq8]) = t.bl;
+    const int kq8 = (tid & 3) * 8;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      *reinterpret_cast<u32x4*>(&bsh[buf][64 * nb + (tid >> 2)][kq8]) = t.bh[nb];
+      *reinterpret_cast<u32x4*>(&bsl[buf][64 * nb + (tid >> 2)][kq8]) = t.bl[nb];
+    }
   };
 
   auto compute = [&](int buf) {
@@ -140,12 +156,12 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
       const u32x4 w1 = *reinterpret_cast<const u32x4*>(&as[buf][wave * 32 + rl][kk + 4]);
       const u32x4 a_hi = {pair_hi(w0[0], w0[1]), pair_hi(w0[2], w0[3]), pair_hi(w1[0], w1[1]), pair_hi(w1[2], w1[3])};
       const u32x4 a_lo = {pair_lo(w0[0], w0[1]), pair_lo(w0[2], w0[3]), pair_lo(w1[0], w1[1]), pair_lo(w1[2], w1[3])};
-      const u32x4 b0h = *reinterpret_cast<const u32x4*>(&bsh[buf][rl][kk]);
-      const u32x4 b0l = *reinterpret_cast<const u32x4*>(&bsl[buf][rl][kk]);
-      const u32x4 b1h = *reinterpret_cast<const u32x4*>(&bsh[buf][32 + rl][kk]);
-      const u32x4 b1l = *reinterpret_cast<const u32x4*>(&bsl[buf][32 + rl][kk]);
-      acc0 = mfma_bf16x3(a_hi, a_lo, b0h, b0l, acc0);
-      acc1 = mfma_bf16x3(a_hi, a_lo, b1h, b1l, acc1);
+#pragma unroll
+      for (int c = 0; c < 2 * NB; ++c) {
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&bsh[buf][32 * c + rl][kk]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&bsl[buf][32 * c + rl][kk]);
+        acc[c] = mfma_bf16x3(a_hi, a_lo, bh, bl, acc[c]);
+      }
     }
   };
   // k-tile kt lives in register set (kt mod DEPTH) until it is written to LDS buffer (kt & 1).  The kernel's
@@ -194,15 +210,16 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   for (int r = 0; r < 16; ++r) {
     const int64_t gr = m0 + wave * 32 + acc_row(r, h);
     if (gr < m) {
-      const int gc = n0 + rl;
-      if constexpr (OUT_MODE == 1) {
-        uint32_t* out = static_cast<uint32_t*>(c);
-        if (gc < n) out[gr * n + gc] = split_pack(alpha * acc0[r]);
-        if (gc + 32 < n) out[gr * n + gc + 32] = split_pack(alpha * acc1[r]);
-      } else {
-        float* out = static_cast<float*>(c) + (OUT_MODE == 2 ? (int64_t)blockIdx.z * m * n : 0);
-        if (gc < n) out[gr * n + gc] = alpha * acc0[r];
-        if (gc + 32 < n) out[gr * n + gc + 32] = alpha * acc1[r];
+#pragma unroll
+      for (int ct = 0; ct < 2 * NB; ++ct) {
+        const int gc = n0 + 32 * ct + rl;
+        if (gc >= n) continue;
+        if constexpr (OUT_MODE == 1) {
+          static_cast<uint32_t*>(c)[gr * n + gc] = split_pack(alpha * acc[ct][r]);
+        } else {
+          float* out = static_cast<float*>(c) + (OUT_MODE == 2 ? (int64_t)blockIdx.z * m * n : 0);
+          out[gr * n + gc] = alpha * acc[ct][r];
+        }
       }
     }
   }
@@ -527,8 +544,13 @@ int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, u
 
 // Split the k loop over grid.z when the row blocks alone cannot fill the chip (small hierarchy levels):
 // a block's k loop is serial, so 64 k-tiles on a handful of blocks would cost ~100 us whatever M is.
+// 64-column blocks per workgroup (template NB): 128 columns pay when the k loop is long (T W, U W': k = C*K); for the
+// short-k, wide-n products (grad_T beyond the strip kernel's k <= 64) the narrow tile keeps more blocks in flight
+int gemm_nn_bf16_col_blocks(int n, int k) { return n > BN && k >= 512 ? 2 : 1; }
+
 int gemm_nn_bf16_splits(int64_t m, int n, int k) {
-  const int64_t blocks = ((m + BM - 1) / BM) * ((n + BN - 1) / BN);
+  const int bnw = BN * gemm_nn_bf16_col_blocks(n, k);
+  const int64_t blocks = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
   const int nkt = (k + BK - 1) / BK;
   if (blocks >= 512 || nkt < 8) return 1;
   int64_t s = (1024 + blocks - 1) / blocks;
@@ -570,17 +592,19 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
   int splits = split_ws ? gemm_nn_bf16_splits(m, n, k) : 1;
   const int per = (nkt + splits - 1) / splits;
   splits = (nkt + per - 1) / per;
-  const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
+  const int nbw = gemm_nn_bf16_col_blocks(n, k);
+  const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN * nbw - 1) / (BN * nbw)), (unsigned)splits);
   const bool fast = (k % 32 == 0) && (m * (int64_t)k * 4 < (1ll << 32)) && ((int64_t)n * kp * 2 < (1ll << 32)) &&
-                    ((m + BM) * (int64_t)k * 4 < (1ll << 32));
-#define SE3_NN(MODE, OUT)                                                                                               \
-  do {                                                                                                                  \
-    if (fast)                                                                                                           \
-      hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, true>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), m, \
-                         n, k, kp, per, alpha_num, alpha_scale);                                                        \
-    else                                                                                                                \
-      hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, false>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), \
-                         m, n, k, kp, per, alpha_num, alpha_scale);                                                     \
+                    ((m + BM) * (int64_t)k * 4 < (1ll << 32)) && ((int64_t)(n + 128) * kp * 2 < (1ll << 32));
+#define SE3_NN_LAUNCH(MODE, F, NBV, OUT)                                                                                  \
+  hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, F, NBV>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), m, n, k, \
+                     kp, per, alpha_num, alpha_scale)
+#define SE3_NN(MODE, OUT)                                      \
+  do {                                                         \
+    if (fast && nbw == 2) SE3_NN_LAUNCH(MODE, true, 2, OUT);   \
+    else if (fast) SE3_NN_LAUNCH(MODE, true, 1, OUT);          \
+    else if (nbw == 2) SE3_NN_LAUNCH(MODE, false, 2, OUT);     \
+    else SE3_NN_LAUNCH(MODE, false, 1, OUT);                   \
   } while (0)
   if (splits > 1) {
     SE3_NN(2, split_ws);
@@ -598,6 +622,7 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
     SE3_NN(0, c);
   }
 #undef SE3_NN
+#undef SE3_NN_LAUNCH
   return check_launch();
 }
 
