@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #ifndef SE3_PAIR_WAVES
 #define SE3_PAIR_WAVES 4
 #endif
+#ifndef SE3_PAIR_ABLATE
+#define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi
+#endif
 #ifndef SE3_PAIR_MLP_FP32
 #define SE3_PAIR_MLP_FP32 0  // 1: kernel MLP on v_mfma_f32_32x32x2_f32 (fewer VALU ops, measured 14 % slower: 0.41 vs 0.36 ms)
 #endif
@@ -136,22 +139,25 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
 #endif
-  const int64_t item = blockIdx.x;
-  if (item >= n_items) return;
   const float rho = *rho_p;
   const int row_bytes = C * 4;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const __amdgpu_buffer_rsrc_t ctrg_rs = buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64);
   // NF = 2: item = two consecutive frames of a point, wavefront v owns frame a0 + v.  NF = 1: item = one row (any
   // F); both wavefronts hold that frame, wavefront v does the GELU of k-step v only (16 of the 32 frame-edges).
   const int groups = g.f_ctr / NF;
+  const int hb = 16 * h;
+  int buf = 0;
+  // Persistent workgroups (SE3_PAIR_PERSIST): the block walks items blockIdx.x, blockIdx.x + gridDim.x, ... so that
+  // the kernel prologue (arguments, descriptors, MLP weights into LDS) is paid once per block, not once per item.
+  for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
   const int64_t ctr = item / groups;
   const int a0 = (int)(item - ctr * groups) * NF;
-  const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
-  const int n_total = (g.ends[ctr] - start) * g.f_nb;
-  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const int start = (SE3_PAIR_ABLATE & 32) ? (int)(ctr * 31) : (ctr > 0 ? g.ends[ctr - 1] : 0);
+  const int n_total = (SE3_PAIR_ABLATE & 32) ? 31 * g.f_nb : (g.ends[ctr] - start) * g.f_nb;
   float yc[3], rc[9];
-  load_geom_record(buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64), (int)(ctr * g.f_ctr + a0 + (NF == 2 ? wv : 0)), yc, rc);  // this wavefront's frame
-  const int hb = 16 * h;
+  load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (NF == 2 ? wv : 0)), yc, rc);  // this wavefront's frame
 
   // Neighbour ids are fetched two chunks ahead and the geometry records one chunk ahead, so that no load result is
   // needed in the chunk that issues it (the dependent chain ids -> record/feature rows costs one memory latency
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   auto nbr_of = [&](int c0) {
     const int fe = min(c0 + kcol, n_total - 1);
     const int e = start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+    if (SE3_PAIR_ABLATE & 16) return (int)(((unsigned)e * 2654435761u) % (unsigned)g.n_nb);  // no id load
     return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
   };
   auto row_of = [&](int nb, int c0) {
@@ -166,7 +173,6 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
     return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
   };
 
-  int buf = 0;
   for (int cbase = 0; cbase < C; cbase += 64 * CT) {
     // this wavefront aggregates channels cbase + 32*(CT*wv + t) + kcol, t = 0..CT-1
     int cb4[CT];
@@ -212,7 +218,8 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
           const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
 #pragma unroll
           for (int t = 0; t < CT; ++t)
-            fw[t][s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, ch_ok[t] ? src_off + cb4[t] : kOobOffset, 0, 0);
+            fw[t][s][j] = (SE3_PAIR_ABLATE & 2) ? (uint32_t)(src_off + cb4[t]) * 2654435761u
+                                                : __builtin_amdgcn_raw_buffer_load_b32(feat_rs, ch_ok[t] ? src_off + cb4[t] : kOobOffset, 0, 0);
         }
       load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       q_a = q_b;
@@ -247,9 +254,14 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
           if (s * 16 < cnt && (NF == 2 || s == wv)) {
             float pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
+            for (int j = 0; j < 8; ++j) pv[j] = (SE3_PAIR_ABLATE & 1) ? phi[8 * s + j] : gelu_scaled(phi[8 * s + j]);
             u32x4 b_hi, b_lo;
-            frags_from_floats(pv, b_hi, b_lo);
+            if (SE3_PAIR_ABLATE & 8) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) b_hi[i] = __float_as_uint(pv[2 * i]), b_lo[i] = __float_as_uint(pv[2 * i + 1]);
+            } else {
+              frags_from_floats(pv, b_hi, b_lo);
+            }
             *reinterpret_cast<u32x4*>(&lds_phi[buf][NF == 2 ? wv : 0][s][0][lane][0]) = b_hi;
             *reinterpret_cast<u32x4*>(&lds_phi[buf][NF == 2 ? wv : 0][s][1][lane][0]) = b_lo;
           }
@@ -286,11 +298,13 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
         for (int r = 0; r < 16; r += 2) {
           uint32_t w0, w1;
           split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
+          if ((SE3_PAIR_ABLATE & 4) && (w0 ^ w1) != 0x12345678u) continue;
           if (FULL || ch0 + acc_row(r, h) < C) t_row[acc_row(r, h) * kBasis + kcol] = w0;
           if (FULL || ch0 + acc_row(r + 1, h) < C) t_row[acc_row(r + 1, h) * kBasis + kcol] = w1;
         }
       }
     if (cbase + 64 * CT < C) __syncthreads();  // the next pass reuses the phi buffers from their start
+  }
   }
 }
 
@@ -702,7 +716,13 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     // a 128-thread workgroup per two frames of a point (even F) or per single row (odd F, e.g. ScanNet's F = 1)
     const bool two = g.f_ctr % 2 == 0;
     const int64_t pair_items = two ? rows / 2 : rows;
-    const dim3 pgrid((unsigned)pair_items), pblock(128);
+    // persistent blocks: enough to fill every CU at the kernel's occupancy, each walking a strided set of items
+    static const int persist = [] {
+      const char* e = getenv("SE3_PAIR_PERSIST");
+      return e ? atoi(e) : 0;
+    }();
+    const int64_t pblocks = persist > 0 && pair_items > persist ? persist : pair_items;
+    const dim3 pgrid((unsigned)pblocks), pblock(128);
 #define SE3_PAIR(CT, FULL)                                                                                              \
   do {                                                                                                                  \
     if (two)                                                                                                            \
