@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 template <int CT, bool FULL, int NF>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
-    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t n_items, int fnb_shift) {
+    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift) {
 #if !SE3_PAIR_MLP_FP32
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
 #endif
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   int buf = 0;
   // Persistent workgroups (SE3_PAIR_PERSIST): the block walks items blockIdx.x, blockIdx.x + gridDim.x, ... so that
   // the kernel prologue (arguments, descriptors, MLP weights into LDS) is paid once per block, not once per item.
-  for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+  for (int64_t item = item_lo + blockIdx.x; item < n_items; item += gridDim.x) {  // items item_lo .. n_items-1
   const int64_t ctr = item / groups;
   const int a0 = (int)(item - ctr * groups) * NF;
   const int start = (SE3_PAIR_ABLATE & 32) ? (int)(ctr * 31) : (ctr > 0 ? g.ends[ctr - 1] : 0);
@@ -698,10 +698,19 @@ int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t st
   return check_launch();
 }
 
+bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels) {
+  return channels >= 64 && getenv("SE3_NO_PAIR") == nullptr;
+}
+
+// row_lo / row_hi (multiples of 2 for even F; < 0: everything): only the rows in that range are produced -- the
+// wave-pair kernel supports it (edge_t_bf16_row_ranges), which lets the caller interleave producer and consumer
+// launches over slices of the rows
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
-                       const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream) {
+                       const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream, int64_t row_lo,
+                       int64_t row_hi) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (rows == 0) return SE3_OK;
+  if (row_lo >= 0 && !edge_t_bf16_row_ranges(g, channels)) return SE3_ERR_UNSUPPORTED;
   // 32-bit byte offsets into the gathered operand; kOobOffset must lie beyond it
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
@@ -721,16 +730,21 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
       const char* e = getenv("SE3_PAIR_PERSIST");
       return e ? atoi(e) : 0;
     }();
-    const int64_t pblocks = persist > 0 && pair_items > persist ? persist : pair_items;
+    const int per = two ? 2 : 1;
+    const int64_t item_lo = row_lo >= 0 ? row_lo / per : 0;
+    const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
+    const int64_t n_range = item_hi - item_lo;
+    if (n_range <= 0) return SE3_OK;
+    const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
 #define SE3_PAIR(CT, FULL)                                                                                              \
   do {                                                                                                                  \
     if (two)                                                                                                            \
       hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 2>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, t_out, pair_items, shift);                                                      \
+                         axes_ext, rho, t_out, item_lo, item_hi, shift);                                                \
     else                                                                                                                \
       hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 1>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, t_out, pair_items, shift);                                                      \
+                         axes_ext, rho, t_out, item_lo, item_hi, shift);                                                \
   } while (0)
     if (channels == 64) SE3_PAIR(1, true);
     else if (channels % 128 == 0) SE3_PAIR(2, true);
