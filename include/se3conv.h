@@ -221,7 +221,8 @@ int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, i
  * only prints wall-clock per batch, tasks/SemSeg/train_dfaust_rot.py:239-296).  When enabled, every
  * kernel launch of the fused operator is bracketed by hipEvents on its own launch stream; read
  * accumulates milliseconds and launch counts per stage tag ("edge_t_fwd", "gemm_out", "gemm_gradT",
- * "edge_param_grad", "gemm_gradW", "edge_t_transposed", "gemm_gradX", "edge_t_recompute").
+ * "edge_param_grad", "gemm_gradW", "edge_t_transposed", "gemm_gradX", "edge_t_recompute", "prep"; the opt-in merged
+ * backward adds "gemm_H" / "edge_bwd", the grid kNN "knn_sort" / "knn_cells" / "knn_fallback").
  * Off by default; this switch is the library's only process-wide state.
  * ------------------------------------------------------------------------------------------- */
 int se3_profile_enable(int on);

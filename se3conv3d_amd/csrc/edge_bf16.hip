@@ -7,8 +7,17 @@
 // 8s..8s+7 of the MLP result, i.e. slot (h, j) <-> frame-edge acc_row(8s + j, h); the A operand
 // (gathered features) is loaded in exactly that order, so no lane ever moves data.
 //
-// Gathered operands (features, grad_out) are read as packed words (hi << 16 | lo) prepared by
-// split_pack_kernel; intermediates (T, grad_T, U) are written as packed words too.
+// Gathered operands (features, grad_out) are read as packed words (hi << 16 | lo) prepared by the batched
+// preparation launch (prep.hip), geometry as 64-byte records; intermediates (T, grad_T, U) are written as packed
+// words too.  The bf16 kernels evaluate GELU in its scaled form (common.h: gelu_scaled): T and U hold kGeluOut times
+// the reference's values, the consuming GEMM divides it out.
+//
+// Kernels in this file:
+//   edge_t_pair_bf16_kernel<CT, FULL, NF>   default for C >= 64: a wave pair per item (two frames, or one row for odd F)
+//   edge_t_bf16_kernel<VW, FC, FULL>        single wavefront per item (edge_bf16_body.h), used for C < 64
+//   edge_t_stream_bf16_kernel               persistent variant of the latter (SE3_STREAM, not faster)
+//   edge_param_grad_bf16_v2_kernel<CH16, NFR>  parameter gradients, 64-channel blocks over blockIdx.y
+//   edge_param_grad_bf16_kernel             generic fallback (channel counts that are not multiples of 16)
 #include <cstdlib>
 
 #include "common.h"
