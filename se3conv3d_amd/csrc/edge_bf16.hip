@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #ifndef SE3_PAIR_WAVES
 #define SE3_PAIR_WAVES 4
 #endif
+#ifndef SE3_PG_ABLATE
+#define SE3_PG_ABLATE 0  // diagnostic builds of edge_param_grad_bf16_v2 (wrong results): 1 no GELU', 2 no feature gather, 4 no grad_T loads, 8 no d[A;beta] product
+#endif
 #ifndef SE3_PAIR_ABLATE
 #define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi
 #endif
@@ -517,7 +520,8 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
       for (int st = 0; st < CH16; ++st)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          gw[a][st][j] = c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u;
+          gw[a][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
+                         : (c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u);
     }
     int q_a = row_of(nb_a, 0);
     float xn_nx[3], rn_nx[9];
@@ -550,6 +554,11 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
 #pragma unroll
       for (int st = 0; st < CH16; ++st) {
         const int voff = c_off + 16 * st < row_ch ? qoff + (16 * st + 8 * h) * 4 : kOobOffset;  // past the row: zeros
+        if (SE3_PG_ABLATE & 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) fw[st][j] = (uint32_t)(voff + j) * 2654435761u;
+          continue;
+        }
         const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
         const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff + 16, 0, 0);
         fw[st][0] = v0[0], fw[st][1] = v0[1], fw[st][2] = v0[2], fw[st][3] = v0[3];
@@ -609,7 +618,8 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float y;
-          gelu_scaled_grad(pre[r], y, dyv[a][r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
+          if (SE3_PG_ABLATE & 1) dyv[a][r] = pre[r];
+          else gelu_scaled_grad(pre[r], y, dyv[a][r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
         }
       }
       // ... then gphi = F gT on the gathered rows, gpre = gphi * GELU', and the d[A;beta] product
@@ -628,6 +638,11 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+          if (SE3_PG_ABLATE & 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dacc[j] += gphi[8 * s + j] * dyv[a][8 * s + j];
+            continue;
+          }
           if (s * 16 < cnt) {
             float gp[8];
             uint32_t wd[8];
