@@ -184,10 +184,9 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=[f"seed{c[0]}" for c in CASES])
-def test_random_shapes_against_oracle(case, amd):
-    seed, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches = case
-    c = random_case(seed, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches)
+def run_case_against_oracle(c, f_in, f_out, amd):
+    """Ball query + operator forward/backward of one random case on the GPU against the oracle: returns the relative
+    errors of out / dx / dA / dbeta / dW (also used by tools/fuzz_parity.py) plus the geometry and reference edges."""
     nb_ref, ends_ref = O.ball_query(c["pts_in"], c["pts_out"], c["bid_in"], c["bid_out"], c["r"])
     nb, ends = amd.ops.ball_query(c["pts_in"].to(DEV), c["pts_out"].to(DEV), c["bid_in"].to(DEV), c["bid_out"].to(DEV), c["r"])
     assert torch.equal(ends.cpu(), ends_ref)
@@ -201,11 +200,18 @@ def test_random_shapes_against_oracle(case, amd):
     a, b, w = (c[k].to(DEV).requires_grad_(True) for k in ("a", "b", "w"))
     out = amd.SE3ConvFunction.apply(x, a, b, w, geom, rho, nu)
     out.backward(c["go"].to(DEV))
-    assert rel_err(out, out_r) < tol(amd)
-    assert rel_err(x.grad, dx_r) < tol(amd)
-    assert rel_err(a.grad, da_r) < tol(amd)
-    assert rel_err(b.grad, db_r) < tol(amd)
-    assert rel_err(w.grad, dw_r) < tol(amd)
+    errs = {"out": rel_err(out, out_r), "dx": rel_err(x.grad, dx_r), "dA": rel_err(a.grad, da_r),
+            "dbeta": rel_err(b.grad, db_r), "dW": rel_err(w.grad, dw_r)}
+    return errs, geom, nb_ref
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"seed{c[0]}" for c in CASES])
+def test_random_shapes_against_oracle(case, amd):
+    seed, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches = case
+    c = random_case(seed, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches)
+    errs, geom, nb_ref = run_case_against_oracle(c, f_in, f_out, amd)
+    for key, err in errs.items():
+        assert err < tol(amd), (key, err)
 
     # the source-major edge list is a permutation of the edges, grouped by source, samples ascending
     ts, te = geom.transpose()

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Random-shape parity sweep (GPU operator vs the fp64 oracle): frames, channel counts, degrees, batch counts and
+input/output cloud sizes drawn at random.  usage: tools/fuzz_parity.py [n_cases] [seed]"""
+import os, sys, random
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import se3conv3d_amd as amd
+from oracle import se3conv_oracle as O
+import test_gpu_parity as T
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+worst = 0.0
+for i in range(n_cases):
+    f_in, f_out = rng.choice([1, 2, 3, 4]), rng.choice([1, 2, 3, 4])
+    c_in = rng.choice([1, 3, 8, 16, 24, 32, 48, 64, 80, 96, 128, 160, 192, 256, 320])
+    c_out = rng.choice([5, 13, 32, 64, 96, 128, 192, 256])
+    n_in = rng.choice([97, 200, 333, 500])
+    n_out = rng.choice([None, None, 64, 150, 400])
+    k_deg = rng.choice([2, 8, 16, 33, 50])
+    batches = rng.choice([1, 2, 3])
+    if n_out is None and f_in != f_out and rng.random() < 0.5:
+        f_out = f_in
+    c = T.random_case(100 + i, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches)
+    for prec in ("bf16x3", "fp32"):
+        amd.set_precision(prec)
+        errs, _, _ = T.run_case_against_oracle(c, f_in, f_out, amd)
+        m = max(errs.values())
+        worst = max(worst, m / T.TOLS[prec])
+        flag = "" if m < T.TOLS[prec] else "   <-- FAIL"
+        print(f"case {i:2d} {prec:6s} F {f_in}->{f_out} C {c_in:3d}->{c_out:3d} n {n_in}->{n_out} k~{k_deg:2d} b{batches}: "
+              f"max rel err {m:.2e}{flag}")
+print(f"worst error / tolerance = {worst:.3f}")
+sys.exit(0 if worst < 1.0 else 1)
