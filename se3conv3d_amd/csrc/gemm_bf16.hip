@@ -9,6 +9,8 @@
 //
 // These are streaming kernels: A (1 GB at the headline shape) is read once, so they are HBM-bound
 // as long as the MFMA side reaches ~1/3 of its peak.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace se3 {
@@ -552,8 +554,9 @@ int gemm_nn_bf16_splits(int64_t m, int n, int k) {
   const int bnw = BN * gemm_nn_bf16_col_blocks(n, k);
   const int64_t blocks = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
   const int nkt = (k + BK - 1) / BK;
-  if (blocks >= 512 || nkt < 8) return 1;
-  int64_t s = (1024 + blocks - 1) / blocks;
+  constexpr int target = 512;  // workgroups aimed at (two per CU); 1024 and 256 measured slower on the 9 k-point level
+  if (blocks >= target / 2 || nkt < 8) return 1;
+  int64_t s = (target + blocks - 1) / blocks;
   if (s > nkt / 4) s = nkt / 4;  // >= 4 k-tiles per split
   return (int)(s < 1 ? 1 : s);
 }
