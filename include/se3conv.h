@@ -58,8 +58,9 @@ typedef struct se3conv_shape {
  *   BF16X3 : every fp32 operand x is split into hi = bf16(x), lo = bf16(x - hi) and every product is
  *            evaluated as hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_bf16 with fp32 accumulate
  *            (~1e-5 relative to the oracle; the north-star tolerance is 1e-4; 16x the MFMA rate at
- *            3 products).  `t_save` is then an opaque buffer of the same size (packed hi/lo words)
- *            and must be passed back to se3conv_bwd with the same precision. */
+ *            3 products).  `t_save` is then an opaque buffer of the same size (packed hi/lo words, or
+ *            3-byte rows -- the library picks per shape) and must be passed back to se3conv_bwd
+ *            with the same precision, shape and process environment. */
 #define SE3_PRECISION_FP32 0
 #define SE3_PRECISION_BF16X3 1
 

@@ -381,6 +381,16 @@ extern "C" int se3_feat_basis_proj_grad(const float* basis, const float* feat, c
   return check_launch();
 }
 
+// The row-sized intermediates (T, and U of the feature gradient) are kept in the 3-byte row format of common.h when
+// the wave-pair edge kernel produces them and the buffer-load GEMMs consume them (SE3_NO_T24=1: packed words
+// everywhere).  tn_cols = the column count of the TN product that also reads the rows (0: none).
+static bool t24_rows(const EdgeGeom& g, int channels, int64_t rows, int tn_cols) {
+  static const bool on = getenv("SE3_NO_T24") == nullptr;
+  return on && kBasis == 32 && channels % 2 == 0 && edge_t_bf16_row_ranges(g, channels) &&
+         2 * rows * (int64_t)channels * kBasis * 4 < (1ll << 32) - 64 && tn_cols % 4 == 0 &&
+         2 * rows * (int64_t)(tn_cols > 0 ? tn_cols : 1) * 4 < (1ll << 32) - 64;
+}
+
 extern "C" size_t se3conv_fwd_workspace_bytes(const se3conv_shape* s, int save_t) {
   return shape_ok(s) ? fwd_layout(s, save_t).total : 0;
 }
@@ -417,6 +427,8 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   const float inv_phi = inv_fin / kGeluOut;  // the bf16 edge kernels produce kGeluOut * phi (gelu_scaled)
+  const bool fused = conv_fused_bf16_supported(g, s->c_in);
+  const bool t24 = !fused && t24_rows(g, s->c_in, rows_out, s->c_out);  // se3conv_bwd decides the same way
   {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
@@ -425,16 +437,18 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
     pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
     pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     pb.split(feat, featpk, s->n_in * s->f_in * s->c_in);
-    pb.weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo);
+    pb.weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, nullptr, 1.0f, false, t24);
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
   }
-  if (conv_fused_bf16_supported(g, s->c_in))  // edge phase + contraction in one launch; T only if the caller wants it
+  if (fused)  // edge phase + contraction in one launch; T only if the caller wants it
     return launch_conv_fused_bf16("conv_fused_fwd", g, featpk, s->n_in * s->f_in, axes_ext, rho, bt_hi, bt_lo, s->c_out,
                                   out, (uint32_t*)t_save, nu, inv_phi, stream);
-  if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream)) return rc;
+  if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream,
+                                  -1, -1, t24))
+    return rc;
   return launch_gemm_nn_bf16("gemm_out", (const uint32_t*)t, bt_hi, bt_lo, out, false, rows_out, s->c_out, ck,
-                             (float*)(ws + l.split), nu, inv_phi, stream);
+                             (float*)(ws + l.split), nu, inv_phi, stream, t24);
 }
 
 extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
@@ -532,6 +546,8 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   const bool feat_branch = want_feat && rows_in > 0;
   const bool merged = feat_branch && want_params && (grad_axes || grad_biases) && rows_out > 0 && l.big_u != 0 &&
                       edge_bwd_pair_bf16_supported(s->f_in, s->c_out);
+  const bool t24_t = !conv_fused_bf16_supported(g, s->c_in) && t24_rows(g, s->c_in, rows_out, s->c_out);  // as se3conv_fwd
+  const bool t24_u = feat_branch && !merged && !conv_fused_bf16_supported(gt, s->c_out) && t24_rows(gt, s->c_out, rows_in, 0);
   const bool strip_t = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);            // grad_T = g W^T
   const bool strip_h = gemm_strip_bf16_applicable(rows_in, s->c_out * kb, s->c_in);   // H = f W''
   {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
@@ -542,7 +558,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
     pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     pb.split(grad_out, gpk, rows_out * s->c_out);
-    if (feat_branch) pb.weights(conv_weights, s->c_in, kb, s->c_out, 2, bx_hi, bx_lo);
+    if (feat_branch) pb.weights(conv_weights, s->c_in, kb, s->c_out, 2, bx_hi, bx_lo, nullptr, 1.0f, false, t24_u);
     if (want_params) {
       pb.split(feat, featpk, rows_in * s->c_in);
       // alpha = nu/F_in is folded into these weights (one multiply per weight instead of one per grad_T element)
@@ -558,11 +574,12 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     const uint32_t* t = (const uint32_t*)t_save;
     if (!t) {
       uint32_t* tt = (uint32_t*)(ws + l.t);
-      if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, rows_in, axes_ext, rho, tt, stream)) return rc;
+      if (int rc = launch_edge_t_bf16("edge_t_recompute", g, featpk, s->c_in, rows_in, axes_ext, rho, tt, stream, -1, -1, t24_t))
+        return rc;
       t = tt;
     }
     return launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck, s->c_out, nu,
-                               inv_phi, stream);
+                               inv_phi, stream, t24_t);
   };
 
   // Opt-in (SE3_BWD_MERGE): one walk over the transposed graph yields U (feature gradient) and d[A;beta]; grad_T and
@@ -609,9 +626,10 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                                           nullptr, nu, inv_phi, fs))
         return rc;
     } else {
-      if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs)) return rc;
+      if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs, -1, -1, t24_u))
+        return rc;
       if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
-                                       fsplit, nu, inv_phi, fs))
+                                       fsplit, nu, inv_phi, fs, t24_u))
         return rc;
     }
   }

@@ -67,6 +67,32 @@ __device__ __forceinline__ void split_pack2(float x0, float x1, uint32_t& w0, ui
   w0 = pair_lo(lo, hi);
   w1 = pair_hi(lo, hi);
 }
+// ---- 3-byte row format ("T24", opt-in) of the row-sized intermediates T and U ---------------------------------
+// An element keeps the upper 24 bits of its fp32 value (rounded): hi = bits 31..16 (a truncated bf16), lo = bits
+// 15..8.  hi + lo reproduce 16 significant bits; the MFMA operands are a_hi = hi (as bf16) and
+// a_lo = bf16(value24 - hi), exact because that difference has at most 8 significant bits.
+// Row layout for C channels x 32 basis functions (k' order = channel pair, basis, channel parity, so that the two
+// values a lane of the edge kernels owns -- channels c and c+1 of one basis function -- are one word + one half-word):
+//   bytes [0, 2*C*32)        uint16 hi[(c/2)*64 + k*2 + (c&1)]
+//   bytes [2*C*32, 3*C*32)   uint8  lo[same index]
+__host__ __device__ inline int64_t t24_row_bytes(int channels) { return (int64_t)channels * kBasis * 3; }
+// position kq in a T24 row -> the index c*32 + k the fp32 / packed-word rows use
+__host__ __device__ inline int t24_k_of(int kq) { return ((((kq >> 6) << 1) | (kq & 1)) << 5) + ((kq >> 1) & 31); }
+__device__ __forceinline__ void t24_pack2(float x0, float x1, uint32_t& hi_pair, uint32_t& lo_pair) {
+  const uint32_t u0 = __float_as_uint(x0) + 0x80u, u1 = __float_as_uint(x1) + 0x80u;  // round to 24 bits
+  hi_pair = __builtin_amdgcn_perm(u1, u0, 0x07060302u);  // u0[31:16] | u1[31:16] << 16
+  lo_pair = __builtin_amdgcn_perm(u1, u0, 0x0c0c0501u);  // u0[15:8] | u1[15:8] << 8
+}
+// hi pair word H (two bf16) + the word L holding their lo bytes at byte positions B0, B0+1 -> the lo fragment word
+template <int B0>
+__device__ __forceinline__ uint32_t t24_lo_word(uint32_t H, uint32_t L) {
+  const uint32_t w0 = __builtin_amdgcn_perm(H, L, 0x0504000cu | ((uint32_t)B0 << 8));
+  const uint32_t w1 = __builtin_amdgcn_perm(H, L, 0x0706000cu | ((uint32_t)(B0 + 1) << 8));
+  const float l0 = __uint_as_float(w0) - __uint_as_float(H << 16);
+  const float l1 = __uint_as_float(w1) - __uint_as_float(H & 0xffff0000u);
+  return cvt_pk_bf16(l0, l1);
+}
+
 // 8 packed words -> the two 8 x bf16 MFMA fragments
 __device__ __forceinline__ void frags_from_words(const uint32_t w[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
@@ -271,7 +297,7 @@ int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t st
 bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels);
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream,
-                       int64_t row_lo = -1, int64_t row_hi = -1);
+                       int64_t row_lo = -1, int64_t row_hi = -1, bool t24 = false);
 int edge_param_grad_bf16_channel_blocks(int channels);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
@@ -365,7 +391,7 @@ struct PrepBatch {
   void geometry(const float* pts, const float* frames, int64_t n, int f, float* records);
   void split(const float* src, uint32_t* dst, int64_t n);
   void weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
-               const float* scale_num = nullptr, float scale = 1.0f, bool frag_layout = false);
+               const float* scale_num = nullptr, float scale = 1.0f, bool frag_layout = false, bool perm24 = false);
   int launch(hipStream_t stream);
 };
 
@@ -375,9 +401,9 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
                            int64_t m, int n, int k, hipStream_t stream);
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
-                        float alpha_scale, hipStream_t stream);
+                        float alpha_scale, hipStream_t stream, bool a24 = false);
 size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k);
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
-                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream);
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24 = false);
 
 }  // namespace se3

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 template <int CT, bool FULL, int NF>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
-    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift) {
+    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift,
+    int t24) {
 #if !SE3_PAIR_MLP_FP32
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
 #endif
@@ -305,6 +306,20 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int ch0 = cbase + 32 * (CT * wv + t);
+        if (t24) {  // 3-byte rows (common.h): channels c, c+1 of this lane = one hi word + one lo half-word
+          char* row = reinterpret_cast<char*>(t_out) + (item * NF + a) * t24_row_bytes(C);
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int ch = ch0 + acc_row(r, h);  // even
+            if (!FULL && ch >= C) continue;
+            uint32_t hp, lp;
+            t24_pack2(acc[a][t][r], (FULL || ch + 1 < C) ? acc[a][t][r + 1] : 0.f, hp, lp);
+            const int idx = (ch >> 1) * kBasis + kcol;
+            reinterpret_cast<uint32_t*>(row)[idx] = hp;
+            reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2)[idx] = (uint16_t)lp;
+          }
+          continue;
+        }
         uint32_t* t_row = t_out + ((item * NF + a) * (int64_t)C + ch0) * kBasis;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
@@ -731,10 +746,11 @@ bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels) {
 // launches over slices of the rows
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream, int64_t row_lo,
-                       int64_t row_hi) {
+                       int64_t row_hi, bool t24) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (rows == 0) return SE3_OK;
-  if (row_lo >= 0 && !edge_t_bf16_row_ranges(g, channels)) return SE3_ERR_UNSUPPORTED;
+  if ((row_lo >= 0 || t24) && !edge_t_bf16_row_ranges(g, channels)) return SE3_ERR_UNSUPPORTED;
+  if (t24 && channels % 2 != 0) return SE3_ERR_UNSUPPORTED;
   // 32-bit byte offsets into the gathered operand; kOobOffset must lie beyond it
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
@@ -765,10 +781,10 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   do {                                                                                                                  \
     if (two)                                                                                                            \
       hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 2>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, t_out, item_lo, item_hi, shift);                                                \
+                         axes_ext, rho, t_out, item_lo, item_hi, shift, t24 ? 1 : 0);                                   \
     else                                                                                                                \
       hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 1>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, t_out, item_lo, item_hi, shift);                                                \
+                         axes_ext, rho, t_out, item_lo, item_hi, shift, t24 ? 1 : 0);                                   \
   } while (0)
     if (channels == 64) SE3_PAIR(1, true);
     else if (channels % 128 == 0) SE3_PAIR(2, true);

@@ -227,6 +227,153 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   }
 }
 
+// NN GEMM over A rows in the 3-byte format (common.h, T24; k a multiple of 64).  What bounds the A stream of these
+// products is the number of 64-byte requests, not the bytes (tools/probes/tile_read3.hip: 6144-byte rows read 64 + 32
+// bytes at a time take as long as 8192-byte rows read 128 bytes at a time), so the loads work on "super tiles" of 64
+// k: 128 B of hi and 64 B of lo per row and instruction.  LDS and the MFMA stage keep the 32-k tiles of the kernel
+// above: the two halves of a super tile are the two LDS buffers.  Lane l of load p reads 16-byte column
+// (l & 7) ^ (4 * (p & 1)), so every thread holds as many pieces of either half and the stores stay full-width.
+template <int OUT_MODE, int NB>
+__global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restrict__ a,
+                                                          const uint16_t* __restrict__ bt_hi,
+                                                          const uint16_t* __restrict__ bt_lo, void* __restrict__ c,
+                                                          int64_t m, int n, int k, int st_per_split,
+                                                          const float* __restrict__ alpha_num, float alpha_scale) {
+  constexpr int BNW = BN * NB;
+  __shared__ __attribute__((aligned(16))) uint16_t ash[2][BM][BK + 8];   // 80-byte pitch
+  __shared__ __attribute__((aligned(16))) uint8_t asl[2][BM][BK + 16];   // 48-byte pitch
+  __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BNW][B_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BNW;
+  const int st_begin = blockIdx.z * st_per_split;
+  const int ns = min(k / 64 - st_begin, st_per_split);  // super tiles of this block (> 0 by construction)
+
+  struct Super { u32x4 ah[4], al[2], bh[2 * NB], bl[2 * NB]; };
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(a), (short)0, (int)(uint32_t)(m * k * 3), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bh_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_hi), (short)0, (int)(uint32_t)((int64_t)n * k * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_lo), (short)0, (int)(uint32_t)((int64_t)n * k * 2), 0x00020000);
+  const int phase = (int)((blockIdx.x * 5u) % (unsigned)ns);  // see gemm_nn_bf16_kernel
+  const uint32_t rb = (uint32_t)k * 3u;
+  const int hsel = (tid >> 2) & 1, lsel = (tid >> 1) & 1;
+  auto load_super = [&](Super& t, int seq) {
+    int st = seq + phase;
+    if (st >= ns) st -= ns;
+    const uint32_t k0 = (uint32_t)(st_begin + st) * 64u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t off = (uint32_t)(m0 + p * 32 + (tid >> 3)) * rb + k0 * 2u + (uint32_t)((tid & 7) ^ ((p & 1) << 2)) * 16u;
+      t.ah[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const uint32_t off = (uint32_t)(m0 + p * 64 + (tid >> 2)) * rb + (uint32_t)k * 2u + k0 + (uint32_t)((tid & 3) ^ (p << 1)) * 16u;
+      t.al[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * NB; ++j) {  // j = 2 * nb + p: columns 64 nb + 32 p + (tid >> 3)
+      const uint32_t off = ((uint32_t)(n0 + 32 * j + (tid >> 3)) * (uint32_t)k + k0 + (uint32_t)((tid & 7) ^ ((j & 1) << 2)) * 8u) * 2u;
+      t.bh[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, off, 0, 0));
+      t.bl[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, off, 0, 0));
+    }
+  };
+  // the 32-k half `hf` of a super tile -> LDS buffer `buf`: pieces whose column bit 2 (hi, B) / bit 1 (lo) equals hf
+  auto store_half = [&](const Super& t, int hf, int buf) {
+    const bool q = (hf ^ hsel) != 0, ql = (hf ^ lsel) != 0;
+    const int r8 = tid >> 3, c4 = (tid & 3) * 8;
+    *reinterpret_cast<u32x4*>(&ash[buf][(q ? 32 : 0) + r8][c4]) = q ? t.ah[1] : t.ah[0];
+    *reinterpret_cast<u32x4*>(&ash[buf][(q ? 96 : 64) + r8][c4]) = q ? t.ah[3] : t.ah[2];
+    *reinterpret_cast<u32x4*>(&asl[buf][(ql ? 64 : 0) + (tid >> 2)][(tid & 1) * 16]) = ql ? t.al[1] : t.al[0];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      *reinterpret_cast<u32x4*>(&bsh[buf][64 * nb + (q ? 32 : 0) + r8][c4]) = q ? t.bh[2 * nb + 1] : t.bh[2 * nb];
+      *reinterpret_cast<u32x4*>(&bsl[buf][64 * nb + (q ? 32 : 0) + r8][c4]) = q ? t.bl[2 * nb + 1] : t.bl[2 * nb];
+    }
+  };
+  f32x16 acc[2 * NB];
+#pragma unroll
+  for (int ct = 0; ct < 2 * NB; ++ct) acc[ct] = zero16();
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kk = 16 * s + 8 * h;
+      // the hi fragment is one 16-byte read; the lo fragment is rebuilt from the 8 lo bytes (7 VALU per pair)
+      const u32x4 a_hi = *reinterpret_cast<const u32x4*>(&ash[buf][wave * 32 + rl][kk]);
+      const uint32_t* lp = reinterpret_cast<const uint32_t*>(&asl[buf][wave * 32 + rl][kk]);
+      const uint32_t l0 = lp[0], l1 = lp[1];
+      const u32x4 a_lo = {t24_lo_word<0>(a_hi[0], l0), t24_lo_word<2>(a_hi[1], l0), t24_lo_word<0>(a_hi[2], l1),
+                          t24_lo_word<2>(a_hi[3], l1)};
+#pragma unroll
+      for (int ct = 0; ct < 2 * NB; ++ct) {
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&bsh[buf][32 * ct + rl][kk]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&bsl[buf][32 * ct + rl][kk]);
+        acc[ct] = mfma_bf16x3(a_hi, a_lo, bh, bl, acc[ct]);
+      }
+    }
+  };
+  // Two super tiles in registers (= the 4 k-tiles in flight of the kernel above).  Step A computes the first half
+  // while the second goes to LDS buffer 1; step B computes the second half, stores the next super tile's first half
+  // to buffer 0 and refills the register set that just emptied.
+  Super t0, t1;
+  load_super(t0, 0);
+  if (ns > 1) load_super(t1, 1);
+  store_half(t0, 0, 0);
+  __syncthreads();
+#define SE3_T24_STEP(CUR, NEXT, ST)                       \
+  compute(0);                                             \
+  store_half(CUR, 1, 1);                                  \
+  __syncthreads();                                        \
+  if ((ST) + 2 < ns) load_super(CUR, (ST) + 2);           \
+  compute(1);                                             \
+  if ((ST) + 1 < ns) store_half(NEXT, 0, 0);              \
+  __syncthreads();
+#define SE3_T24_STEP_FULL(CUR, NEXT, ST) \
+  compute(0);                            \
+  store_half(CUR, 1, 1);                 \
+  __syncthreads();                       \
+  load_super(CUR, (ST) + 2);             \
+  compute(1);                            \
+  store_half(NEXT, 0, 0);                \
+  __syncthreads();
+  int st = 0;
+  for (; st + 4 <= ns; st += 2) {  // no conditions around the loads (see gemm_nn_bf16_kernel)
+    SE3_T24_STEP_FULL(t0, t1, st)
+    SE3_T24_STEP_FULL(t1, t0, st + 1)
+  }
+  for (; st < ns; st += 2) {
+    SE3_T24_STEP(t0, t1, st)
+    if (st + 1 < ns) {
+      SE3_T24_STEP(t1, t0, st + 1)
+    }
+  }
+#undef SE3_T24_STEP
+#undef SE3_T24_STEP_FULL
+
+  const float alpha = OUT_MODE == 2 ? 1.0f : (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t gr = m0 + wave * 32 + acc_row(r, h);
+    if (gr < m) {
+#pragma unroll
+      for (int ct = 0; ct < 2 * NB; ++ct) {
+        const int gc = n0 + 32 * ct + rl;
+        if (gc >= n) continue;
+        if constexpr (OUT_MODE == 1) {
+          static_cast<uint32_t*>(c)[gr * n + gc] = split_pack(alpha * acc[ct][r]);
+        } else {
+          float* out = static_cast<float*>(c) + (OUT_MODE == 2 ? (int64_t)blockIdx.z * m * n : 0);
+          out[gr * n + gc] = alpha * acc[ct][r];
+        }
+      }
+    }
+  }
+}
+
 // Row-strip GEMM for the wide, write-dominated products with a short k (grad_T = g W^T, H = f W''):
 //   C[m, n] (packed words) = A[m, k] (packed words) * Bt[n, k]^T,   k <= 64, n large (C_in*K or C_out*K = 2048)
 // A wavefront keeps its 32 rows of A as MFMA fragments for the whole kernel and walks the n range 32 columns
@@ -369,12 +516,16 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partials, void* _
 // One block: 128 (ka) x 64 (n) outputs over rows [split*chunk, (split+1)*chunk) in stages of 32 rows.
 // FAST (n % 4 == 0, operands < 4 GB): unconditional raw buffer loads bounded at the split's last row (rows
 // past it and columns past ka / n read as 0), stages prefetched 3 deep in registers like gemm_nn.
-template <bool FAST>
+// A24: A rows in the 3-byte format (common.h, T24; ka a multiple of 64); the partial rows are written at t24_k_of().
+template <bool FAST, bool A24>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __restrict__ a,
                                                            const uint32_t* __restrict__ b,
                                                            float* __restrict__ partials, int64_t m, int ka, int n,
                                                            int64_t chunk) {
-  __shared__ __attribute__((aligned(16))) uint32_t at[2][BK][128];
+  static_assert(!A24 || FAST, "the 3-byte A format is only read through buffer loads");
+  __shared__ __attribute__((aligned(16))) uint32_t at[2][A24 ? 1 : BK][128];
+  __shared__ __attribute__((aligned(16))) uint16_t ath[2][A24 ? BK : 1][128 + 8];
+  __shared__ __attribute__((aligned(16))) uint8_t atl[2][A24 ? BK : 1][128 + 16];
   __shared__ __attribute__((aligned(16))) uint32_t bt[2][BK][BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
@@ -387,14 +538,28 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
 
   struct Stage { u32x4 a0, a1, a2, a3, b0, b1; };
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint32_t*>(a), (short)0, FAST ? (int)(uint32_t)(me * ka * 4) : 0, 0x00020000);
+      const_cast<uint32_t*>(a), (short)0, FAST ? (int)(uint32_t)(me * ka * (A24 ? 3 : 4)) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint32_t*>(b), (short)0, FAST ? (int)(uint32_t)(me * n * 4) : 0, 0x00020000);
   const int arow = tid >> 5, acq = (tid & 31) * 4, brow = tid >> 4, bcq = (tid & 15) * 4;
   const bool a_ok = ka0 + acq < ka, b_ok = n0 + bcq < n;
   auto load_stage = [&](Stage& t, int64_t st) {
     const int64_t mm = mb + st * BK;
-    if constexpr (FAST) {
+    if constexpr (A24) {
+      const uint32_t oob = 0xfffffff0u;
+      const uint32_t rb = (uint32_t)ka * 3u;
+      // hi: 32 rows x 256 B = 2 pieces of 16 B per thread; lo: 32 rows x 128 B = 1 piece per thread
+      const bool h_ok = ka0 + (tid & 15) * 8 < ka, l_ok = ka0 + (tid & 7) * 16 < ka;
+      const uint32_t ho = (uint32_t)(mm + (tid >> 4)) * rb + (uint32_t)(ka0 + (tid & 15) * 8) * 2u;
+      const uint32_t lo = (uint32_t)(mm + (tid >> 3)) * rb + (uint32_t)ka * 2u + (uint32_t)(ka0 + (tid & 7) * 16);
+      const uint32_t bo = b_ok ? (uint32_t)(((mm + brow) * n + n0 + bcq) * 4) : oob;
+      const uint32_t bs16 = (uint32_t)n * 64u;
+      t.a0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, h_ok ? ho : oob, 0, 0));
+      t.a1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, h_ok ? ho + 16u * rb : oob, 0, 0));
+      t.a2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, l_ok ? lo : oob, 0, 0));
+      t.b0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, bo, 0, 0));
+      t.b1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_ok ? bo + bs16 : oob, 0, 0));
+    } else if constexpr (FAST) {
       const uint32_t oob = 0xfffffff0u;  // beyond num_records: the load returns 0
       const uint32_t ao = a_ok ? (uint32_t)(((mm + arow) * ka + ka0 + acq) * 4) : oob;
       const uint32_t bo = b_ok ? (uint32_t)(((mm + brow) * n + n0 + bcq) * 4) : oob;
@@ -421,10 +586,16 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
     }
   };
   auto store_stage = [&](const Stage& t, int buf) {
-    *reinterpret_cast<u32x4*>(&at[buf][arow][acq]) = t.a0;
-    *reinterpret_cast<u32x4*>(&at[buf][arow + 8][acq]) = t.a1;
-    *reinterpret_cast<u32x4*>(&at[buf][arow + 16][acq]) = t.a2;
-    *reinterpret_cast<u32x4*>(&at[buf][arow + 24][acq]) = t.a3;
+    if constexpr (A24) {
+      *reinterpret_cast<u32x4*>(&ath[buf][tid >> 4][(tid & 15) * 8]) = t.a0;
+      *reinterpret_cast<u32x4*>(&ath[buf][16 + (tid >> 4)][(tid & 15) * 8]) = t.a1;
+      *reinterpret_cast<u32x4*>(&atl[buf][tid >> 3][(tid & 7) * 16]) = t.a2;
+    } else {
+      *reinterpret_cast<u32x4*>(&at[buf][arow][acq]) = t.a0;
+      *reinterpret_cast<u32x4*>(&at[buf][arow + 8][acq]) = t.a1;
+      *reinterpret_cast<u32x4*>(&at[buf][arow + 16][acq]) = t.a2;
+      *reinterpret_cast<u32x4*>(&at[buf][arow + 24][acq]) = t.a3;
+    }
     *reinterpret_cast<u32x4*>(&bt[buf][brow][bcq]) = t.b0;
     *reinterpret_cast<u32x4*>(&bt[buf][brow + 16][bcq]) = t.b1;
   };
@@ -440,12 +611,21 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int row = 16 * s + 8 * h + j;
-        wa[j] = at[buf][row][wave * 32 + rl];
+        if constexpr (A24) wa[j] = (uint32_t)ath[buf][row][wave * 32 + rl] | ((uint32_t)atl[buf][row][wave * 32 + rl] << 16);
+        else wa[j] = at[buf][row][wave * 32 + rl];
         wb0[j] = bt[buf][row][rl];
         wb1[j] = bt[buf][row][32 + rl];
       }
       u32x4 a_hi, a_lo, b_hi, b_lo;
-      frags_from_words(wa, a_hi, a_lo);
+      if constexpr (A24) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // wa = hi16 | lo8 << 16 of rows 2i, 2i+1
+          a_hi[i] = __builtin_amdgcn_perm(wa[2 * i + 1], wa[2 * i], 0x05040100u);
+          a_lo[i] = t24_lo_word<0>(a_hi[i], __builtin_amdgcn_perm(wa[2 * i + 1], wa[2 * i], 0x0c0c0602u));
+        }
+      } else {
+        frags_from_words(wa, a_hi, a_lo);
+      }
       frags_from_words(wb0, b_hi, b_lo);
       acc0 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc0);
       frags_from_words(wb1, b_hi, b_lo);
@@ -488,8 +668,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
   float* out = partials + (int64_t)blockIdx.z * ka * n;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = ka0 + wave * 32 + acc_row(r, h);
-    if (row < ka) {
+    const int kq = ka0 + wave * 32 + acc_row(r, h);
+    if (kq < ka) {
+      const int row = A24 ? t24_k_of(kq) : kq;
       if (n0 + rl < n) out[(int64_t)row * n + n0 + rl] = acc0[r];
       if (n0 + 32 + rl < n) out[(int64_t)row * n + n0 + 32 + rl] = acc1[r];
     }
@@ -587,7 +768,7 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
 
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
-                        float alpha_scale, hipStream_t stream) {
+                        float alpha_scale, hipStream_t stream, bool a24) {
   if (m == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   const int kp = (k + 31) / 32 * 32;
@@ -599,15 +780,24 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
   const dim3 grid((unsigned)((m + BM - 1) / BM), (unsigned)((n + BN * nbw - 1) / (BN * nbw)), (unsigned)splits);
   const bool fast = (k % 32 == 0) && (m * (int64_t)k * 4 < (1ll << 32)) && ((int64_t)n * kp * 2 < (1ll << 32)) &&
                     ((m + BM) * (int64_t)k * 4 < (1ll << 32)) && ((int64_t)(n + 128) * kp * 2 < (1ll << 32));
-#define SE3_NN_LAUNCH(MODE, F, NBV, OUT)                                                                                  \
-  hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, F, NBV>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), m, n, k, \
-                     kp, per, alpha_num, alpha_scale)
-#define SE3_NN(MODE, OUT)                                      \
-  do {                                                         \
-    if (fast && nbw == 2) SE3_NN_LAUNCH(MODE, true, 2, OUT);   \
-    else if (fast) SE3_NN_LAUNCH(MODE, true, 1, OUT);          \
-    else if (nbw == 2) SE3_NN_LAUNCH(MODE, false, 2, OUT);     \
-    else SE3_NN_LAUNCH(MODE, false, 1, OUT);                   \
+  if (a24 && (!fast || k % 64 != 0)) return SE3_ERR_UNSUPPORTED;
+  const int st_per = (per + 1) / 2;  // 3-byte rows: the kernel walks super tiles of 64 k
+  if (a24) splits = (k / 64 + st_per - 1) / st_per;
+  const dim3 grid24((unsigned)((m + BM - 1) / BM), grid.y, (unsigned)splits);
+#define SE3_NN_LAUNCH(MODE, F, NBV, OUT)                                                                              \
+  hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, F, NBV>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), m, n, \
+                     k, kp, per, alpha_num, alpha_scale)
+#define SE3_NN_LAUNCH24(MODE, NBV, OUT)                                                                               \
+  hipLaunchKernelGGL((gemm_nn_t24_kernel<MODE, NBV>), grid24, dim3(256), 0, stream, (const uint8_t*)a, bt_hi, bt_lo,   \
+                     (void*)(OUT), m, n, k, st_per, alpha_num, alpha_scale)
+#define SE3_NN(MODE, OUT)                                    \
+  do {                                                       \
+    if (a24 && nbw == 2) SE3_NN_LAUNCH24(MODE, 2, OUT);      \
+    else if (a24) SE3_NN_LAUNCH24(MODE, 1, OUT);             \
+    else if (fast && nbw == 2) SE3_NN_LAUNCH(MODE, true, 2, OUT); \
+    else if (fast) SE3_NN_LAUNCH(MODE, true, 1, OUT);        \
+    else if (nbw == 2) SE3_NN_LAUNCH(MODE, false, 2, OUT);   \
+    else SE3_NN_LAUNCH(MODE, false, 1, OUT);                 \
   } while (0)
   if (splits > 1) {
     SE3_NN(2, split_ws);
@@ -626,6 +816,7 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
   }
 #undef SE3_NN
 #undef SE3_NN_LAUNCH
+#undef SE3_NN_LAUNCH24
   return check_launch();
 }
 
@@ -635,7 +826,7 @@ size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k) {
 }
 
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
-                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream) {
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24) {
   if (ka == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   int64_t chunk = (m + splits - 1) / splits;
@@ -644,10 +835,13 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
   const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
   const bool fast = (n % 4 == 0) && ((m + chunk) * (int64_t)ka * 4 < (1ll << 32) - 64) &&
                     ((m + chunk) * (int64_t)n * 4 < (1ll << 32) - 64);
-  if (fast)
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  if (a24 && (!fast || ka % 64 != 0)) return SE3_ERR_UNSUPPORTED;
+  if (a24)
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  else if (fast)
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
   else
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
   return launch_reduce_partials(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, stream);
 }
 

@@ -64,13 +64,14 @@ __device__ void job_weights(const PrepJob& j, int block, int blocks) {
     const int nn = (int)(idx / kp), kk = (int)(idx % kp);
     float v = 0.f;
     if (kk < k) {
-      if (mode == 0) v = w[(int64_t)kk * c_out + nn];
+      const int ks = (frag & 2) ? t24_k_of(kk) : kk;  // the A operand is in the 3-byte row format: its k order
+      if (mode == 0) v = w[(int64_t)ks * c_out + nn];
       else if (mode == 1) v = w[(int64_t)nn * c_out + kk];
-      else if (mode == 2) v = w[((int64_t)nn * kb + (kk % kb)) * c_out + kk / kb];
+      else if (mode == 2) v = w[((int64_t)nn * kb + (ks % kb)) * c_out + ks / kb];
       else v = w[((int64_t)kk * kb + (nn % kb)) * c_out + nn / kb];
     }
     const uint32_t pk = split_pack(v * sc);
-    const int64_t o = frag ? ((((int64_t)(nn / 32) * (kp / 16) + kk / 16) * 64 + ((kk % 16) / 8) * 32 + nn % 32) * 8 + kk % 8)
+    const int64_t o = (frag & 1) ? ((((int64_t)(nn / 32) * (kp / 16) + kk / 16) * 64 + ((kk % 16) / 8) * 32 + nn % 32) * 8 + kk % 8)
                            : idx;
     bt_hi[o] = (uint16_t)(pk >> 16);
     bt_lo[o] = (uint16_t)(pk & 0xffffu);
@@ -118,7 +119,7 @@ void PrepBatch::split(const float* src, uint32_t* dst, int64_t n) {
 }
 
 void PrepBatch::weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
-                        const float* scale_num, float scale, bool frag_layout) {
+                        const float* scale_num, float scale, bool frag_layout, bool perm24) {
   int n, k;
   if (mode == 0) n = c_out, k = c_in * kb;
   else if (mode == 1) n = c_in * kb, k = c_out;
@@ -128,7 +129,7 @@ void PrepBatch::weights(const float* w, int c_in, int kb, int c_out, int mode, u
   PrepJob& j = jobs.job[jobs.count++];
   j = PrepJob{};
   j.type = kJobWeights, j.blocks = blocks_for((int64_t)n * kp, 2048), j.a = w, j.b = scale_num, j.o0 = bt_hi, j.o1 = bt_lo;
-  j.p[0] = c_in, j.p[1] = kb, j.p[2] = c_out, j.p[3] = mode, j.p[4] = n, j.p[5] = k, j.p[6] = kp, j.p[7] = frag_layout ? 1 : 0;
+  j.p[0] = c_in, j.p[1] = kb, j.p[2] = c_out, j.p[3] = mode, j.p[4] = n, j.p[5] = k, j.p[6] = kp, j.p[7] = (frag_layout ? 1 : 0) | (perm24 ? 2 : 0);
   j.scale = scale;
 }
 
