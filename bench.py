@@ -99,20 +99,22 @@ def layer_flops(n, e):
             "gemm_H": dense, "edge_t_transposed": edge, "edge_param_grad": pg, "edge_bwd": pg + ep * 2 * CH * KB}
 
 
-def stage_bytes(n, e):
+def stage_bytes(n, e, t24=True):
     """HBM bytes each kernel of the (unfused) pipeline has to move at least: its gathered rows counted
-    once per edge (uncached-gather model), its dense operands and results once."""
+    once per edge (uncached-gather model), its dense operands and results once.  t24: T and U are stored in the
+    3-byte row format (bf16x3 path, C >= 64); grad_T always is packed 4-byte words."""
     rows = n * FRAMES
-    t_bytes = 4 * rows * CH * KB  # T / grad_T / U: [rows, C, K] words
+    g_bytes = 4 * rows * CH * KB  # grad_T: [rows, C, K] words
+    t_bytes = (3 if t24 else 4) * rows * CH * KB  # T / U
     geom = 8 * e + 4 * n + 12 * 2 * n + 36 * 2 * rows
     w = 4 * CH * KB * CH
     # every point-edge touches its neighbour's F*C block once per pass (SURVEY.md section 8d); the two centre
     # frames of a point share that gather
-    edge = geom + 4 * e * FRAMES * CH + t_bytes
-    return {"edge_t_fwd": edge, "edge_t_transposed": edge, "edge_param_grad": edge,
-            "gemm_out": t_bytes + w + 4 * rows * CH, "gemm_gradT": t_bytes + w + 4 * rows * CH,
+    gather = geom + 4 * e * FRAMES * CH
+    return {"edge_t_fwd": gather + t_bytes, "edge_t_transposed": gather + t_bytes, "edge_param_grad": gather + g_bytes,
+            "gemm_out": t_bytes + w + 4 * rows * CH, "gemm_gradT": g_bytes + w + 4 * rows * CH,
             "gemm_gradX": t_bytes + w + 4 * rows * CH, "gemm_gradW": t_bytes + 4 * rows * CH + w,
-            "gemm_H": t_bytes + w + 4 * rows * CH, "edge_bwd": edge + t_bytes,
+            "gemm_H": g_bytes + w + 4 * rows * CH, "edge_bwd": gather + g_bytes + t_bytes,
             "prep": 3 * 8 * rows * CH + 2 * (48 + 64) * rows + 6 * w}
 
 
@@ -238,7 +240,8 @@ def main():
 
     stages = profile_level0(lib, levels[0], reps=5)
     fl = layer_flops(levels[0]["n"], levels[0]["e"])
-    sb = stage_bytes(levels[0]["n"], levels[0]["e"])
+    t24 = args.precision == "bf16x3" and CH >= 64 and CH % 2 == 0 and "SE3_NO_T24" not in os.environ
+    sb = stage_bytes(levels[0]["n"], levels[0]["e"], t24)
     peak_tf = PEAK_MFMA_TFLOPS[args.precision]
     dom = max(stages, key=lambda t: stages[t][0]) if stages else None
     roofline = None

@@ -86,6 +86,12 @@ int se3_compute_keys(const float* pts, const int32_t* batch_ids, const float* aa
 int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float* aabb_min,
                    float* aabb_max, void* stream);
 
+/* Grid parameters of a ball query exactly as point_cloud_lib/custom_ops/BallQuery.py:34-38 builds them, in one call
+ * and without a host sync: aabb_min [n_batches,3] = per-batch minimum - 1e-6; num_cells [3] = max over batches of
+ * int(((max - 1e-6) - aabb_min) / radius) + 1.  aabb_max_scratch: [n_batches,3] floats of scratch. */
+int se3_ball_query_grid(const float* pts_src, const int32_t* batch_src, int64_t n_src, int32_t n_batches, float radius,
+                        float* aabb_min, float* aabb_max_scratch, int32_t* num_cells, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ball query  <-  point_cloud_lib_ops.ball_query
  *   (custom_ops/ball_query/ball_query.cuh:30-38, host ball_query.cu:22-103; max_neighbors = 0,

@@ -377,6 +377,34 @@ extern "C" int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_
   return check_launch();
 }
 
+namespace {
+// grid parameters of a ball query (BallQuery.py:34-38): min' = min - 1e-6, max' = max - 1e-6,
+// cells[d] = max over batches of int((max' - min') / radius) + 1; empty batches do not vote
+__global__ void ball_query_grid_kernel(float* __restrict__ mn, const float* __restrict__ mx, int n_batches, float radius,
+                                       int32_t* __restrict__ num_cells) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_batches * 3) return;
+  const float lo = mn[i], hi = mx[i];
+  const float lo_s = __fsub_rn(lo, 1e-6f), hi_s = __fsub_rn(hi, 1e-6f);
+  if (lo <= hi) atomicMax(&num_cells[i % 3], (int)__fdiv_rn(__fsub_rn(hi_s, lo_s), radius) + 1);
+  mn[i] = lo_s;
+}
+}  // namespace
+
+extern "C" int se3_ball_query_grid(const float* pts_src, const int32_t* batch_src, int64_t n_src, int32_t n_batches,
+                                   float radius, float* aabb_min, float* aabb_max_scratch, int32_t* num_cells,
+                                   void* stream_) {
+  if (n_src < 0 || n_batches < 1 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
+  if (!aabb_min || !aabb_max_scratch || !num_cells) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemsetAsync(num_cells, 0, 3 * sizeof(int32_t), stream) != hipSuccess) return SE3_ERR_LAUNCH;
+  if (int rc = se3_batch_aabb(pts_src, batch_src, n_src, n_batches, aabb_min, aabb_max_scratch, stream_)) return rc;
+  hipLaunchKernelGGL(ball_query_grid_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, aabb_min,
+                     aabb_max_scratch, n_batches, radius, num_cells);
+  return check_launch();
+}
+
+
 extern "C" size_t se3_knn_query_grid_workspace_bytes(int64_t n) { return knn_layout(n).total; }
 
 extern "C" int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, const float* aabb_min,

@@ -119,12 +119,19 @@ def batch_aabb(pts, batch_ids, n_batches: Optional[int] = None) -> Tuple[torch.T
 
 
 def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float, n_batches: Optional[int] = None):
-    """Grid parameters exactly as BallQuery.forward builds them (BallQuery.py:34-38), on device."""
-    mn, mx = batch_aabb(pts_src, batch_src, n_batches)
-    mn = mn - 1e-6
-    mx = mx - 1e-6
-    num_cells = (((mx - mn) / radius).to(torch.int32) + 1).max(dim=0)[0].to(torch.int32)
-    return mn.contiguous(), num_cells.contiguous()
+    """Grid parameters exactly as BallQuery.forward builds them (BallQuery.py:34-38), on device, one library call."""
+    lib = _lib.load()
+    if n_batches is None:
+        # one tiny sync, the same one the reference pays with `torch::amax(...).item()` (ball_query.cu:46)
+        n_batches = int(batch_src.max().item()) + 1 if batch_src.numel() else 1
+    dev = pts_src.device
+    box = torch.empty((2, n_batches, 3), dtype=torch.float32, device=dev)  # [0] = shifted minimum, [1] = scratch
+    num_cells = torch.empty(3, dtype=torch.int32, device=dev)
+    _lib.check(lib.se3_ball_query_grid(
+        _ptr(pts_src, torch.float32, "pts_src"), _ptr(batch_src, torch.int32, "batch_src", dev), pts_src.shape[0],
+        n_batches, float(radius), C.c_void_p(box[0].data_ptr()), C.c_void_p(box[1].data_ptr()),
+        _ptr(num_cells, torch.int32, "num_cells"), _stream()), "se3_ball_query_grid")
+    return box[0], num_cells
 
 
 def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
@@ -142,9 +149,9 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
     bs = _as(batch_src, torch.int32)
     bd = _as(batch_dst, torch.int32)
     n_src, n_dst = pts_src.shape[0], pts_dst.shape[0]
-    ends = torch.zeros(n_dst, dtype=torch.int32, device=dev)
     if n_dst == 0 or n_src == 0:
-        return torch.zeros((0, 2), dtype=torch.int32, device=dev), ends
+        return torch.zeros((0, 2), dtype=torch.int32, device=dev), torch.zeros(n_dst, dtype=torch.int32, device=dev)
+    ends = torch.empty(n_dst, dtype=torch.int32, device=dev)  # every entry is written by the count phase
     mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches)
     nbytes = lib.se3_ball_query_workspace_bytes(n_src, n_dst)
     ws = _workspace(nbytes, dev)
@@ -169,15 +176,17 @@ class BallQuery(torch.autograd.Function):
     and ``start_ids`` (inclusive ends) as int32; ``max_neighbors`` must be 0."""
 
     @staticmethod
-    def forward(ctx, p_pt_src, p_pt_sample, p_batch_id_src, p_batch_id_sample, radius, max_neighbors):
+    def forward(ctx, p_pt_src, p_pt_sample, p_batch_id_src, p_batch_id_sample, radius, max_neighbors, n_batches=None):
+        """``n_batches`` (extension; the reference reads it back from the device, ball_query.cu:46): batch count
+        when the caller knows it -- saves a host sync."""
         if max_neighbors != 0:
             raise NotImplementedError("max_neighbors > 0 (random sub-sampling) is not used by any model path")
-        nb, ends = ball_query(p_pt_src, p_pt_sample, p_batch_id_src, p_batch_id_sample, radius)
+        nb, ends = ball_query(p_pt_src, p_pt_sample, p_batch_id_src, p_batch_id_sample, radius, n_batches)
         return nb.to(torch.int64), ends
 
     @staticmethod
     def backward(ctx, *grads):
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 def csr_transpose(neighbors_i32: torch.Tensor, n_src: int) -> Tuple[torch.Tensor, torch.Tensor]:

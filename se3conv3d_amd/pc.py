@@ -69,6 +69,13 @@ class Pointcloud(object):
         self.batch_ids_ = self.batch_ids_.to(p_device)
         self.batch_size_ = self.batch_size_.to(p_device)
 
+    def num_batches(self) -> int:
+        """``batch_size_`` as a host integer, read back once per cloud (the native calls size their per-batch
+        tables with it; the reference re-reads it from the device in every ball query, ball_query.cu:46)."""
+        if getattr(self, "_num_batches", None) is None:
+            self._num_batches = int(self.batch_size_)
+        return self._num_batches
+
 
 class PointcloudRotEquiv(Pointcloud):
     """Point cloud with ``n_frames`` SO(3) reference frames per point."""
@@ -176,7 +183,7 @@ class BQNeighborhood(Neighborhood):
     def __compute_neighborhood__(self):
         self.neighbors_, self.start_ids_ = ops.BallQuery.apply(
             self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_, self.samples_.batch_ids_,
-            self.radius_, self.max_neighbors_)
+            self.radius_, self.max_neighbors_, self.pc_src_.num_batches())
 
 
 class KnnNeighborhood(Neighborhood):
@@ -218,7 +225,7 @@ class GridSubSample(object):
         self.pc_src_ = p_pc_src
         self.cell_size_ = p_cell_size
         pts = p_pc_src.pts_
-        mn, mx = ops.batch_aabb(pts, p_pc_src.batch_ids_, int(p_pc_src.batch_size_))  # BoundingBox.py:17-18
+        mn, mx = ops.batch_aabb(pts, p_pc_src.batch_ids_, p_pc_src.num_batches())  # BoundingBox.py:17-18
         mn, mx = mn - 1e-6, mx + 1e-6
         self.num_cells_ = (((mx - mn) / p_cell_size).to(torch.int32) + 1).max(dim=0)[0]
         keys = ops.ComputeKeys.apply(pts, p_pc_src.batch_ids_, mn, self.num_cells_,

@@ -17,6 +17,7 @@ STAGES = {
     "edge_param_grad_bf16_v2_kernel": ["edge_param_grad"],
     "edge_bwd_pair_bf16_kernel": ["edge_bwd"],
     "gemm_nn_bf16_kernel": ["gemm_out", "gemm_gradX"],
+    "gemm_nn_t24_kernel": ["gemm_out", "gemm_gradX"],
     "gemm_strip_bf16_kernel": ["gemm_gradT"],
     "gemm_tn_bf16_kernel": ["gemm_gradW"],
     "prep_batch_kernel": ["prep"],
