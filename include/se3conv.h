@@ -86,6 +86,42 @@ int se3_compute_keys(const float* pts, const int32_t* batch_ids, const float* aa
 int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float* aabb_min,
                    float* aabb_max, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * hierarchy build (scope row f-2)  <-  point_cloud_lib/pc/Grid.py:20-51, pc/GridSubSample.py:63-93,
+ *                                      pc/PointHierarchy.py:40-57
+ * se3_grid_subsample: one level of grid-average sub-sampling.  Bounding boxes (+-1e-6, BoundingBox.py:17-18), cell
+ *   counts (Grid.py:28-29), keys (ComputeKeys), then what torch.unique(return_inverse=True) + argsort give:
+ *     cell_ids   [n]  cell of every point, cells numbered in ascending key order
+ *     sorted_ids [n]  point ids grouped by cell (input order inside a cell)
+ *     cell_ends  [n]  inclusive end offsets into sorted_ids, first *n_cells entries valid
+ *     n_cells    [1]  (device) number of occupied cells = points of the next level; the caller's one host sync
+ *     cell_pts   [n,3] / cell_batch_ids [n]: first *n_cells rows = the next level (cell means / batch ids)
+ * se3_segment_pool / se3_segment_unpool: pool_tensor ("avg" = scatter_mean, "max" = scatter_max, also min / sum)
+ *   over those cells and the maps back to the rows: mode sum = the gather of upsample_tensor (GridSubSample.py:93)
+ *   and, as a pool, its gradient; avg / max / min unpool = the gradients of the pools (max / min route to the row
+ *   that supplied the extremum, `arg` [n_cells,C] from the forward, like torch_scatter).
+ * Modes: 0 avg, 1 max, 2 min, 3 sum.  Summation order is fixed (input order inside a cell). */
+#define SE3_POOL_AVG 0
+#define SE3_POOL_MAX 1
+#define SE3_POOL_MIN 2
+#define SE3_POOL_SUM 3
+size_t se3_grid_subsample_workspace_bytes(int64_t n, int32_t n_batches);
+int se3_grid_subsample(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float cell_size,
+                       void* workspace, size_t workspace_bytes, int32_t* cell_ids, int32_t* sorted_ids,
+                       int32_t* cell_ends, int32_t* n_cells, float* cell_pts, int32_t* cell_batch_ids, void* stream);
+int se3_segment_pool(const float* src, const int32_t* sorted_ids, const int32_t* cell_ends, int64_t n_cells,
+                     int32_t channels, int32_t mode, float* out, int32_t* arg, void* stream);
+int se3_segment_unpool(const float* cell_vals, const int32_t* cell_ids, const int32_t* cell_ends, const int32_t* arg,
+                       int64_t n, int32_t channels, int32_t mode, float* out, void* stream);
+
+/* Frame pooling (scope row f-3)  <-  PointcloudRotEquiv.feature_pooling (pc/PointcloudRotEquiv.py:224-251): the F rows
+ * point*F + frame of x [n_points*F, C] -> out [n_points, C]; `arg` [n_points, C] (max / min only) = winning frame.
+ * se3_frame_unpool is its gradient: grad_out [n_points, C] -> grad_x [n_points*F, C]. */
+int se3_frame_pool(const float* x, int64_t n_points, int32_t frames, int32_t channels, int32_t mode, float* out,
+                   int32_t* arg, void* stream);
+int se3_frame_unpool(const float* grad_out, const int32_t* arg, int64_t n_points, int32_t frames, int32_t channels,
+                     int32_t mode, float* grad_x, void* stream);
+
 /* Grid parameters of a ball query exactly as point_cloud_lib/custom_ops/BallQuery.py:34-38 builds them, in one call
  * and without a host sync: aabb_min [n_batches,3] = per-batch minimum - 1e-6; num_cells [3] = max over batches of
  * int(((max - 1e-6) - aabb_min) / radius) + 1.  aabb_max_scratch: [n_batches,3] floats of scratch. */

@@ -470,3 +470,56 @@ def pne_conv_forward_backward(pts_in, pts_out, neighbors, ends, x, proj_axes, pr
     out.backward(t(grad_out))
     return out.detach(), x.grad, a.grad, b.grad, w.grad
 
+
+
+# ------------------------------------------------------------------- hierarchy build and frame pooling (rows f-2, f-3)
+def grid_subsample(pts: torch.Tensor, batch_ids: torch.Tensor, cell_size: float):
+    """One grid-average sub-sampling step: ``(cell_ids [N] int64, n_cells, level_pts [n_cells,3], level_batch)``.
+
+    BoundingBox.py:17-18 (scatter_min - 1e-6 / scatter_max + 1e-6 per batch element), Grid.py:28-29 (cell counts =
+    max over batches of int((max - min) / cell) + 1), Grid.py:37-45 (ComputeKeys with the same cell size in every
+    dimension, then ``torch.unique(return_inverse=True)``: cells numbered in ascending key order),
+    PointHierarchy.py:46-49 (level points = scatter_mean, level batch ids = scatter_max over the cells)."""
+    pts = pts.to(torch.float32)
+    b = batch_ids.to(torch.int64)
+    nb = int(b.max()) + 1
+    idx = b[:, None].expand(-1, 3)
+    mx = torch.zeros((nb, 3)).scatter_reduce(0, idx, pts, "amax", include_self=False) + 1e-6
+    mn = torch.zeros((nb, 3)).scatter_reduce(0, idx, pts, "amin", include_self=False) - 1e-6
+    num_cells = torch.max(((mx - mn) / cell_size).to(torch.int32) + 1, dim=0)[0]
+    keys = compute_keys(pts, batch_ids, mn, num_cells, torch.full((3,), cell_size, dtype=torch.float32))
+    _, cell_ids = torch.unique(keys, return_inverse=True)
+    n_cells = int(cell_ids.max()) + 1
+    return cell_ids, n_cells, segment_pool(pts, cell_ids, n_cells, "avg"), segment_pool(batch_ids, cell_ids, n_cells, "max")
+
+
+def segment_pool(x: torch.Tensor, cell_ids: torch.Tensor, n_cells: int, method: str) -> torch.Tensor:
+    """``GridSubSample.__subsample_tensor__`` (GridSubSample.py:63-77): torch_scatter's ``scatter_mean`` (sum / count)
+    and ``scatter_max`` over the cell ids; "min" / "sum" likewise (``scatter_min`` / ``scatter_add``)."""
+    how = {"avg": "mean", "max": "amax", "min": "amin", "sum": "sum"}[method]
+    idx = cell_ids.to(torch.int64)
+    if x.dim() > 1:
+        idx = idx.reshape((-1,) + (1,) * (x.dim() - 1)).expand_as(x)
+    out = torch.zeros((n_cells,) + tuple(x.shape[1:]), dtype=x.dtype)
+    if method in ("avg", "sum") or not x.requires_grad:
+        return out.scatter_reduce(0, idx, x, how, include_self=False)
+    # max / min with a gradient: torch_scatter routes it to ONE arg index per (cell, channel) (which one of several
+    # equal values is not defined there); torch's own amax backward would split it between ties.  Take the first.
+    ext = out.scatter_reduce(0, idx, x.detach(), how, include_self=False)
+    rows = torch.arange(x.shape[0]).reshape((-1,) + (1,) * (x.dim() - 1)).expand_as(x)
+    cand = torch.where(x.detach() == torch.gather(ext, 0, idx), rows, torch.full_like(rows, x.shape[0]))
+    arg = torch.full(out.shape, x.shape[0], dtype=torch.int64).scatter_reduce(0, idx, cand, "amin", include_self=True)
+    return torch.gather(x, 0, arg)
+
+
+def segment_upsample(x: torch.Tensor, cell_ids: torch.Tensor) -> torch.Tensor:
+    """``GridSubSample.__upsample_tensor__`` (GridSubSample.py:93): ``p_tensor[cell_ids]``."""
+    return x[cell_ids.to(torch.int64)]
+
+
+def frame_pool(x: torch.Tensor, n_frames: int, method: str) -> torch.Tensor:
+    """``PointcloudRotEquiv.feature_pooling`` (PointcloudRotEquiv.py:224-251): scatter over the index
+    ``repeat(arange(N), 'n -> (n t)', t=F)``, i.e. a reduction over the F consecutive rows of every point."""
+    n = x.shape[0] // n_frames
+    ids = torch.arange(n, dtype=torch.int64).repeat_interleave(n_frames)
+    return segment_pool(x, ids, n, method)

@@ -41,6 +41,12 @@ SIGNATURES = {
     "se3_error_string": (C.c_char_p, [C.c_int]),
     "se3_compute_keys": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "se3_batch_aabb": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "se3_grid_subsample_workspace_bytes": (_SZ, [_I64, _I32]),
+    "se3_grid_subsample": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
+    "se3_segment_pool": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
+    "se3_segment_unpool": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "se3_frame_pool": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "se3_frame_unpool": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "se3_ball_query_grid": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P, _P, _P]),
     "se3_ball_query_workspace_bytes": (_SZ, [_I64, _I64]),
     "se3_ball_query_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _SZ, _P, _P]),

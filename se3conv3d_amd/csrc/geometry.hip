@@ -378,15 +378,16 @@ extern "C" int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_
 }
 
 namespace {
-// grid parameters of a ball query (BallQuery.py:34-38): min' = min - 1e-6, max' = max - 1e-6,
-// cells[d] = max over batches of int((max' - min') / radius) + 1; empty batches do not vote
-__global__ void ball_query_grid_kernel(float* __restrict__ mn, const float* __restrict__ mx, int n_batches, float radius,
-                                       int32_t* __restrict__ num_cells) {
+// grid parameters: min' = min - 1e-6, max' = max + max_shift, cells[d] = max over batches of
+// int((max' - min') / cell) + 1; empty batches do not vote.  max_shift = -1e-6 in BallQuery.py:34-38,
+// +1e-6 in BoundingBox.py:17-18 (grid sub-sampling, Grid.py:28-29).
+__global__ void grid_params_kernel(float* __restrict__ mn, const float* __restrict__ mx, int n_batches, float cell,
+                                   float max_shift, int32_t* __restrict__ num_cells) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_batches * 3) return;
   const float lo = mn[i], hi = mx[i];
-  const float lo_s = __fsub_rn(lo, 1e-6f), hi_s = __fsub_rn(hi, 1e-6f);
-  if (lo <= hi) atomicMax(&num_cells[i % 3], (int)__fdiv_rn(__fsub_rn(hi_s, lo_s), radius) + 1);
+  const float lo_s = __fsub_rn(lo, 1e-6f), hi_s = __fadd_rn(hi, max_shift);
+  if (lo <= hi) atomicMax(&num_cells[i % 3], (int)__fdiv_rn(__fsub_rn(hi_s, lo_s), cell) + 1);
   mn[i] = lo_s;
 }
 }  // namespace
@@ -399,8 +400,8 @@ extern "C" int se3_ball_query_grid(const float* pts_src, const int32_t* batch_sr
   hipStream_t stream = (hipStream_t)stream_;
   if (hipMemsetAsync(num_cells, 0, 3 * sizeof(int32_t), stream) != hipSuccess) return SE3_ERR_LAUNCH;
   if (int rc = se3_batch_aabb(pts_src, batch_src, n_src, n_batches, aabb_min, aabb_max_scratch, stream_)) return rc;
-  hipLaunchKernelGGL(ball_query_grid_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, aabb_min,
-                     aabb_max_scratch, n_batches, radius, num_cells);
+  hipLaunchKernelGGL(grid_params_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, aabb_min,
+                     aabb_max_scratch, n_batches, radius, -1e-6f, num_cells);
   return check_launch();
 }
 
@@ -560,5 +561,267 @@ extern "C" int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int6
       return SE3_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(group_ends_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, ssrc, n_edges, n_src, t_ends);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hierarchy build (scope row f-2): grid sub-sampling and the pool / up-sample maps between two levels.
+//   reference: pc/Grid.py:20-51 (bounding box, cell counts, ComputeKeys, torch.unique(return_inverse)),
+//              pc/GridSubSample.py:63-93 (scatter_mean / scatter_max over the cell ids, gather for up-sampling),
+//              pc/PointHierarchy.py:40-51 (level points = cell means, level batch ids = cell max).
+// Cells are numbered in ascending key order (what torch.unique returns); inside a cell the points keep their
+// input order (stable sort), so every reduction below has a fixed summation order (the reference's is not defined).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void cell_heads_kernel(const int64_t* __restrict__ skeys, int64_t n, int32_t* __restrict__ flags) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    flags[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1 : 0;
+}
+
+// ranks = inclusive scan of the head flags: position i of the sorted order belongs to cell ranks[i] - 1
+__global__ void cell_scatter_kernel(const int32_t* __restrict__ sids, const int32_t* __restrict__ ranks,
+                                    const int32_t* __restrict__ flags, int64_t n, int32_t* __restrict__ cell_ids,
+                                    int32_t* __restrict__ cell_ends, int32_t* __restrict__ n_cells) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = ranks[i] - 1;
+    cell_ids[sids[i]] = r;
+    if (i == n - 1 || flags[i + 1]) cell_ends[r] = (int32_t)(i + 1);
+    if (i == n - 1) *n_cells = r + 1;
+  }
+}
+
+enum { kPoolAvg = 0, kPoolMax = 1, kPoolMin = 2, kPoolSum = 3 };
+
+// out[cell, ch] = reduce over the cell's rows (sorted_ids[start .. end)) of src[row, ch]; thread = (cell, channel),
+// channels fastest, so a cell's row is read with consecutive lanes.  n_cells_dev != nullptr: the cell count is still
+// on the device (inside se3_grid_subsample); the grid is sized for the upper bound.
+template <int MODE>
+__global__ void segment_pool_kernel(const float* __restrict__ src, const int32_t* __restrict__ sorted_ids,
+                                    const int32_t* __restrict__ cell_ends, int64_t n_cells, const int32_t* n_cells_dev,
+                                    int c, float* __restrict__ out, int32_t* __restrict__ arg) {
+  if (n_cells_dev) n_cells = *n_cells_dev;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_cells * c;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = idx / c;
+    const int ch = (int)(idx - cell * c);
+    const int start = cell > 0 ? cell_ends[cell - 1] : 0, end = cell_ends[cell];
+    float acc = 0.f;
+    int best = -1;
+    for (int j = start; j < end; ++j) {
+      const int id = sorted_ids[j];
+      const float v = src[(int64_t)id * c + ch];
+      if (MODE == kPoolAvg || MODE == kPoolSum) {
+        acc += v;
+      } else if (best < 0 || (MODE == kPoolMax ? v > acc : v < acc)) {  // first extremum wins (lowest row id)
+        acc = v, best = id;
+      }
+    }
+    if (MODE == kPoolAvg && end > start) acc = __fdiv_rn(acc, (float)(end - start));
+    out[idx] = acc;
+    if (arg) arg[idx] = best;
+  }
+}
+
+// the maps from cells back to rows: MODE sum = plain gather (the up-sampling itself and the gradient of a sum),
+// avg = gather / cell size, max / min = the gradient goes to the row that supplied the extremum
+template <int MODE>
+__global__ void segment_unpool_kernel(const float* __restrict__ cell_vals, const int32_t* __restrict__ cell_ids,
+                                      const int32_t* __restrict__ cell_ends, const int32_t* __restrict__ arg, int64_t n,
+                                      int c, float* __restrict__ out) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * c; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / c;
+    const int ch = (int)(idx - row * c);
+    const int cell = cell_ids[row];
+    float v = cell_vals[(int64_t)cell * c + ch];
+    if (MODE == kPoolAvg) v = __fdiv_rn(v, (float)(cell_ends[cell] - (cell > 0 ? cell_ends[cell - 1] : 0)));
+    if (MODE == kPoolMax || MODE == kPoolMin) v = arg[(int64_t)cell * c + ch] == (int32_t)row ? v : 0.f;
+    out[idx] = v;
+  }
+}
+
+__global__ void cell_batch_ids_kernel(const int32_t* __restrict__ batch_ids, const int32_t* __restrict__ sorted_ids,
+                                      const int32_t* __restrict__ cell_ends, const int32_t* __restrict__ n_cells_dev,
+                                      int32_t* __restrict__ out) {
+  const int64_t n_cells = *n_cells_dev;
+  for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < n_cells; cell += (int64_t)gridDim.x * blockDim.x)
+    out[cell] = batch_ids[sorted_ids[cell > 0 ? cell_ends[cell - 1] : 0]];  // the batch id is part of the key
+}
+
+// Frame pooling (scope row f-3, pc/PointcloudRotEquiv.py:224-251): rows point*F + frame -> one row per point
+template <int MODE>
+__global__ void frame_pool_kernel(const float* __restrict__ x, int64_t n_pts, int f, int c, float* __restrict__ out,
+                                  int32_t* __restrict__ arg) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_pts * c; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = idx / c;
+    const int ch = (int)(idx - p * c);
+    float acc = 0.f;
+    int best = -1;
+    for (int a = 0; a < f; ++a) {
+      const float v = x[(p * f + a) * c + ch];
+      if (MODE == kPoolAvg || MODE == kPoolSum) acc += v;
+      else if (best < 0 || (MODE == kPoolMax ? v > acc : v < acc)) acc = v, best = a;
+    }
+    if (MODE == kPoolAvg) acc = __fdiv_rn(acc, (float)f);
+    out[idx] = acc;
+    if (arg) arg[idx] = best;
+  }
+}
+
+template <int MODE>
+__global__ void frame_unpool_kernel(const float* __restrict__ g, const int32_t* __restrict__ arg, int64_t n_pts, int f,
+                                    int c, float* __restrict__ out) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_pts * f * c;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / c;
+    const int ch = (int)(idx - row * c);
+    const int64_t p = row / f;
+    const int a = (int)(row - p * f);
+    float v = g[p * c + ch];
+    if (MODE == kPoolAvg) v = __fdiv_rn(v, (float)f);
+    if (MODE == kPoolMax || MODE == kPoolMin) v = arg[p * c + ch] == a ? v : 0.f;
+    out[idx] = v;
+  }
+}
+
+struct GsLayout {
+  size_t box_min, box_max, num_cells, keys, skeys, ids, flags, ranks, temp, temp_bytes, total;
+};
+
+GsLayout gs_layout(int64_t n, int n_batches) {
+  GsLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t nn = (size_t)(n > 0 ? n : 1), nb = (size_t)(n_batches > 0 ? n_batches : 1);
+  l.box_min = take(nb * 12), l.box_max = take(nb * 12), l.num_cells = take(16);
+  l.keys = take(nn * 8), l.skeys = take(nn * 8), l.ids = take(nn * 4), l.flags = take(nn * 4), l.ranks = take(nn * 4);
+  size_t sort_bytes = 0, scan_bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr,
+                                           (int32_t*)nullptr, (int)nn);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)nn);
+  l.temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  l.temp = take(l.temp_bytes);
+  l.total = off;
+  return l;
+}
+
+}  // namespace
+
+extern "C" size_t se3_grid_subsample_workspace_bytes(int64_t n, int32_t n_batches) { return gs_layout(n, n_batches).total; }
+
+extern "C" int se3_grid_subsample(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches,
+                                  float cell_size, void* workspace, size_t workspace_bytes, int32_t* cell_ids,
+                                  int32_t* sorted_ids, int32_t* cell_ends, int32_t* n_cells, float* cell_pts,
+                                  int32_t* cell_batch_ids, void* stream_) {
+  if (n < 0 || n_batches < 1 || !(cell_size > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
+  if (n >= (1ll << 31) / 3) return SE3_ERR_UNSUPPORTED;
+  if (!n_cells) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return hipMemsetAsync(n_cells, 0, sizeof(int32_t), stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  if (!pts || !batch_ids || !workspace || !cell_ids || !sorted_ids || !cell_ends || !cell_pts || !cell_batch_ids)
+    return SE3_ERR_INVALID_ARGUMENT;
+  const GsLayout l = gs_layout(n, n_batches);
+  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  float* box_min = (float*)(ws + l.box_min);
+  float* box_max = (float*)(ws + l.box_max);
+  int32_t* num_cells = (int32_t*)(ws + l.num_cells);
+  int64_t* keys = (int64_t*)(ws + l.keys);
+  int64_t* skeys = (int64_t*)(ws + l.skeys);
+  int32_t* ids = (int32_t*)(ws + l.ids);
+  int32_t* flags = (int32_t*)(ws + l.flags);
+  int32_t* ranks = (int32_t*)(ws + l.ranks);
+  if (hipMemsetAsync(num_cells, 0, 3 * sizeof(int32_t), stream) != hipSuccess) return SE3_ERR_LAUNCH;
+  if (int rc = se3_batch_aabb(pts, batch_ids, n, n_batches, box_min, box_max, stream_)) return rc;
+  hipLaunchKernelGGL(grid_params_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, box_min, box_max,
+                     n_batches, cell_size, 1e-6f, num_cells);
+  hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, pts, batch_ids, box_min, num_cells,
+                     (const float*)nullptr, cell_size, n, keys, ids);
+  size_t temp_bytes = l.temp_bytes;
+  if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sorted_ids, (int)n, 0, 64, stream) !=
+      hipSuccess)
+    return SE3_ERR_LAUNCH;
+  hipLaunchKernelGGL(cell_heads_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, skeys, n, flags);
+  temp_bytes = l.temp_bytes;
+  if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, flags, ranks, (int)n, stream) != hipSuccess)
+    return SE3_ERR_LAUNCH;
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, sorted_ids, ranks, flags, n, cell_ids,
+                     cell_ends, n_cells);
+  // level points = cell means (first n_cells rows of cell_pts), level batch ids
+  hipLaunchKernelGGL(segment_pool_kernel<kPoolAvg>, dim3(blocks_for(n * 3)), dim3(256), 0, stream, pts, sorted_ids,
+                     cell_ends, (int64_t)0, n_cells, 3, cell_pts, (int32_t*)nullptr);
+  hipLaunchKernelGGL(cell_batch_ids_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, batch_ids, sorted_ids, cell_ends,
+                     n_cells, cell_batch_ids);
+  return check_launch();
+}
+
+extern "C" int se3_segment_pool(const float* src, const int32_t* sorted_ids, const int32_t* cell_ends, int64_t n_cells,
+                                int32_t channels, int32_t mode, float* out, int32_t* arg, void* stream_) {
+  if (n_cells < 0 || channels < 1 || mode < kPoolAvg || mode > kPoolSum) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_cells == 0) return SE3_OK;
+  if (!src || !sorted_ids || !cell_ends || !out) return SE3_ERR_INVALID_ARGUMENT;
+  if ((mode == kPoolMax || mode == kPoolMin) && !arg) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid(blocks_for(n_cells * channels)), block(256);
+#define SE3_POOL(M)                                                                                                   \
+  hipLaunchKernelGGL(segment_pool_kernel<M>, grid, block, 0, stream, src, sorted_ids, cell_ends, n_cells,                 \
+                     (const int32_t*)nullptr, channels, out, arg)
+  if (mode == kPoolAvg) SE3_POOL(kPoolAvg);
+  else if (mode == kPoolMax) SE3_POOL(kPoolMax);
+  else if (mode == kPoolMin) SE3_POOL(kPoolMin);
+  else SE3_POOL(kPoolSum);
+#undef SE3_POOL
+  return check_launch();
+}
+
+extern "C" int se3_segment_unpool(const float* cell_vals, const int32_t* cell_ids, const int32_t* cell_ends,
+                                  const int32_t* arg, int64_t n, int32_t channels, int32_t mode, float* out,
+                                  void* stream_) {
+  if (n < 0 || channels < 1 || mode < kPoolAvg || mode > kPoolSum) return SE3_ERR_INVALID_ARGUMENT;
+  if (n == 0) return SE3_OK;
+  if (!cell_vals || !cell_ids || !out || (mode == kPoolAvg && !cell_ends)) return SE3_ERR_INVALID_ARGUMENT;
+  if ((mode == kPoolMax || mode == kPoolMin) && !arg) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid(blocks_for(n * channels)), block(256);
+#define SE3_UNPOOL(M) \
+  hipLaunchKernelGGL(segment_unpool_kernel<M>, grid, block, 0, stream, cell_vals, cell_ids, cell_ends, arg, n, channels, out)
+  if (mode == kPoolAvg) SE3_UNPOOL(kPoolAvg);
+  else if (mode == kPoolMax) SE3_UNPOOL(kPoolMax);
+  else if (mode == kPoolMin) SE3_UNPOOL(kPoolMin);
+  else SE3_UNPOOL(kPoolSum);
+#undef SE3_UNPOOL
+  return check_launch();
+}
+
+extern "C" int se3_frame_pool(const float* x, int64_t n_points, int32_t frames, int32_t channels, int32_t mode, float* out,
+                              int32_t* arg, void* stream_) {
+  if (n_points < 0 || frames < 1 || channels < 1 || mode < kPoolAvg || mode > kPoolSum) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_points == 0) return SE3_OK;
+  if (!x || !out || ((mode == kPoolMax || mode == kPoolMin) && !arg)) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid(blocks_for(n_points * channels)), block(256);
+#define SE3_FPOOL(M) hipLaunchKernelGGL(frame_pool_kernel<M>, grid, block, 0, stream, x, n_points, frames, channels, out, arg)
+  if (mode == kPoolAvg) SE3_FPOOL(kPoolAvg);
+  else if (mode == kPoolMax) SE3_FPOOL(kPoolMax);
+  else if (mode == kPoolMin) SE3_FPOOL(kPoolMin);
+  else SE3_FPOOL(kPoolSum);
+#undef SE3_FPOOL
+  return check_launch();
+}
+
+extern "C" int se3_frame_unpool(const float* grad_out, const int32_t* arg, int64_t n_points, int32_t frames,
+                                int32_t channels, int32_t mode, float* grad_x, void* stream_) {
+  if (n_points < 0 || frames < 1 || channels < 1 || mode < kPoolAvg || mode > kPoolSum) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_points == 0) return SE3_OK;
+  if (!grad_out || !grad_x || ((mode == kPoolMax || mode == kPoolMin) && !arg)) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid(blocks_for(n_points * frames * channels)), block(256);
+#define SE3_FUNPOOL(M) \
+  hipLaunchKernelGGL(frame_unpool_kernel<M>, grid, block, 0, stream, grad_out, arg, n_points, frames, channels, grad_x)
+  if (mode == kPoolAvg) SE3_FUNPOOL(kPoolAvg);
+  else if (mode == kPoolMax) SE3_FUNPOOL(kPoolMax);
+  else if (mode == kPoolMin) SE3_FUNPOOL(kPoolMin);
+  else SE3_FUNPOOL(kPoolSum);
+#undef SE3_FUNPOOL
   return check_launch();
 }

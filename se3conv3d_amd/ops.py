@@ -38,7 +38,14 @@ def get_precision() -> str:
 
 
 # --------------------------------------------------------------------------------------- helpers
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> C.c_void_p:
+    """The current HIP stream of the current device (the raw query: ``torch.cuda.current_stream()`` builds a Python
+    object through several device-index lookups, ~20 us per call)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -201,6 +208,137 @@ def csr_transpose(neighbors_i32: torch.Tensor, n_src: int) -> Tuple[torch.Tensor
                                      C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(t_samples, torch.int32, "t_samples"),
                                      _ptr(t_ends, torch.int32, "t_ends"), _stream()), "se3_csr_transpose")
     return t_samples, t_ends
+
+
+# ------------------------------------------------------------------------- hierarchy build (row f-2)
+POOL_MODES = {"avg": 0, "max": 1, "min": 2, "sum": 3}
+
+
+class GridCells:
+    """Result of one grid sub-sampling step (``se3_grid_subsample``): the cell of every point (what
+    ``torch.unique(keys, return_inverse=True)`` returns in Grid.py:45), the points grouped by cell, the cell sizes
+    as inclusive end offsets, and the next level's points / batch ids (PointHierarchy.py:46-49)."""
+
+    def __init__(self, cell_ids, sorted_ids, cell_ends, n_cells, pts, batch_ids):
+        self.cell_ids, self.sorted_ids, self.cell_ends, self.n_cells = cell_ids, sorted_ids, cell_ends, n_cells
+        self.pts, self.batch_ids = pts, batch_ids
+
+
+def grid_subsample(pts, batch_ids, cell_size: float, n_batches: Optional[int] = None) -> GridCells:
+    lib = _lib.load()
+    pts = _as(pts, torch.float32)
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("grid_subsample: only [N,3] point sets are supported")
+    if not (cell_size > 0):
+        raise ValueError("grid_subsample: cell size must be positive")
+    b = _as(batch_ids, torch.int32)
+    dev, n = pts.device, pts.shape[0]
+    if n_batches is None:
+        n_batches = int(b.max().item()) + 1 if n else 1
+    i32 = torch.int32
+    cell_ids = torch.empty(n, dtype=i32, device=dev)
+    sorted_ids = torch.empty(n, dtype=i32, device=dev)
+    cell_ends = torch.empty(n, dtype=i32, device=dev)
+    n_cells = torch.zeros(1, dtype=i32, device=dev)
+    cell_pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    cell_bid = torch.empty(n, dtype=i32, device=dev)
+    ws = _workspace(lib.se3_grid_subsample_workspace_bytes(n, n_batches), dev)
+    _lib.check(lib.se3_grid_subsample(
+        _ptr(pts, torch.float32, "pts"), _ptr(b, i32, "batch_ids", dev), n, n_batches, float(cell_size),
+        C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(cell_ids, i32, "cell_ids"), _ptr(sorted_ids, i32, "sorted_ids"),
+        _ptr(cell_ends, i32, "cell_ends"), _ptr(n_cells, i32, "n_cells"), _ptr(cell_pts, torch.float32, "cell_pts"),
+        _ptr(cell_bid, i32, "cell_batch_ids"), _stream()), "se3_grid_subsample")
+    m = int(n_cells.item())  # the level size has to reach the host: every later allocation depends on it
+    return GridCells(cell_ids, sorted_ids, cell_ends[:m], m, cell_pts[:m], cell_bid[:m])
+
+
+def _rows2d(t):
+    return t.reshape(t.shape[0], -1) if t.dim() != 2 else t
+
+
+def _segment_pool(cells: GridCells, x2, mode: int, want_arg: bool):
+    lib = _lib.load()
+    c = x2.shape[1]
+    out = torch.empty((cells.n_cells, c), dtype=torch.float32, device=x2.device)
+    arg = torch.empty((cells.n_cells, c), dtype=torch.int32, device=x2.device) if want_arg else None
+    _lib.check(lib.se3_segment_pool(_ptr(x2, torch.float32, "src"), _ptr(cells.sorted_ids, torch.int32, "sorted_ids"),
+                                    _ptr(cells.cell_ends, torch.int32, "cell_ends"), cells.n_cells, c, mode,
+                                    _ptr(out, torch.float32, "out"), _ptr(arg, torch.int32, "arg"), _stream()),
+               "se3_segment_pool")
+    return out, arg
+
+
+def _segment_unpool(cells: GridCells, v2, arg, mode: int):
+    lib = _lib.load()
+    n, c = cells.cell_ids.shape[0], v2.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=v2.device)
+    _lib.check(lib.se3_segment_unpool(_ptr(v2, torch.float32, "cell_vals"), _ptr(cells.cell_ids, torch.int32, "cell_ids"),
+                                      _ptr(cells.cell_ends, torch.int32, "cell_ends"), _ptr(arg, torch.int32, "arg"),
+                                      n, c, mode, _ptr(out, torch.float32, "out"), _stream()), "se3_segment_unpool")
+    return out
+
+
+class GridPool(torch.autograd.Function):
+    """``pool_tensor`` of one level step (GridSubSample.py:63-77): rows of level l -> rows of level l+1."""
+
+    @staticmethod
+    def forward(ctx, x, cells, method):
+        mode = POOL_MODES[method]
+        x2 = _rows2d(_as(x, torch.float32))
+        out, arg = _segment_pool(cells, x2, mode, mode in (1, 2))
+        ctx.cells, ctx.mode, ctx.arg, ctx.shape = cells, mode, arg, x.shape
+        return out.reshape((cells.n_cells,) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = _rows2d(_as(g, torch.float32))
+        return _segment_unpool(ctx.cells, g2, ctx.arg, ctx.mode).reshape(ctx.shape), None, None
+
+
+class GridUpsample(torch.autograd.Function):
+    """``upsample_tensor`` (GridSubSample.py:93: ``p_tensor[cell_ids]``); the gradient is a segment sum in fixed order
+    instead of the atomics of an index_add."""
+
+    @staticmethod
+    def forward(ctx, x, cells):
+        x2 = _rows2d(_as(x, torch.float32))
+        ctx.cells, ctx.shape = cells, x.shape
+        return _segment_unpool(cells, x2, None, 3).reshape((cells.cell_ids.shape[0],) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = _rows2d(_as(g, torch.float32))
+        return _segment_pool(ctx.cells, g2, 3, False)[0].reshape(ctx.shape), None
+
+
+# ------------------------------------------------------------------------------ frame pooling (row f-3)
+class FramePool(torch.autograd.Function):
+    """``PointcloudRotEquiv.feature_pooling`` (pc/PointcloudRotEquiv.py:224-251): [N*F, C] -> [N, C]."""
+
+    @staticmethod
+    def forward(ctx, x, n_frames, method):
+        lib = _lib.load()
+        mode = POOL_MODES[method]
+        x2 = _rows2d(_as(x, torch.float32))
+        if x2.shape[0] % n_frames:
+            raise ValueError("feature_pooling: rows are not a multiple of the frame count")
+        n, c = x2.shape[0] // n_frames, x2.shape[1]
+        out = torch.empty((n, c), dtype=torch.float32, device=x2.device)
+        arg = torch.empty((n, c), dtype=torch.int32, device=x2.device) if mode in (1, 2) else None
+        _lib.check(lib.se3_frame_pool(_ptr(x2, torch.float32, "x"), n, n_frames, c, mode, _ptr(out, torch.float32, "out"),
+                                      _ptr(arg, torch.int32, "arg"), _stream()), "se3_frame_pool")
+        ctx.mode, ctx.arg, ctx.f, ctx.shape = mode, arg, n_frames, x.shape
+        return out.reshape((n,) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        g2 = _rows2d(_as(g, torch.float32))
+        n, c = g2.shape
+        gx = torch.empty((n * ctx.f, c), dtype=torch.float32, device=g2.device)
+        _lib.check(lib.se3_frame_unpool(_ptr(g2, torch.float32, "grad_out"), _ptr(ctx.arg, torch.int32, "arg"), n, ctx.f, c,
+                                        ctx.mode, _ptr(gx, torch.float32, "grad_x"), _stream()), "se3_frame_unpool")
+        return gx.reshape(ctx.shape), None, None
 
 
 # ------------------------------------------------------------------------------- frames (row f-1)

@@ -144,17 +144,11 @@ class PointcloudRotEquiv(Pointcloud):
         self.batch_ids_considering_frames_ = self.batch_ids_considering_frames_.to(p_device)
 
     def feature_pooling(self, p_in_tensor, p_pooling_method="avg"):
-        """Pool the F per-frame feature rows of every point (pc/PointcloudRotEquiv.py:224-251)."""
-        x = p_in_tensor.reshape(self.pts_.shape[0], self.n_frames_, -1)
-        if p_pooling_method == "avg":
-            return x.mean(1)
-        if p_pooling_method == "max":
-            return x.max(1)[0]
-        if p_pooling_method == "min":
-            return x.min(1)[0]
-        if p_pooling_method == "sum":
-            return x.sum(1)
-        raise ValueError(p_pooling_method)
+        """Pool the F per-frame feature rows of every point (pc/PointcloudRotEquiv.py:224-251), one HIP kernel
+        forward and one backward."""
+        if p_pooling_method not in ops.POOL_MODES:
+            raise ValueError(p_pooling_method)
+        return ops.FramePool.apply(p_in_tensor, self.n_frames_, p_pooling_method)
 
 
 # ----------------------------------------------------------------------------------- neighbourhoods
@@ -219,33 +213,31 @@ def sample_reference_frames_pca(points, p_neighborhood, axis_fixed=False, dtype=
 
 # --------------------------------------------------------------------------------------- hierarchy
 class GridSubSample(object):
-    """Grid-average sub-sampling (pc/GridSubSample.py, pc/Grid.py, pc/BoundingBox.py)."""
+    """Grid-average sub-sampling (pc/GridSubSample.py, pc/Grid.py, pc/BoundingBox.py): one library call builds the cell
+    ids, the per-cell point lists and the next level's points / batch ids (``ops.grid_subsample``)."""
 
     def __init__(self, p_pc_src, p_cell_size):
         self.pc_src_ = p_pc_src
         self.cell_size_ = p_cell_size
-        pts = p_pc_src.pts_
-        mn, mx = ops.batch_aabb(pts, p_pc_src.batch_ids_, p_pc_src.num_batches())  # BoundingBox.py:17-18
-        mn, mx = mn - 1e-6, mx + 1e-6
-        self.num_cells_ = (((mx - mn) / p_cell_size).to(torch.int32) + 1).max(dim=0)[0]
-        keys = ops.ComputeKeys.apply(pts, p_pc_src.batch_ids_, mn, self.num_cells_,
-                                     torch.full((3,), p_cell_size, dtype=torch.float32, device=pts.device))
-        _, self.cell_ids_ = torch.unique(keys, return_inverse=True)
-        self.num_out_ = int(self.cell_ids_.max().item()) + 1 if keys.numel() else 0
+        self.cells_ = ops.grid_subsample(p_pc_src.pts_, p_pc_src.batch_ids_, p_cell_size, p_pc_src.num_batches())
+        self.cell_ids_ = self.cells_.cell_ids
+        self.num_out_ = self.cells_.n_cells
 
     def __subsample_tensor__(self, p_tensor, p_method="avg"):
-        idx = self.cell_ids_
-        if p_tensor.dim() > 1:
-            idx = idx.reshape((-1,) + (1,) * (p_tensor.dim() - 1)).expand_as(p_tensor)
-        out = torch.zeros((self.num_out_,) + tuple(p_tensor.shape[1:]), dtype=p_tensor.dtype, device=p_tensor.device)
-        if p_method == "avg":
-            return out.scatter_reduce(0, idx, p_tensor, "mean", include_self=False)
-        if p_method == "max":
-            return out.scatter_reduce(0, idx, p_tensor, "amax", include_self=False)
-        raise ValueError(p_method)
+        if p_method not in ("avg", "max"):
+            raise ValueError(p_method)
+        if p_tensor is self.pc_src_.pts_ and p_method == "avg" and not p_tensor.requires_grad:
+            return self.cells_.pts
+        if p_tensor is self.pc_src_.batch_ids_ and p_method == "max":
+            return self.cells_.batch_ids.to(p_tensor.dtype)
+        if not p_tensor.is_floating_point():
+            return ops.GridPool.apply(p_tensor.to(torch.float32), self.cells_, p_method).to(p_tensor.dtype)
+        return ops.GridPool.apply(p_tensor, self.cells_, p_method)
 
     def __upsample_tensor__(self, p_tensor):
-        return p_tensor[self.cell_ids_]
+        if not p_tensor.is_floating_point():
+            return p_tensor[self.cell_ids_.to(torch.int64)]
+        return ops.GridUpsample.apply(p_tensor, self.cells_)
 
 
 class PointHierarchy(object):

@@ -146,3 +146,37 @@ def test_oracle_pne_layer_matches_reference_fixture(path):
     for got, key in ((out, "out"), (dx, "dx"), (da, "dA"), (db, "dbeta"), (dw, "dW")):
         ref = torch.as_tensor(d[key]).double()
         assert float((got - ref).norm() / ref.norm()) < 2e-6, key
+
+
+def test_oracle_hierarchy_and_frame_pooling_match_reference_fixture():
+    """Scope rows f-2 / f-3: grid sub-sampling (cell ids bit-exact, level points / batch ids), pool / up-sample maps
+    and frame pooling with their gradients against the reference's PointHierarchy / feature_pooling."""
+    d = np.load(os.path.join(GOLDEN, "hierarchy.npz"))
+    pts, bid = torch.from_numpy(d["pts"]), torch.from_numpy(d["batch"])
+    for lv in (0, 1):
+        ids, m, lp, lb = O.grid_subsample(pts, bid, float(d["cells"][lv]))
+        assert np.array_equal(ids.numpy(), d[f"cell_ids_l{lv}"].astype(np.int64))
+        assert m == d[f"pts_l{lv + 1}"].shape[0]
+        np.testing.assert_allclose(lp.numpy(), d[f"pts_l{lv + 1}"], rtol=0, atol=2e-7)
+        assert np.array_equal(lb.numpy(), d[f"batch_l{lv + 1}"])
+        pts, bid = lp, lb
+    ids0 = torch.from_numpy(d["cell_ids_l0"]).long()
+    m0 = d["pts_l1"].shape[0]
+    for method in ("avg", "max"):
+        x = torch.from_numpy(d[f"pool_{method}_x"]).requires_grad_(True)
+        y = O.segment_pool(x, ids0, m0, method)
+        y.backward(torch.from_numpy(d[f"pool_{method}_g"]))
+        np.testing.assert_allclose(y.detach().numpy(), d[f"pool_{method}_y"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(x.grad.numpy(), d[f"pool_{method}_dx"], rtol=0, atol=1e-6)
+    z = torch.from_numpy(d["up_z"]).requires_grad_(True)
+    up = O.segment_upsample(z, ids0)
+    up.backward(torch.from_numpy(d["up_g"]))
+    assert np.array_equal(up.detach().numpy(), d["up_y"])
+    np.testing.assert_allclose(z.grad.numpy(), d["up_dz"], rtol=0, atol=1e-5)
+    f = int(d["frames"])
+    for method in ("avg", "max", "min", "sum"):
+        x = torch.from_numpy(d[f"fpool_{method}_x"]).requires_grad_(True)
+        y = O.frame_pool(x, f, method)
+        y.backward(torch.from_numpy(d[f"fpool_{method}_g"]))
+        np.testing.assert_allclose(y.detach().numpy(), d[f"fpool_{method}_y"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(x.grad.numpy(), d[f"fpool_{method}_dx"], rtol=0, atol=1e-6)

@@ -90,7 +90,15 @@ def _install_shims():
         return out
 
     ops.knn_query = knn_query
-    ops.compute_keys = _unavailable
+    def compute_keys(pts, batch_ids, aabb_min, num_cells, cell_size):
+        # compute_keys.cu:32-71, grid_utils.cuh:57-93: cell = clamp(floor((p - min[b]) * (1/cell))), row-major key
+        inv = torch.reciprocal(cell_size.to(torch.float32))
+        rel = (pts.to(torch.float32) - aabb_min[batch_ids.long()]) * inv
+        nc = num_cells.to(torch.int64)
+        cell = torch.minimum(torch.maximum(torch.floor(rel).to(torch.int64), torch.zeros(3, dtype=torch.int64)), nc - 1)
+        return ((batch_ids.to(torch.int64) * nc[0] + cell[:, 0]) * nc[1] + cell[:, 1]) * nc[2] + cell[:, 2]
+
+    ops.compute_keys = compute_keys
     sys.modules["point_cloud_lib_ops"] = ops
 
     ts = types.ModuleType("torch_scatter")
@@ -235,6 +243,46 @@ def pca_case(pclib, seed):
     return out
 
 
+def hierarchy_case(pclib, seed):
+    """Scope rows f-2 / f-3 through the reference's Python: PointHierarchy (grid_avg, two sub-samples: Grid,
+    BoundingBox, GridSubSample with the scatter stand-ins), pool_tensor avg / max with gradients, upsample_tensor with
+    gradient, and PointcloudRotEquiv.feature_pooling for every method with gradients."""
+    torch.manual_seed(seed)
+    n, c, f = 700, 12, 4
+    pts = torch.rand(n, 3) * torch.tensor([1.0, 0.8, 0.5])
+    bid = torch.sort(torch.randint(0, 3, (n,), dtype=torch.int32)).values
+    cells = [0.11, 0.23]
+    hier = pclib.pc.PointHierarchy(pclib.pc.Pointcloud(pts, bid), 2, "grid_avg", grid_radii=cells)
+    out = {"pts": pts.numpy(), "batch": bid.numpy(), "cells": np.array(cells, dtype=np.float32)}
+    for lv in (1, 2):
+        out[f"pts_l{lv}"] = hier.pcs_[lv].pts_.numpy()
+        out[f"batch_l{lv}"] = hier.pcs_[lv].batch_ids_.numpy().astype(np.int32)
+        out[f"cell_ids_l{lv - 1}"] = hier.sub_sampled_objs_[lv - 1].grid_.cell_ids_.numpy().astype(np.int32)
+    for method in ("avg", "max"):
+        x = torch.randn(n, c, requires_grad=True)
+        y = hier.pool_tensor(x, 0, 1, method)
+        g = torch.randn_like(y)
+        y.backward(g)
+        out[f"pool_{method}_x"], out[f"pool_{method}_y"] = x.detach().numpy(), y.detach().numpy()
+        out[f"pool_{method}_g"], out[f"pool_{method}_dx"] = g.numpy(), x.grad.numpy()
+    z = torch.randn(hier.pcs_[1].pts_.shape[0], c, requires_grad=True)
+    up = hier.upsample_tensor(z, 1, 0)
+    gu = torch.randn_like(up)
+    up.backward(gu)
+    out["up_z"], out["up_y"], out["up_g"], out["up_dz"] = z.detach().numpy(), up.detach().numpy(), gu.numpy(), z.grad.numpy()
+    cfg = {"pca": False, "n_frames": f, "fixed_axis": False}
+    pcr = pclib.pc.PointcloudRotEquiv(pts[:150], bid[:150], cfg)
+    out["frames"] = np.int32(f)
+    for method in ("avg", "max", "min", "sum"):
+        xf = torch.randn(150 * f, c, requires_grad=True)
+        yf = pcr.feature_pooling(xf, method)
+        gf = torch.randn_like(yf)
+        yf.backward(gf)
+        out[f"fpool_{method}_x"], out[f"fpool_{method}_y"] = xf.detach().numpy(), yf.detach().numpy()
+        out[f"fpool_{method}_g"], out[f"fpool_{method}_dx"] = gf.numpy(), xf.grad.numpy()
+    return out
+
+
 def pne_case(pclib, seed, n_in, n_out, c_in, c_out, k_deg, batches):
     """The reference's non-equivariant PNEConvLayer ('mlp_gelu', aggregation 'add', 3-D offsets; scope row f-4):
     plain Pointcloud, BQNeighborhood, forward + backward through LinearPNE / FeatBasisProj / einsum."""
@@ -295,6 +343,12 @@ def main():
     pclib = _import_reference()
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("", "hierarchy"):
+        path = os.path.join(OUT, "hierarchy.npz")
+        np.savez_compressed(path, **hierarchy_case(pclib, 11))
+        print(f"{path}: size={os.path.getsize(path) / 1e6:.2f} MB")
+    if only == "hierarchy":
+        return
     for name, seed, n_in, n_out, c_in, c_out, k, b in PNE_CASES:
         path = os.path.join(OUT, f"{name}.npz")
         np.savez_compressed(path, **pne_case(pclib, seed, n_in, n_out, c_in, c_out, k, b))
