@@ -385,8 +385,8 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
 #ifndef SE3_STRIP_ROT
 #define SE3_STRIP_ROT 17
 #endif
-template <int KS>  // kp / 16
-__global__ __launch_bounds__(256, 4) void gemm_strip_bf16_kernel(const uint32_t* __restrict__ a,
+template <int KS>  // kp / 16: 2, 4 (k <= 64, 120 VGPRs) or 8 (k <= 128: twice the fragments, 3 waves per SIMD)
+__global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void gemm_strip_bf16_kernel(const uint32_t* __restrict__ a,
                                                                  const uint16_t* __restrict__ bt_hi,
                                                                  const uint16_t* __restrict__ bt_lo,
                                                                  uint32_t* __restrict__ c, int64_t m, int n, int k) {
@@ -430,27 +430,33 @@ __global__ __launch_bounds__(256, 4) void gemm_strip_bf16_kernel(const uint32_t*
   u32x4 bh[KS], bl[KS];
   auto load_b = [&](int n0) {
     const uint32_t off = (uint32_t)(((n0 / 32) * KS * 64 + lane) * 16);  // fragment-ordered planes, 1 KB per k-step
+    const uint32_t off4 = off + 4096u;  // the instruction's immediate offset has 12 bits: k-steps 4.. go through here
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
                    : "+v"(bh[ks])
-                   : "v"(off), "s"(bh_rs), "n"(1024 * ks)
+                   : "v"(ks < 4 ? off : off4), "s"(bh_rs), "n"(1024 * (ks & 3))
                    : "memory");
       asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3"
                    : "+v"(bl[ks])
-                   : "v"(off), "s"(bl_rs), "n"(1024 * ks)
+                   : "v"(ks < 4 ? off : off4), "s"(bl_rs), "n"(1024 * (ks & 3))
                    : "memory");
     }
   };
-  static_assert(KS == 2 || KS == 4, "operand lists of SE3_WAIT_B");
+  static_assert(KS == 2 || KS == 4 || KS == 8, "operand lists of SE3_WAIT_B");
 #define SE3_WAIT_B(CNT)                                                                                           \
   do {                                                                                                            \
     if constexpr (KS == 2)                                                                                        \
       asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bl[0]), "+v"(bl[1])::"memory");   \
-    else                                                                                                          \
+    else if constexpr (KS == 4)                                                                                   \
       asm volatile("s_waitcnt vmcnt(" #CNT ")"                                                                    \
                    : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[KS - 2]), "+v"(bh[KS - 1]), "+v"(bl[0]), "+v"(bl[1]),      \
                      "+v"(bl[KS - 2]), "+v"(bl[KS - 1])::"memory");                                               \
+    else                                                                                                          \
+      asm volatile("s_waitcnt vmcnt(" #CNT ")"                                                                    \
+                   : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]), "+v"(bh[KS - 4]), "+v"(bh[KS - 3]),      \
+                     "+v"(bh[KS - 2]), "+v"(bh[KS - 1]), "+v"(bl[0]), "+v"(bl[1]), "+v"(bl[2]), "+v"(bl[3]),      \
+                     "+v"(bl[KS - 4]), "+v"(bl[KS - 3]), "+v"(bl[KS - 2]), "+v"(bl[KS - 1])::"memory");           \
   } while (0)
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) bh[ks] = bl[ks] = u32x4{0u, 0u, 0u, 0u};
@@ -745,7 +751,7 @@ int gemm_nn_bf16_splits(int64_t m, int n, int k) {
 // Row-strip kernel: packed output, k <= 64, n a multiple of 32, weights prepared with frag_layout and alpha folded in.
 bool gemm_strip_bf16_applicable(int64_t m, int n, int k) {
   const int kp = (k + 31) / 32 * 32;
-  return kp <= 64 && n >= 512 && n % 32 == 0 && n <= (1 << 22) && m >= 128 * 16 &&
+  return kp <= 128 && kp != 96 && n >= 512 && n % 32 == 0 && n <= (1 << 22) && m >= 128 * 16 &&
          (m + 128) * (int64_t)k * 4 < (1ll << 32) - 64 && (int64_t)(n + 64) * kp * 2 < (1ll << 32) - 64;
 }
 
@@ -759,10 +765,13 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
   const int n_tiles = n / 32;
   if (n_split > n_tiles / 4) n_split = n_tiles / 4 > 0 ? n_tiles / 4 : 1;  // >= 4 column tiles per block
   const dim3 sgrid((unsigned)row_blocks, (unsigned)n_split);
-  if ((k + 31) / 32 * 32 == 32)
+  const int kp = (k + 31) / 32 * 32;
+  if (kp == 32)
     hipLaunchKernelGGL(gemm_strip_bf16_kernel<2>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k);
-  else
+  else if (kp == 64)
     hipLaunchKernelGGL(gemm_strip_bf16_kernel<4>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k);
+  else
+    hipLaunchKernelGGL(gemm_strip_bf16_kernel<8>, sgrid, dim3(256), 0, stream, a, bt_hi, bt_lo, c, m, n, k);
   return check_launch();
 }
 

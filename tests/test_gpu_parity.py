@@ -181,6 +181,8 @@ CASES = [
     (19, 300, 200, 2, 2, 192, 64, 16, 2),     # C_in = 192 = 128 + 64: partial last channel pass; gathers 64 ch in bwd
     (20, 200, None, 2, 2, 320, 320, 12, 1),   # widest ScanNet level (3 passes fwd and bwd, 5 param-grad blocks)
     (21, 300, None, 4, 2, 80, 144, 12, 1),    # C % 16 == 0 but not % 32 / % 64; F_in = 4 gathered by 2 centre frames
+    (22, 1100, None, 2, 2, 128, 128, 10, 1),  # >= 2048 rows and C_out = 128: grad_T through the strip GEMM with 8 k-steps
+    (23, 1100, None, 2, 2, 64, 112, 10, 1),   # the same with k = 112 (padded to 128) and 3-byte T / U rows
 ]
 
 
