@@ -110,7 +110,8 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     if cache is not None and cache[0] == key:
         return cache[1]
     geom = ops.ConvGeometry.build(p_pc_in.pts_, p_pc_out.pts_, p_pc_in.local_frames_, p_pc_out.local_frames_,
-                                  p_neighborhood.neighbors_, p_neighborhood.start_ids_)
+                                  p_neighborhood.neighbors_, p_neighborhood.start_ids_,
+                                  symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and p_pc_in is p_pc_out)
     try:
         p_neighborhood._se3_geom = (key, geom)
     except AttributeError:
@@ -236,7 +237,9 @@ class PNEConvLayer(IConvLayer):
             geom = cache[1]
         else:
             geom = ops.ConvGeometry.build(pc_in.pts_, pc_out.pts_, pc_in.local_frames_, pc_out.local_frames_,
-                                          p_neighborhood.neighbors_, p_neighborhood.start_ids_)
+                                          p_neighborhood.neighbors_, p_neighborhood.start_ids_,
+                                          symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and
+                                          p_pc_in is p_pc_out)
             try:
                 p_neighborhood._se3_geom_plain = (key, geom)
             except AttributeError:

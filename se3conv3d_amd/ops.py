@@ -433,9 +433,12 @@ class ConvGeometry:
     neighbors: torch.Tensor    # [E,2] int32
     ends: torch.Tensor         # [N_out] int32
     _transpose: Optional[Tuple[torch.Tensor, torch.Tensor]] = field(default=None, repr=False)
+    # the edge relation is symmetric (a radius graph of a cloud with itself: ||s - p|| < r both ways, bit for bit):
+    # the source-major edge list is then the sample-major one read the other way round, nothing to build
+    symmetric: bool = False
 
     @staticmethod
-    def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends) -> "ConvGeometry":
+    def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends, symmetric: bool = False) -> "ConvGeometry":
         n_out = pts_out.shape[0]
         ends = _as(ends, torch.int32)
         if ends.shape[0] != n_out:
@@ -445,11 +448,17 @@ class ConvGeometry:
         nb = _as(neighbors, torch.int32)
         if nb.dim() != 2 or nb.shape[1] != 2:
             raise ValueError("neighbors must be [E,2]")
-        return ConvGeometry(_as(pts_in, torch.float32), _as(pts_out, torch.float32), fi, fo, nb, ends)
+        if symmetric and pts_in.shape[0] != n_out:
+            raise ValueError("a symmetric neighbourhood needs the same cloud on both sides")
+        return ConvGeometry(_as(pts_in, torch.float32), _as(pts_out, torch.float32), fi, fo, nb, ends, None, symmetric)
 
     def transpose(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Source-major edge list ``(t_samples [E], t_ends [N_in])`` for the feature gradient."""
         if self._transpose is None:
-            self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0])
+            if self.symmetric:  # samples of source p = sources of sample p
+                self._transpose = (self.neighbors[:, 1].contiguous(), self.ends)
+            else:
+                self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0])
         return self._transpose
 
     def shape(self, c_in: int, c_out: int, num_basis: int, precision: Optional[str] = None) -> Se3Shape:

@@ -172,6 +172,9 @@ class BQNeighborhood(Neighborhood):
     def __init__(self, p_pc_src, p_samples, p_radius, p_max_neighbors=0):
         self.radius_ = p_radius
         self.max_neighbors_ = p_max_neighbors
+        # a cloud against itself: (s, p) is an edge iff (p, s) is -- the operator's backward then needs no
+        # source-major copy of the edge list (ops.ConvGeometry.transpose)
+        self.symmetric_ = p_pc_src is p_samples and p_max_neighbors == 0
         super().__init__(p_pc_src, p_samples)
 
     def __compute_neighborhood__(self):

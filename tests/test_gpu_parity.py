@@ -488,3 +488,41 @@ def test_state_dict_and_init_match_reference_layout(amd):
     assert fac.create_conv_layer(8, 8) in fac.conv_list_
     with pytest.raises(Exception):
         amd.PNEConvLayerRotEquivFactory(9, 32, "kp_gauss").create_conv_layer(8, 8)(None, None, None, None)
+
+
+def test_symmetric_neighbourhood_needs_no_transposed_copy(amd):
+    """A ball query of a cloud against itself is a symmetric relation (the predicate is bit-for-bit the same both
+    ways): the layer then uses the edge list itself as the source-major list.  Same per-source sample sets as the
+    sorted copy, and the same gradients."""
+    g = torch.Generator().manual_seed(31)
+    n = 3000
+    pts = torch.rand(n, 3, generator=g)
+    bid = torch.sort(torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)).values
+    pc = amd.pc.PointcloudRotEquiv(pts.to(DEV), bid.to(DEV), {"pca": False, "n_frames": 2, "fixed_axis": False})
+    nbh = amd.pc.BQNeighborhood(pc, pc, 0.11)
+    assert nbh.symmetric_
+    geom = amd.layers._geometry_of(pc, pc, nbh)
+    assert geom.symmetric
+    ts, te = geom.transpose()
+    ts2, te2 = amd.ops.csr_transpose(geom.neighbors, n)
+    assert torch.equal(te, te2)
+    src = torch.repeat_interleave(torch.arange(n, device=DEV), torch.diff(te2.long(), prepend=torch.zeros(1, dtype=torch.long, device=DEV)))
+    assert torch.equal(canon_edges(torch.stack((ts.long(), src), 1)), canon_edges(torch.stack((ts2.long(), src), 1)))
+    # different clouds on the two sides: not symmetric, the sorted copy is built
+    pc2 = amd.pc.PointcloudRotEquiv(pts[:1000].to(DEV), bid[:1000].to(DEV), {"pca": False, "n_frames": 2, "fixed_axis": False})
+    nbh2 = amd.pc.BQNeighborhood(pc, pc2, 0.11)
+    assert not nbh2.symmetric_ and not amd.layers._geometry_of(pc, pc2, nbh2).symmetric
+    # gradients through the layer agree with the explicit (non-symmetric) geometry
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(32, 32).to(DEV)
+    conv.norm_neigh_dist_.fill_(1 / 0.11), conv.norm_num_neighs_.fill_(0.05)
+    x = torch.randn(n * 2, 32, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn(n * 2, 32, generator=g).to(DEV)
+    conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh).backward(go)
+    gx_sym = x.grad.clone()
+    geom_plain = amd.ops.ConvGeometry.build(pc.pts_, pc.pts_, pc.local_frames_, pc.local_frames_, nbh.neighbors_, nbh.start_ids_)
+    x2 = x.detach().clone().requires_grad_(True)
+    out = amd.SE3ConvFunction.apply(x2, conv.proj_axes_, conv.proj_biases_, conv.conv_weights_, geom_plain,
+                                    conv.norm_neigh_dist_, conv.norm_num_neighs_)
+    out.backward(go)
+    assert rel_err(gx_sym, x2.grad) < 2e-6
+
