@@ -275,11 +275,14 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   return l;
 }
 
-// Optional second stream for the backward pass (SE3_OVERLAP=1): the parameter branch (grad_T GEMM ->
-// edge_param_grad, weight-gradient GEMM) and the feature branch (transposed edge kernel -> grad_X GEMM) are
-// independent.  Measured on MI355X at the headline shape: 2.90 ms with the branches side by side vs 2.89 ms
-// back to back -- the kernels slow each other down in proportion (both are limited by the memory system), so
-// it is off by default.  The stream and its two events are created once per process.
+// Second stream for the backward pass: the parameter branch (grad_T GEMM -> edge_param_grad, weight-gradient GEMM)
+// and the feature branch (transposed edge kernel -> grad_X GEMM) are independent.  Measured on MI355X at the headline
+// shape: the kernels slow each other down more than in proportion (2.15 ms side by side vs 2.07 back to back), so
+// it is used for mid-sized levels only (kOverlapRows; SE3_OVERLAP=1 forces it, SE3_OVERLAP_ROWS=n moves the limit).
+// The stream and its two events are created once per process.
+// backward branches on two streams for this range of output rows: above it every kernel fills the chip by itself
+// (measured: 2.15 vs 2.07 ms at 131 k rows), below it the fork / join costs more than the overlap returns
+constexpr int kOverlapRows = 32768, kOverlapMinRows = 4096;
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -613,7 +616,13 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     hipStream_t fs = stream;
     uint32_t* ubuf = bigw;
     float* fsplit = (float*)(ws + l.split);
-    if (want_params && l.big_u != 0 && side.ok && getenv("SE3_OVERLAP") != nullptr) {
+    // small levels cannot fill the chip with one kernel at a time: their two branches run side by side
+    static const int64_t overlap_rows = [] {
+      if (getenv("SE3_OVERLAP") != nullptr) return (int64_t)1 << 62;
+      const char* e = getenv("SE3_OVERLAP_ROWS");
+      return e ? (int64_t)atoll(e) : (int64_t)kOverlapRows;
+    }();
+    if (want_params && l.big_u != 0 && side.ok && rows_out <= overlap_rows && (rows_out > kOverlapMinRows || overlap_rows > kOverlapRows)) {
       if (hipEventRecord(side.fork, stream) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess)
         return SE3_ERR_LAUNCH;
       fs = side.stream;

@@ -183,6 +183,7 @@ CASES = [
     (21, 300, None, 4, 2, 80, 144, 12, 1),    # C % 16 == 0 but not % 32 / % 64; F_in = 4 gathered by 2 centre frames
     (22, 1100, None, 2, 2, 128, 128, 10, 1),  # >= 2048 rows and C_out = 128: grad_T through the strip GEMM with 8 k-steps
     (23, 1100, None, 2, 2, 64, 112, 10, 1),   # the same with k = 112 (padded to 128) and 3-byte T / U rows
+    (24, 2500, None, 2, 2, 32, 48, 8, 1),     # 5000 output rows: the two backward branches run on two streams
 ]
 
 
