@@ -143,6 +143,9 @@ int se3_ball_query_grid(const float* pts_src, const int32_t* batch_src, int64_t 
  *   (count_neighbors.cu:84-89).  `aabb_min`/`num_cells` as BallQuery.py:34-38 builds them.
  * The workspace written by `count` must be passed unchanged to `store`.
  * ------------------------------------------------------------------------------------------- */
+/* 0 when the source set is small enough for the all-pairs path of the two phases below (aabb_min / num_cells may
+ * then be NULL: no boxes, keys or sort are needed), 1 when they search through the cell grid. */
+int se3_ball_query_needs_grid(int64_t n_src);
 size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst);
 int se3_ball_query_count(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
                          const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,

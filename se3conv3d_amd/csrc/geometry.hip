@@ -6,6 +6,8 @@
 //   to travel to the host) -> one wavefront per sample tests the flattened candidate list 64 at a
 //   time; hits are compacted with ballot + popcount, so the order inside a sample is deterministic
 //   (the reference scatters with atomics, store_neighbors.cu:129-175).
+#include <algorithm>
+
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
@@ -135,6 +137,54 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
       const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       hit = __fsqrt_rn(d2) < 1.0f;
       id = __float_as_int(p.w);
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (STORE && hit) {
+      const int slot = base + found + __popcll(mask & ((1ull << lane) - 1ull));
+      neighbors[(int64_t)slot * 2] = (int32_t)s;
+      neighbors[(int64_t)slot * 2 + 1] = id;
+    }
+    found += __popcll(mask);
+  }
+  if (!STORE && lane == 0) counts[s] = found;
+}
+
+// Small source sets (n_src <= kBqScanAllMax): one wavefront per sample tests every source, 64 at a time -- no boxes,
+// keys, sort or windows, i.e. 3 launches instead of 16 where the launches are all there is to the cost.  Same
+// predicate, same batch test; hits of a sample come out in ascending source id.
+constexpr int64_t kBqScanAllMax = 2048;
+// STORE = false also leaves (x, y, z, batch id) records of the sources in the workspace: the store phase of the C ABI
+// is not handed the source arrays again.
+template <bool STORE>
+__global__ __launch_bounds__(256) void scan_all_kernel(const float* __restrict__ pts_src, const int32_t* __restrict__ batch_src,
+                                                       float4* __restrict__ recs, const float* __restrict__ pts_dst,
+                                                       const int32_t* __restrict__ batch_dst, float inv_r, int n_src,
+                                                       int64_t n_dst, int32_t* __restrict__ counts,
+                                                       const int32_t* __restrict__ ends, int32_t* __restrict__ neighbors) {
+  const int lane = threadIdx.x & 63;
+  if (!STORE) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_src) recs[t] = make_float4(pts_src[t * 3], pts_src[t * 3 + 1], pts_src[t * 3 + 2], __int_as_float(batch_src[t]));
+  }
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_dst) return;
+  const float sx = pts_dst[s * 3], sy = pts_dst[s * 3 + 1], sz = pts_dst[s * 3 + 2];
+  const int sb = batch_dst[s];
+  int found = 0;
+  const int base = STORE ? (s > 0 ? ends[s - 1] : 0) : 0;
+  for (int c0 = 0; c0 < n_src; c0 += 64) {
+    const int id = c0 + lane;
+    bool hit = false;
+    if (id < n_src) {
+      float4 p;
+      if (STORE) p = recs[id];
+      else p = make_float4(pts_src[(int64_t)id * 3], pts_src[(int64_t)id * 3 + 1], pts_src[(int64_t)id * 3 + 2],
+                           __int_as_float(batch_src[id]));
+      const float dx = __fmul_rn(__fsub_rn(sx, p.x), inv_r);
+      const float dy = __fmul_rn(__fsub_rn(sy, p.y), inv_r);
+      const float dz = __fmul_rn(__fsub_rn(sz, p.z), inv_r);
+      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      hit = __float_as_int(p.w) == sb && __fsqrt_rn(d2) < 1.0f;
     }
     const unsigned long long mask = __ballot(hit);
     if (STORE && hit) {
@@ -453,6 +503,8 @@ extern "C" int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, co
   return launch_knn_listed(pts, batch_ids, n, (int)k, out, list, list_count, stream);
 }
 
+extern "C" int se3_ball_query_needs_grid(int64_t n_src) { return n_src > kBqScanAllMax ? 1 : 0; }
+
 extern "C" size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst) {
   return bq_layout(n_src, n_dst).total;
 }
@@ -464,13 +516,25 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
   if (n_src < 0 || n_dst < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_src >= (1ll << 31) || n_dst >= (1ll << 31) / 9) return SE3_ERR_UNSUPPORTED;
   if (n_dst == 0) return SE3_OK;
-  if (!pts_dst || !batch_dst || !aabb_min || !num_cells || !workspace || !ends ||
-      (n_src > 0 && (!pts_src || !batch_src)))
+  const bool scan_all = n_src <= kBqScanAllMax;
+  if (!pts_dst || !batch_dst || !workspace || !ends || (n_src > 0 && (!pts_src || !batch_src)) ||
+      (!scan_all && (!aabb_min || !num_cells)))
     return SE3_ERR_INVALID_ARGUMENT;
   const BqLayout l = bq_layout(n_src, n_dst);
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   char* ws = (char*)workspace;
+  if (scan_all) {
+    int32_t* counts = (int32_t*)(ws + l.counts);
+    size_t temp_bytes = l.temp_bytes;
+    const int64_t blocks = std::max((n_dst + 3) / 4, (n_src + 255) / 256);
+    hipLaunchKernelGGL(scan_all_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, pts_src, batch_src,
+                       (float4*)(ws + l.spts), pts_dst, batch_dst, 1.0f / radius, (int)n_src, n_dst, counts,
+                       (const int32_t*)nullptr, (int32_t*)nullptr);
+    if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
+      return SE3_ERR_LAUNCH;
+    return check_launch();
+  }
   int64_t* keys = (int64_t*)(ws + l.keys);
   int64_t* skeys = (int64_t*)(ws + l.skeys);
   int32_t* ids = (int32_t*)(ws + l.ids);
@@ -503,13 +567,19 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
 extern "C" int se3_ball_query_store(const float* pts_dst, const int32_t* batch_dst, float radius, int64_t n_src,
                                     int64_t n_dst, const void* workspace, size_t workspace_bytes,
                                     const int32_t* ends, int64_t n_edges, int32_t* neighbors, void* stream) {
-  (void)batch_dst;
   if (n_src < 0 || n_dst < 0 || n_edges < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_dst == 0 || n_edges == 0) return SE3_OK;
   if (!pts_dst || !workspace || !ends || !neighbors) return SE3_ERR_INVALID_ARGUMENT;
   const BqLayout l = bq_layout(n_src, n_dst);
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   const char* ws = (const char*)workspace;
+  if (n_src <= kBqScanAllMax) {  // the count phase took the all-pairs path (and left the source records)
+    if (!batch_dst) return SE3_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(scan_all_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, (const int32_t*)nullptr, (float4*)(ws + l.spts), pts_dst, batch_dst,
+                       1.0f / radius, (int)n_src, n_dst, (int32_t*)nullptr, ends, neighbors);
+    return check_launch();
+  }
   hipLaunchKernelGGL(scan_candidates_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
                      (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors);

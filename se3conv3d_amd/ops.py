@@ -159,7 +159,8 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
     if n_dst == 0 or n_src == 0:
         return torch.zeros((0, 2), dtype=torch.int32, device=dev), torch.zeros(n_dst, dtype=torch.int32, device=dev)
     ends = torch.empty(n_dst, dtype=torch.int32, device=dev)  # every entry is written by the count phase
-    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches)
+    # small source sets are searched all-pairs by the library: no boxes / cell grid to prepare
+    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
     nbytes = lib.se3_ball_query_workspace_bytes(n_src, n_dst)
     ws = _workspace(nbytes, dev)
     f32, i32 = torch.float32, torch.int32

@@ -269,6 +269,23 @@ def test_empty_rows_and_empty_graph(amd):
     assert float(out0.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n_src,n_dst,batches,r", [(6000, 1500, 3, 0.09), (2048, 2500, 2, 0.12), (2049, 300, 1, 0.15),
+                                                     (40, 5000, 2, 0.4)])
+def test_ball_query_both_search_paths_match_oracle(amd, n_src, n_dst, batches, r):
+    """Source sets up to 2048 points are searched all-pairs, larger ones through the cell grid (se3_ball_query_needs_grid):
+    the edge sets of both are those of the oracle, bit for bit, batches kept apart."""
+    g = torch.Generator().manual_seed(n_src)
+    ps = torch.rand(n_src, 3, generator=g) * torch.tensor([1.0, 0.8, 0.6])
+    pd = torch.rand(n_dst, 3, generator=g) * torch.tensor([1.0, 0.8, 0.6])
+    bs = torch.sort(torch.randint(0, batches, (n_src,), generator=g, dtype=torch.int32)).values
+    bd = torch.sort(torch.randint(0, batches, (n_dst,), generator=g, dtype=torch.int32)).values
+    bs[-1] = batches - 1
+    nb_r, ends_r = O.ball_query(ps, pd, bs, bd, r)
+    nb, ends = amd.ops.ball_query(ps.to(DEV), pd.to(DEV), bs.to(DEV), bd.to(DEV), r, batches)
+    assert torch.equal(ends.cpu(), ends_r)
+    assert torch.equal(canon_edges(nb), canon_edges(nb_r))
+
+
 def test_compute_keys_bit_exact(amd):
     g = torch.Generator().manual_seed(5)
     pts = torch.rand(5000, 3, generator=g) * torch.tensor([2.0, 1.0, 0.5])
