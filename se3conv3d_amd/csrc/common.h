@@ -84,13 +84,29 @@ __device__ __forceinline__ void t24_pack2(float x0, float x1, uint32_t& hi_pair,
   lo_pair = __builtin_amdgcn_perm(u1, u0, 0x0c0c0501u);  // u0[15:8] | u1[15:8] << 8
 }
 // hi pair word H (two bf16) + the word L holding their lo bytes at byte positions B0, B0+1 -> the lo fragment word
-template <int B0>
+template <int B0, int B1 = B0 + 1>
 __device__ __forceinline__ uint32_t t24_lo_word(uint32_t H, uint32_t L) {
   const uint32_t w0 = __builtin_amdgcn_perm(H, L, 0x0504000cu | ((uint32_t)B0 << 8));
-  const uint32_t w1 = __builtin_amdgcn_perm(H, L, 0x0706000cu | ((uint32_t)(B0 + 1) << 8));
+  const uint32_t w1 = __builtin_amdgcn_perm(H, L, 0x0706000cu | ((uint32_t)B1 << 8));
   const float l0 = __uint_as_float(w0) - __uint_as_float(H << 16);
   const float l1 = __uint_as_float(w1) - __uint_as_float(H & 0xffff0000u);
   return cvt_pk_bf16(l0, l1);
+}
+
+// ds_read_b64_tr_b16: every group of 16 lanes reads a block of 4 rows x 16 columns of 16-bit values and gets it back
+// column-major -- lane i of the group receives column i, rows 0..3 packed as two words (row0 | row1 << 16, row2 |
+// row3 << 16).  Lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3 (8-byte aligned).  That is
+// the bf16 MFMA fragment of an operand whose K index runs over the ROWS of the LDS image (the TN GEMM's operands);
+// mapping verified by tools/probes/tr_read.hip.  EXEC must be all ones.
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)p));
+}
+// fragment = rows r .. r+3 and r+4 .. r+7 of the image for this lane's column
+__device__ __forceinline__ u32x4 lds_frag_tr16(const uint16_t* p_rows03, const uint16_t* p_rows47) {
+  const u32x2 a = lds_read_tr16(p_rows03), b = lds_read_tr16(p_rows47);
+  return u32x4{a[0], a[1], b[0], b[1]};
 }
 
 // 8 packed words -> the two 8 x bf16 MFMA fragments

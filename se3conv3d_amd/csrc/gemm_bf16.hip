@@ -529,10 +529,17 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
                                                            float* __restrict__ partials, int64_t m, int ka, int n,
                                                            int64_t chunk) {
   static_assert(!A24 || FAST, "the 3-byte A format is only read through buffer loads");
+  // A24: hi / lo planes of A (lo bytes widened to 16 bits) and of B as 16-bit images whose rows are the K index of
+  // the MFMAs; the fragments come out of ds_read_b64_tr_b16 (common.h) ready-made: 12 LDS reads and no v_perm per
+  // k-step where gathering them with scalar reads took 32 reads + 24 v_perm.  Row pitches of 16 (mod 64) dwords
+  // keep the 4-row blocks of a half-wavefront on distinct banks.
+  constexpr int APITCH = 128 + 32, BPITCH = BN + 32;  // 320- and 192-byte rows
   __shared__ __attribute__((aligned(16))) uint32_t at[2][A24 ? 1 : BK][128];
-  __shared__ __attribute__((aligned(16))) uint16_t ath[2][A24 ? BK : 1][128 + 8];
-  __shared__ __attribute__((aligned(16))) uint8_t atl[2][A24 ? BK : 1][128 + 16];
-  __shared__ __attribute__((aligned(16))) uint32_t bt[2][BK][BN];
+  __shared__ __attribute__((aligned(16))) uint16_t ath[2][A24 ? BK : 1][APITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t atl[2][A24 ? BK : 1][APITCH];
+  __shared__ __attribute__((aligned(16))) uint32_t bt[2][A24 ? 1 : BK][BN];
+  __shared__ __attribute__((aligned(16))) uint16_t bth[2][A24 ? BK : 1][BPITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t btl[2][A24 ? BK : 1][BPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
   const int ka0 = blockIdx.x * 128;
@@ -595,15 +602,26 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
     if constexpr (A24) {
       *reinterpret_cast<u32x4*>(&ath[buf][tid >> 4][(tid & 15) * 8]) = t.a0;
       *reinterpret_cast<u32x4*>(&ath[buf][16 + (tid >> 4)][(tid & 15) * 8]) = t.a1;
-      *reinterpret_cast<u32x4*>(&atl[buf][tid >> 3][(tid & 7) * 16]) = t.a2;
+      u32x4 e0, e1;  // 16 lo bytes -> 16 half-words
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        e0[2 * i] = __builtin_amdgcn_perm(0u, t.a2[i], 0x0c010c00u), e0[2 * i + 1] = __builtin_amdgcn_perm(0u, t.a2[i], 0x0c030c02u);
+        e1[2 * i] = __builtin_amdgcn_perm(0u, t.a2[2 + i], 0x0c010c00u), e1[2 * i + 1] = __builtin_amdgcn_perm(0u, t.a2[2 + i], 0x0c030c02u);
+      }
+      *reinterpret_cast<u32x4*>(&atl[buf][tid >> 3][(tid & 7) * 16]) = e0;
+      *reinterpret_cast<u32x4*>(&atl[buf][tid >> 3][(tid & 7) * 16 + 8]) = e1;
+      *reinterpret_cast<u32x2*>(&bth[buf][brow][bcq]) = u32x2{pair_hi(t.b0[0], t.b0[1]), pair_hi(t.b0[2], t.b0[3])};
+      *reinterpret_cast<u32x2*>(&btl[buf][brow][bcq]) = u32x2{pair_lo(t.b0[0], t.b0[1]), pair_lo(t.b0[2], t.b0[3])};
+      *reinterpret_cast<u32x2*>(&bth[buf][brow + 16][bcq]) = u32x2{pair_hi(t.b1[0], t.b1[1]), pair_hi(t.b1[2], t.b1[3])};
+      *reinterpret_cast<u32x2*>(&btl[buf][brow + 16][bcq]) = u32x2{pair_lo(t.b1[0], t.b1[1]), pair_lo(t.b1[2], t.b1[3])};
     } else {
       *reinterpret_cast<u32x4*>(&at[buf][arow][acq]) = t.a0;
       *reinterpret_cast<u32x4*>(&at[buf][arow + 8][acq]) = t.a1;
       *reinterpret_cast<u32x4*>(&at[buf][arow + 16][acq]) = t.a2;
       *reinterpret_cast<u32x4*>(&at[buf][arow + 24][acq]) = t.a3;
+      *reinterpret_cast<u32x4*>(&bt[buf][brow][bcq]) = t.b0;
+      *reinterpret_cast<u32x4*>(&bt[buf][brow + 16][bcq]) = t.b1;
     }
-    *reinterpret_cast<u32x4*>(&bt[buf][brow][bcq]) = t.b0;
-    *reinterpret_cast<u32x4*>(&bt[buf][brow + 16][bcq]) = t.b1;
   };
 
   f32x16 acc0 = zero16(), acc1 = zero16();
@@ -611,27 +629,37 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
 #if SE3_GEMM_ABLATE & 1
     return;
 #endif
+    if constexpr (A24) {
+      const int grp = lane >> 4, q = (lane >> 2) & 3, p4 = (lane & 3) * 4;
+      const int col = 16 * (grp & 1) + p4;  // this lane's address: row q of the block, 4 columns from here
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int r0 = 16 * s + 8 * (grp >> 1) + q;
+        const u32x4 a_hi = lds_frag_tr16(&ath[buf][r0][wave * 32 + col], &ath[buf][r0 + 4][wave * 32 + col]);
+        const u32x4 lw = lds_frag_tr16(&atl[buf][r0][wave * 32 + col], &atl[buf][r0 + 4][wave * 32 + col]);
+        const u32x4 a_lo = {t24_lo_word<0, 2>(a_hi[0], lw[0]), t24_lo_word<0, 2>(a_hi[1], lw[1]),
+                            t24_lo_word<0, 2>(a_hi[2], lw[2]), t24_lo_word<0, 2>(a_hi[3], lw[3])};
+        u32x4 b_hi = lds_frag_tr16(&bth[buf][r0][col], &bth[buf][r0 + 4][col]);
+        u32x4 b_lo = lds_frag_tr16(&btl[buf][r0][col], &btl[buf][r0 + 4][col]);
+        acc0 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc0);
+        b_hi = lds_frag_tr16(&bth[buf][r0][32 + col], &bth[buf][r0 + 4][32 + col]);
+        b_lo = lds_frag_tr16(&btl[buf][r0][32 + col], &btl[buf][r0 + 4][32 + col]);
+        acc1 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc1);
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint32_t wa[8], wb0[8], wb1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int row = 16 * s + 8 * h + j;
-        if constexpr (A24) wa[j] = (uint32_t)ath[buf][row][wave * 32 + rl] | ((uint32_t)atl[buf][row][wave * 32 + rl] << 16);
-        else wa[j] = at[buf][row][wave * 32 + rl];
+        wa[j] = at[buf][row][wave * 32 + rl];
         wb0[j] = bt[buf][row][rl];
         wb1[j] = bt[buf][row][32 + rl];
       }
       u32x4 a_hi, a_lo, b_hi, b_lo;
-      if constexpr (A24) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // wa = hi16 | lo8 << 16 of rows 2i, 2i+1
-          a_hi[i] = __builtin_amdgcn_perm(wa[2 * i + 1], wa[2 * i], 0x05040100u);
-          a_lo[i] = t24_lo_word<0>(a_hi[i], __builtin_amdgcn_perm(wa[2 * i + 1], wa[2 * i], 0x0c0c0602u));
-        }
-      } else {
-        frags_from_words(wa, a_hi, a_lo);
-      }
+      frags_from_words(wa, a_hi, a_lo);
       frags_from_words(wb0, b_hi, b_lo);
       acc0 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc0);
       frags_from_words(wb1, b_hi, b_lo);
