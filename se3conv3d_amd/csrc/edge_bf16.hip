@@ -489,7 +489,9 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
   const int c_off = 64 * (int)blockIdx.y;
   const int row_bytes = row_ch * 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][2][64][4];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_desc[NW][NFR][32][12];
+  // descriptor image for the d[A;beta] product: hi / lo bf16 planes, row = frame-edge, 12 columns ([desc(9), 1, 0, 0]).
+  // Its MFMA fragments have the K index over the rows: read with ds_read_b64_tr_b16 (common.h), 4 per (frame, k-step).
+  __shared__ __attribute__((aligned(16))) uint16_t lds_desc[NW][NFR][2][32][12];
   __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NW][NFR][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
   // the final block reduction reuses the gT image (NW * 10 * 32 floats <= NW * CH16 * 1024 words)
   float(*lds_red)[kDescExt][kBasis] = reinterpret_cast<float(*)[kDescExt][kBasis]>(&lds_gt[0][0][0][0][0][0]);
@@ -587,20 +589,22 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
       else
         edge_descriptor(yc, rc, xn, rn, rho, d);
 
-      // descriptor image for the d[A;beta] product: half h writes the rows of frame a0+h
-      if (NFR == 2 || h == 0) {
-        uint32_t* dst = &lds_desc[wave][NFR == 2 ? h : 0][kcol][0];
-        uint32_t pw[12];
-#pragma unroll
-        for (int i = 0; i < 8; i += 2) split_pack2(d[i], d[i + 1], pw[i], pw[i + 1]);
-        split_pack2(d[8], 1.0f, pw[8], pw[9]);
-        pw[10] = pw[11] = 0u;
-        *reinterpret_cast<u32x4*>(dst) = u32x4{pw[0], pw[1], pw[2], pw[3]};
-        *reinterpret_cast<u32x4*>(dst + 4) = u32x4{pw[4], pw[5], pw[6], pw[7]};
-        *reinterpret_cast<u32x4*>(dst + 8) = u32x4{pw[8], pw[9], pw[10], pw[11]};
-      }
       u32x4 own_hi, own_lo, oth_hi, oth_lo;
       frags_from_floats(d, own_hi, own_lo);
+      // descriptor image: half h writes the rows of frame a0+h -- the split pairs above are the rows of the two planes
+      if (NFR == 2 || h == 0) {
+        uint32_t p_hi, p_lo;
+        split2(d[8], 1.0f, p_hi, p_lo);
+        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+        uint16_t* dh = &lds_desc[wave][NFR == 2 ? h : 0][0][kcol][0];
+        uint16_t* dl = &lds_desc[wave][NFR == 2 ? h : 0][1][kcol][0];
+        *reinterpret_cast<u32x2v*>(dh) = u32x2v{own_hi[0], own_hi[1]};
+        *reinterpret_cast<u32x2v*>(dh + 4) = u32x2v{own_hi[2], own_hi[3]};
+        *reinterpret_cast<u32x2v*>(dh + 8) = u32x2v{p_hi, 0u};
+        *reinterpret_cast<u32x2v*>(dl) = u32x2v{own_lo[0], own_lo[1]};
+        *reinterpret_cast<u32x2v*>(dl + 4) = u32x2v{own_lo[2], own_lo[3]};
+        *reinterpret_cast<u32x2v*>(dl + 8) = u32x2v{p_lo, 0u};
+      }
       {
         float d8 = d[8];
         if (NFR == 2) {  // dims 8, 9 of frame a come from the half that did not build frame a's descriptor
@@ -641,7 +645,9 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
       u32x4 fa_hi[CH16], fa_lo[CH16];
 #pragma unroll
       for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
-      const int jcol = min(kcol, 11);
+      // this lane's address for the transposed reads: row (lane >> 2) & 3 of a 4-row block, columns 4 (lane & 3)
+      // (the image has 12 columns: the last quad points at columns 8..11 again, what it returns lands in unused columns)
+      const int tr_row = (lane >> 2) & 3, tr_col = min((lane & 3) * 4, 8);
 #pragma unroll
       for (int a = 0; a < NFR; ++a) {
         f32x16 gphi = zero16();
@@ -660,15 +666,14 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
           }
           if (s * 16 < cnt) {
             float gp[8];
-            uint32_t wd[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              gp[j] = gphi[8 * s + j] * dyv[a][8 * s + j];
-              wd[j] = lds_desc[wave][a][acc_row(8 * s + j, h)][jcol];
-            }
-            u32x4 ga_hi, ga_lo, db_hi, db_lo;
+            for (int j = 0; j < 8; ++j) gp[j] = gphi[8 * s + j] * dyv[a][8 * s + j];
+            u32x4 ga_hi, ga_lo;
             frags_from_floats(gp, ga_hi, ga_lo);
-            frags_from_words(wd, db_hi, db_lo);
+            // K slot (h, j) of this k-step is frame-edge acc_row(8 s + j, h) = 16 s + 4 h + (j & 3) + 8 (j >> 2)
+            const int r0 = 16 * s + 4 * h + tr_row;
+            const u32x4 db_hi = lds_frag_tr16(&lds_desc[wave][a][0][r0][tr_col], &lds_desc[wave][a][0][r0 + 8][tr_col]);
+            const u32x4 db_lo = lds_frag_tr16(&lds_desc[wave][a][1][r0][tr_col], &lds_desc[wave][a][1][r0 + 8][tr_col]);
             dacc = mfma_bf16x3(ga_hi, ga_lo, db_hi, db_lo, dacc);
           }
         }
