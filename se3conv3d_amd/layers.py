@@ -109,8 +109,11 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
            p_pc_out.local_frames_.data_ptr(), p_pc_in.pts_.data_ptr(), p_pc_out.pts_.data_ptr())
     if cache is not None and cache[0] == key:
         return cache[1]
+    nb32 = getattr(p_neighborhood, "neighbors_i32_", None)  # the library's own list when it built the neighbourhood
+    if nb32 is None or nb32.shape[0] != p_neighborhood.neighbors_.shape[0]:
+        nb32 = p_neighborhood.neighbors_
     geom = ops.ConvGeometry.build(p_pc_in.pts_, p_pc_out.pts_, p_pc_in.local_frames_, p_pc_out.local_frames_,
-                                  p_neighborhood.neighbors_, p_neighborhood.start_ids_,
+                                  nb32, p_neighborhood.start_ids_,
                                   symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and p_pc_in is p_pc_out)
     try:
         p_neighborhood._se3_geom = (key, geom)
@@ -236,8 +239,11 @@ class PNEConvLayer(IConvLayer):
         if cache is not None and cache[0] == key:
             geom = cache[1]
         else:
+            nb32 = getattr(p_neighborhood, "neighbors_i32_", None)
+            if nb32 is None or nb32.shape[0] != p_neighborhood.neighbors_.shape[0]:
+                nb32 = p_neighborhood.neighbors_
             geom = ops.ConvGeometry.build(pc_in.pts_, pc_out.pts_, pc_in.local_frames_, pc_out.local_frames_,
-                                          p_neighborhood.neighbors_, p_neighborhood.start_ids_,
+                                          nb32, p_neighborhood.start_ids_,
                                           symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and
                                           p_pc_in is p_pc_out)
             try:

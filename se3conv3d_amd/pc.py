@@ -178,9 +178,15 @@ class BQNeighborhood(Neighborhood):
         super().__init__(p_pc_src, p_samples)
 
     def __compute_neighborhood__(self):
-        self.neighbors_, self.start_ids_ = ops.BallQuery.apply(
-            self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_, self.samples_.batch_ids_,
-            self.radius_, self.max_neighbors_, self.pc_src_.num_batches())
+        if self.max_neighbors_ != 0:
+            raise NotImplementedError("max_neighbors > 0 (random sub-sampling) is not used by any model path")
+        # same call as ops.BallQuery.apply (which stays for code that uses the op directly), without the autograd node --
+        # the edge list carries no gradient -- and keeping the int32 list the native kernels read next to the
+        # int64 ``neighbors_`` the reference exposes
+        nb, self.start_ids_ = ops.ball_query(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
+                                             self.samples_.batch_ids_, self.radius_, self.pc_src_.num_batches())
+        self.neighbors_i32_ = nb
+        self.neighbors_ = nb.to(torch.int64)
 
 
 class KnnNeighborhood(Neighborhood):
