@@ -180,3 +180,51 @@ def test_oracle_hierarchy_and_frame_pooling_match_reference_fixture():
         y.backward(torch.from_numpy(d[f"fpool_{method}_g"]))
         np.testing.assert_allclose(y.detach().numpy(), d[f"fpool_{method}_y"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(x.grad.numpy(), d[f"fpool_{method}_dx"], rtol=0, atol=1e-6)
+
+
+def _load_block(d, blocks, factory):
+    blk = blocks.ResNetFormer(32, 48, factory, blocks.BatchNormPC, 0.0)
+    state = {k[len("state/"):]: torch.from_numpy(np.asarray(d[k])) for k in d.files if k.startswith("state/")}
+    missing = blk.load_state_dict(state, strict=True)  # the reference's keys, one for one
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return blk.train()
+
+
+def test_resnetformer_block_glue_matches_reference_fixture():
+    """The torch glue of se3conv3d_amd.blocks (norms, skips with their gains, point-wise MLP, linear skip) around a
+    CPU stand-in of the convolution (the oracle) against the reference's ResNetFormer: the reference state_dict loads
+    key for key, output, input gradient, every parameter gradient and the batch-norm running statistics agree."""
+    import types
+    from se3conv3d_amd import blocks
+
+    d = np.load(os.path.join(GOLDEN, "resnetformer_block.npz"))
+    pts, frames = torch.from_numpy(d["pts"]), torch.from_numpy(d["frames"])
+    bid = torch.from_numpy(d["batch"])
+    nb, _ = O.ball_query(pts, pts, bid, bid, float(d["radius"]))
+
+    class OracleConv(torch.nn.Module):  # same parameter / buffer names as the layer
+        def __init__(self, c_in, c_out):
+            super().__init__()
+            self.proj_axes_ = torch.nn.Parameter(torch.zeros(9, 32))
+            self.proj_biases_ = torch.nn.Parameter(torch.zeros(32))
+            self.conv_weights_ = torch.nn.Parameter(torch.zeros(c_in, 32, c_out))
+            self.register_buffer("norm_neigh_dist_", torch.tensor(0.0))
+            self.register_buffer("norm_num_neighs_", torch.tensor(0.0))
+
+        def forward(self, p_pc_in, p_pc_out, p_in_features, p_neighborhood):
+            return O.conv_forward(pts, pts, frames, frames, nb, p_in_features, self.proj_axes_, self.proj_biases_,
+                                  self.conv_weights_, self.norm_neigh_dist_, self.norm_num_neighs_)
+
+    factory = types.SimpleNamespace(create_conv_layer=lambda ci, co: OracleConv(ci, co))
+    blk = _load_block(d, blocks, factory)
+    pc = types.SimpleNamespace(batch_size_=torch.tensor(2), batch_ids_=bid)
+    x = torch.from_numpy(d["x"]).requires_grad_(True)
+    out = blk(pc, x, None)
+    out.backward(torch.from_numpy(d["g"]))
+    t = lambda k: torch.from_numpy(np.asarray(d[k]))
+    assert rel_err(out, t("out")) < 5e-6 and rel_err(x.grad, t("dx")) < 5e-6
+    for name, p in blk.named_parameters():
+        assert rel_err(p.grad, t("grad/" + name)) < 2e-5, name
+    for k, v in blk.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), d["after/" + k], rtol=1e-5, atol=1e-6)

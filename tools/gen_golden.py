@@ -283,6 +283,42 @@ def hierarchy_case(pclib, seed):
     return out
 
 
+def block_case(pclib, seed):
+    """A whole ResNetFormer block of the reference (BatchNormPC in training mode, SkipConnection with gamma moved off
+    its 1e-6 initial value, no drop path) around PNEConvLayerRotEquiv: state_dict, input, output and every gradient."""
+    torch.manual_seed(seed)
+    n, f, c_in, c_out = 220, 2, 32, 48
+    pts = torch.rand(n, 3)
+    bid = torch.sort(torch.randint(0, 2, (n,), dtype=torch.int32)).values
+    pc = pclib.pc.PointcloudRotEquiv(pts, bid, {"pca": False, "n_frames": f, "fixed_axis": False})
+    r = _radius(n / 2, 12)
+    nbh = pclib.pc.BQNeighborhood(pc, pc, r)
+    fact = pclib.layers.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu")
+    blk = pclib.layers.ResNetFormer(c_in, c_out, fact, pclib.layers.BatchNormPC, 0.0)
+    blk.train()
+    with torch.no_grad():
+        blk.spatial_conv_.norm_neigh_dist_.fill_(1.0 / r)
+        blk.spatial_conv_.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / nbh.neighbors_.shape[0])
+        blk.spatial_conv_.proj_biases_.uniform_(-0.5, 0.5)
+        blk.skip_path_1_.gamma_.fill_(0.7)
+        blk.skip_path_2_.gamma_.fill_(1.3)
+    state0 = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(n * f, c_in, requires_grad=True)
+    out = blk(pc, x, nbh)
+    g = torch.randn_like(out)
+    out.backward(g)
+    data = {"pts": pts.numpy(), "batch": bid.numpy(), "frames": pc.local_frames_.numpy(), "radius": np.float32(r),
+            "x": x.detach().numpy(), "out": out.detach().numpy(), "g": g.numpy(), "dx": x.grad.numpy()}
+    for k, v in state0.items():
+        data["state/" + k] = v.numpy()
+    for k, v in blk.named_parameters():
+        data["grad/" + k] = v.grad.numpy()
+    for k, v in blk.state_dict().items():
+        if "running" in k:
+            data["after/" + k] = v.numpy()
+    return data
+
+
 def pne_case(pclib, seed, n_in, n_out, c_in, c_out, k_deg, batches):
     """The reference's non-equivariant PNEConvLayer ('mlp_gelu', aggregation 'add', 3-D offsets; scope row f-4):
     plain Pointcloud, BQNeighborhood, forward + backward through LinearPNE / FeatBasisProj / einsum."""
@@ -348,6 +384,12 @@ def main():
         np.savez_compressed(path, **hierarchy_case(pclib, 11))
         print(f"{path}: size={os.path.getsize(path) / 1e6:.2f} MB")
     if only == "hierarchy":
+        return
+    if only in ("", "block"):
+        path = os.path.join(OUT, "resnetformer_block.npz")
+        np.savez_compressed(path, **block_case(pclib, 13))
+        print(f"{path}: size={os.path.getsize(path) / 1e6:.2f} MB")
+    if only == "block":
         return
     for name, seed, n_in, n_out, c_in, c_out, k, b in PNE_CASES:
         path = os.path.join(OUT, f"{name}.npz")
