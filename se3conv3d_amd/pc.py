@@ -69,6 +69,21 @@ class Pointcloud(object):
         self.batch_ids_ = self.batch_ids_.to(p_device)
         self.batch_size_ = self.batch_size_.to(p_device)
 
+    @staticmethod
+    def _pool_rows_by(ids, p_in_tensor, p_pooling_method, n_out):
+        how = {"avg": "mean", "max": "amax", "min": "amin", "sum": "sum"}[p_pooling_method]
+        idx = ids.to(torch.int64).reshape((-1,) + (1,) * (p_in_tensor.dim() - 1)).expand_as(p_in_tensor)
+        out = torch.zeros((n_out,) + tuple(p_in_tensor.shape[1:]), dtype=p_in_tensor.dtype, device=p_in_tensor.device)
+        return out.scatter_reduce(0, idx, p_in_tensor, how, include_self=False)
+
+    def global_pooling(self, p_in_tensor, p_pooling_method="avg"):
+        """One row per batch element (pc/Pointcloud.py:58-76; classification heads -- [B, C] outputs, plain torch)."""
+        return self._pool_rows_by(self.batch_ids_, p_in_tensor, p_pooling_method, self.num_batches())
+
+    def global_upsample(self, p_in_tensor):
+        """pc/Pointcloud.py:79-88."""
+        return torch.index_select(p_in_tensor, 0, self.batch_ids_.to(torch.int64))
+
     def num_batches(self) -> int:
         """``batch_size_`` as a host integer, read back once per cloud (the native calls size their per-batch
         tables with it; the reference re-reads it from the device in every ball query, ball_query.cu:46)."""
@@ -142,6 +157,19 @@ class PointcloudRotEquiv(Pointcloud):
         super().to_device(p_device)
         self.local_frames_ = self.local_frames_.to(p_device)
         self.batch_ids_considering_frames_ = self.batch_ids_considering_frames_.to(p_device)
+
+    def global_pooling(self, p_in_tensor, p_pooling_method="avg"):
+        """Rows are per (point, frame) here (pc/PointcloudRotEquiv.py:252-270)."""
+        return self._pool_rows_by(self.batch_ids_considering_frames_, p_in_tensor, p_pooling_method, self.num_batches())
+
+    def global_upsample(self, p_in_tensor):
+        return torch.index_select(p_in_tensor, 0, self.batch_ids_considering_frames_.to(torch.int64))
+
+    def global_pooling_specific_feature_pooling(self, p_in_tensor, p_global_pooling_method="avg",
+                                                p_feature_pooling_method="avg"):
+        """Frames first, then batch elements (pc/PointcloudRotEquiv.py:195-222)."""
+        pooled = self.feature_pooling(p_in_tensor, p_pooling_method=p_feature_pooling_method)
+        return self._pool_rows_by(self.batch_ids_, pooled, p_global_pooling_method, self.num_batches())
 
     def feature_pooling(self, p_in_tensor, p_pooling_method="avg"):
         """Pool the F per-frame feature rows of every point (pc/PointcloudRotEquiv.py:224-251), one HIP kernel

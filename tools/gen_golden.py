@@ -280,6 +280,12 @@ def hierarchy_case(pclib, seed):
         yf.backward(gf)
         out[f"fpool_{method}_x"], out[f"fpool_{method}_y"] = xf.detach().numpy(), yf.detach().numpy()
         out[f"fpool_{method}_g"], out[f"fpool_{method}_dx"] = gf.numpy(), xf.grad.numpy()
+    for method in ("avg", "max"):
+        xg = torch.randn(150 * f, c)
+        out[f"gpool_{method}_x"] = xg.numpy()
+        out[f"gpool_{method}_y"] = pcr.global_pooling(xg, method).numpy()
+        out[f"gpool2_{method}_y"] = pcr.global_pooling_specific_feature_pooling(xg, method, "max").numpy()
+    out["gpool_batch"] = bid[:150].numpy()
     return out
 
 
