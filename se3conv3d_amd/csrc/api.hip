@@ -630,6 +630,37 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       fsplit = (float*)(ws + l.split2);
       branch_forked = true;
     }
+    // One stream: the two kernels that write a row-sized tensor (U, grad_T) go first, their readers after them.
+    // Whatever runs right behind a ~1 GB writer is slowed while the caches drain (a memory-bound reader by 15-30 %,
+    // whichever tensor it reads): in the order  U-writer, grad_X GEMM, grad_T writer, parameter gradients  two readers
+    // sit in that position, here only one does (gemm_gradX 0.221 -> 0.187 ms at the headline shape).
+    // SE3_BWD_BRANCH_ORDER=1 restores branch-by-branch order.
+    static const bool branch_order = getenv("SE3_BWD_BRANCH_ORDER") != nullptr;
+    if (!branch_order && !branch_forked && !conv_fused_bf16_supported(gt, s->c_out) && want_params && l.big_u != 0) {
+      ubuf = (uint32_t*)(ws + l.big_u);
+      fsplit = (float*)(ws + l.split2);
+      if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs, -1, -1, t24_u))
+        return rc;
+      if (strip_t) {
+        if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream)) return rc;
+      } else if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
+                                              (float*)(ws + l.split), nullptr, 1.0f, stream)) {
+        return rc;
+      }
+      if (grad_axes || grad_biases) {
+        int n_part = 0;
+        if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
+                                                 l.n_param_partials, &n_part, stream))
+          return rc;
+        hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
+                           grad_axes, grad_biases, 0.5f);
+      }
+      if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
+                                       fsplit, nu, inv_phi, fs, t24_u))
+        return rc;
+      if (int rc = weight_gradient()) return rc;
+      return check_launch();
+    }
     if (conv_fused_bf16_supported(gt, s->c_out)) {
       if (int rc = launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, bx_hi, bx_lo, s->c_in, grad_feat,
                                           nullptr, nu, inv_phi, fs))

@@ -8,6 +8,7 @@ re-running a slice of the parity suite in a child process with the variable set:
   SE3_PAIR_PERSIST=n  wave-pair edge kernel with n persistent workgroups walking strided items
   SE3_NO_T24=1      T and U as packed hi/lo words instead of the 3-byte row format (what C < 64 always uses)
   SE3_OVERLAP=1     backward branches on two streams at every size (default: 4 k - 32 k output rows only)
+  SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
 
 One child at a time; each child is an ordinary `pytest -m gpu` run over the golden / random-shape / headline
 tests of tests/test_gpu_parity.py.
@@ -24,7 +25,7 @@ SLICE = "golden or random_shapes or headline_subset or features_only or empty_ro
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("var", ["SE3_BWD_MERGE", "SE3_NO_PAIR", "SE3CONV_FUSED", "SE3_PG_SINGLE", "SE3_PAIR_PERSIST=64",
-                                 "SE3_NO_T24", "SE3_OVERLAP"])
+                                 "SE3_NO_T24", "SE3_OVERLAP", "SE3_BWD_BRANCH_ORDER"])
 def test_variant_passes_parity_slice(var):
     env = dict(os.environ)
     name, _, value = var.partition("=")
