@@ -20,6 +20,13 @@
 //   edge_param_grad_bf16_kernel             generic fallback (channel counts that are not multiples of 16)
 #include <cstdlib>
 
+// T / U rows leave the wave-pair kernel through non-temporal stores: the kernel is VALU-bound and does not care, and
+// the kernel that follows it (the GEMM reading those rows) no longer runs against the write-back of ~300 MB of dirty
+// lines left in L2 and the memory-side cache: gemm_out 0.221 -> 0.188 ms.  (The strip GEMM is bound by its stores:
+// there the same flag costs 0.03 ms and buys 0.02 in the parameter-gradient kernel behind it -- not used.)
+#ifndef SE3_NT_STORES
+#define SE3_NT_STORES 1
+#endif
 #include "common.h"
 #include "edge_bf16_body.h"
 
@@ -315,8 +322,13 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
             uint32_t hp, lp;
             t24_pack2(acc[a][t][r], (FULL || ch + 1 < C) ? acc[a][t][r + 1] : 0.f, hp, lp);
             const int idx = (ch >> 1) * kBasis + kcol;
+#if SE3_NT_STORES
+            __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
+            __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2) + idx);
+#else
             reinterpret_cast<uint32_t*>(row)[idx] = hp;
             reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2)[idx] = (uint16_t)lp;
+#endif
           }
           continue;
         }
@@ -326,8 +338,13 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
           uint32_t w0, w1;
           split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
           if ((SE3_PAIR_ABLATE & 4) && (w0 ^ w1) != 0x12345678u) continue;
+#if SE3_NT_STORES
+          if (FULL || ch0 + acc_row(r, h) < C) __builtin_nontemporal_store(w0, &t_row[acc_row(r, h) * kBasis + kcol]);
+          if (FULL || ch0 + acc_row(r + 1, h) < C) __builtin_nontemporal_store(w1, &t_row[acc_row(r + 1, h) * kBasis + kcol]);
+#else
           if (FULL || ch0 + acc_row(r, h) < C) t_row[acc_row(r, h) * kBasis + kcol] = w0;
           if (FULL || ch0 + acc_row(r + 1, h) < C) t_row[acc_row(r + 1, h) * kBasis + kcol] = w1;
+#endif
         }
       }
     if (cbase + 64 * CT < C) __syncthreads();  // the next pass reuses the phi buffers from their start
