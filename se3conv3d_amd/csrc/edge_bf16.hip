@@ -112,7 +112,13 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
   uint32_t* t_rows = t_out + item * FC * (int64_t)channels * kBasis;  // rows FC*item .. FC*item + FC-1
   const int row_words = channels * kBasis;
   edge_item_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, item, fnb_shift,
-                               [&](int a, int off, uint32_t w) { t_rows[a * row_words + off] = w; });
+                               [&](int a, int off, uint32_t w) {
+#if SE3_NT_STORES
+                                 __builtin_nontemporal_store(w, &t_rows[a * row_words + off]);
+#else
+                                 t_rows[a * row_words + off] = w;
+#endif
+                               });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,7 +371,11 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_stream_bf16_kerne
   const int64_t first = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   edge_stream_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, first, (int64_t)gridDim.x * 4, n_items, fnb_shift,
                                  [&](int64_t item, int a, int off, uint32_t w) {
+#if SE3_NT_STORES
+                                   __builtin_nontemporal_store(w, &t_out[(item * FC + a) * row_words + off]);
+#else
                                    t_out[(item * FC + a) * row_words + off] = w;
+#endif
                                  });
 }
 
