@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void edge_t_kernel(EdgeGeom g, const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ch = cbase + VW * acc_row(r, h) + t;
-        if (ch < channels) t_row[(int64_t)ch * kBasis + kcol] = acc[t][r];
+        // non-temporal: the GEMM that follows does not run against this kernel's write-back (see edge_bf16.hip)
+        if (ch < channels) __builtin_nontemporal_store(acc[t][r], &t_row[(int64_t)ch * kBasis + kcol]);
       }
   }
 }
