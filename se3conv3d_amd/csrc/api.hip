@@ -435,10 +435,12 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
+    const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
     PrepBatch pb;
     pb.axes(proj_axes, proj_biases, axes_ext);
     pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
-    pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    if (same_cloud) geom_out = geom_in;  // a cloud against itself: one set of records serves both sides
+    else pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     pb.split(feat, featpk, s->n_in * s->f_in * s->c_in);
     pb.weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, nullptr, 1.0f, false, t24);
     if (int rc = pb.launch(stream)) return rc;
@@ -556,10 +558,12 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
+    const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
     PrepBatch pb;
     pb.axes(proj_axes, proj_biases, axes_ext);
     pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
-    pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    if (same_cloud) geom_out = geom_in;
+    else pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     pb.split(grad_out, gpk, rows_out * s->c_out);
     if (feat_branch) pb.weights(conv_weights, s->c_in, kb, s->c_out, 2, bx_hi, bx_lo, nullptr, 1.0f, false, t24_u);
     if (want_params) {
