@@ -12,7 +12,18 @@
  *   - all floating point is fp32, all indices int32 (keys int64), tensors dense row-major;
  *   - caller allocates every output and the workspace (size from the matching *_workspace_bytes);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream), makes no hidden host synchronisation, keeps no global state and is re-entrant;
+ *     stream) of the CURRENT device -- the library never switches devices -- and makes no hidden
+ *     host synchronisation;
+ *   - re-entrant: calls on different streams (or from different threads) share no events, streams
+ *     or buffers.  Process-wide state, all of it listed here: (1) the profiling switch below;
+ *     (2) se3conv_bwd keeps one internal side stream + fork/join event pair per (device, caller
+ *     stream) it has been called on, created on first use, for running its two branches side by side
+ *     on mid-sized levels -- the side stream is always joined back into `stream` before the call
+ *     returns, on error paths too; (3) kernel-variant switches read ONCE from the environment at first
+ *     use (A/B and ablation knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP,
+ *     SE3_OVERLAP_ROWS, SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_STREAM,
+ *     SE3_PG_SINGLE, SE3_BWD_MERGE, SE3CONV_FUSED.  `t_save` written by se3conv_fwd must be consumed
+ *     by se3conv_bwd in the same process (same switches);
  *   - return value: SE3_OK (0) or a negative SE3_ERR_* code; no exceptions cross the boundary.
  *
  * Layouts: points [N,3]; frames [N,F,9] = row-major 3x3 per (point,frame)
@@ -269,7 +280,7 @@ int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, i
  * accumulates milliseconds and launch counts per stage tag ("edge_t_fwd", "gemm_out", "gemm_gradT",
  * "edge_param_grad", "gemm_gradW", "edge_t_transposed", "gemm_gradX", "edge_t_recompute", "prep"; the opt-in merged
  * backward adds "gemm_H" / "edge_bwd", the grid kNN "knn_sort" / "knn_cells" / "knn_fallback").
- * Off by default; this switch is the library's only process-wide state.
+ * Off by default.
  * ------------------------------------------------------------------------------------------- */
 int se3_profile_enable(int on);
 int se3_profile_reset(void);

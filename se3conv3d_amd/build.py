@@ -7,6 +7,7 @@ hipcc cross-compiles for gfx950 without a GPU, so this also is the CPU-side "doe
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -40,9 +41,23 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _fingerprint() -> str:
+    """What the objects were compiled with: a change of flags (SE3_CXXFLAGS carries the ablation / variant defines of
+    tools/*.sh, some of which give deliberately wrong results) must rebuild everything, whatever the mtimes say."""
+    return hashlib.sha256(" ".join([ARCH, *FLAGS]).encode()).hexdigest()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
+    stamp = os.path.join(LIBDIR, "build_flags.sha256")
+    fp = _fingerprint()
+    try:
+        with open(stamp) as fh:
+            same_flags = fh.read().strip() == fp
+    except OSError:
+        same_flags = False
+    force = force or not same_flags
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -57,10 +72,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
         subprocess.run(cmd, check=True)
 
     if jobs:
+        if os.path.exists(stamp):
+            os.remove(stamp)  # an interrupted build must not look up to date
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
+    with open(stamp, "w") as fh:
+        fh.write(fp + "\n")
     return LIB
 
 

@@ -1,6 +1,11 @@
 // extern "C" entry points of the fused operator + the API-parity ops (see include/se3conv.h).
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -283,21 +288,53 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
 // backward branches on two streams for this range of output rows: above it every kernel fills the chip by itself
 // (measured: 2.15 vs 2.07 ms at 131 k rows), below it the fork / join costs more than the overlap returns
 constexpr int kOverlapRows = 32768, kOverlapMinRows = 4096;
+// One side stream + fork / join event pair per (device, caller stream), created on first use ON that device and kept
+// for the life of the process: two backward calls on two caller streams (or threads) never share events or a stream,
+// and a caller stream on device 1 never gets a side stream of device 0.  Two calls racing on the SAME caller stream are
+// the caller's race anyway.  The table only grows by the number of distinct streams the caller uses.
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   bool ok = false;
 };
-SideStream& side_stream() {
-  static SideStream ss = [] {
+SideStream* side_stream_for(hipStream_t caller) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SideStream> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = pool.find({dev, caller});
+  if (it == pool.end()) {
     SideStream v;
     v.ok = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&v.fork, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&v.join, hipEventDisableTiming) == hipSuccess;
-    return v;
-  }();
-  return ss;
+    it = pool.emplace(std::make_pair(dev, caller), v).first;
+  }
+  return it->second.ok ? &it->second : nullptr;
 }
+// Joins the forked side stream back into the caller's stream on EVERY exit path of se3conv_bwd once the fork has
+// happened (an early `return rc` would otherwise leave the side stream writing into buffers the caller is about to
+// free, and a stream capture with an unjoined fork).
+struct ForkJoin {
+  SideStream* side = nullptr;
+  hipStream_t main = nullptr;
+  bool forked = false;
+  int fork(SideStream* s, hipStream_t m) {
+    if (hipEventRecord(s->fork, m) != hipSuccess || hipStreamWaitEvent(s->stream, s->fork, 0) != hipSuccess)
+      return SE3_ERR_LAUNCH;
+    side = s, main = m, forked = true;
+    return SE3_OK;
+  }
+  int join() {
+    if (!forked) return SE3_OK;
+    forked = false;
+    if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(main, side->join, 0) != hipSuccess)
+      return SE3_ERR_LAUNCH;
+    return SE3_OK;
+  }
+  ~ForkJoin() { (void)join(); }
+};
 
 EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
                       const int32_t* neighbors, const int32_t* ends, const se3conv_shape* s) {
@@ -614,7 +651,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   }
 
   bool branch_forked = false;
-  SideStream& side = side_stream();
+  ForkJoin fj;  // joins on every exit path from here on
   if (feat_branch) {
     // feature branch: on the side stream when there is a parameter branch to overlap with (SE3_OVERLAP)
     hipStream_t fs = stream;
@@ -626,10 +663,11 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       const char* e = getenv("SE3_OVERLAP_ROWS");
       return e ? (int64_t)atoll(e) : (int64_t)kOverlapRows;
     }();
-    if (want_params && l.big_u != 0 && side.ok && rows_out <= overlap_rows && (rows_out > kOverlapMinRows || overlap_rows > kOverlapRows)) {
-      if (hipEventRecord(side.fork, stream) != hipSuccess || hipStreamWaitEvent(side.stream, side.fork, 0) != hipSuccess)
-        return SE3_ERR_LAUNCH;
-      fs = side.stream;
+    SideStream* side = nullptr;
+    if (want_params && l.big_u != 0 && rows_out <= overlap_rows && (rows_out > kOverlapMinRows || overlap_rows > kOverlapRows) &&
+        (side = side_stream_for(stream)) != nullptr) {
+      if (int rc = fj.fork(side, stream)) return rc;
+      fs = side->stream;
       ubuf = (uint32_t*)(ws + l.big_u);
       fsplit = (float*)(ws + l.split2);
       branch_forked = true;
@@ -694,18 +732,11 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     }
     if (int rc = weight_gradient()) return rc;
   }
-  if (branch_forked) {
-    if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(stream, side.join, 0) != hipSuccess)
-      return SE3_ERR_LAUNCH;
-  }
+  if (int rc = fj.join()) return rc;
   return check_launch();
 }
 
 // ---- optional per-kernel timing ------------------------------------------------------------------
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
 
 namespace se3 {
 namespace {

@@ -201,12 +201,14 @@ __global__ __launch_bounds__(256) void scan_all_kernel(const float* __restrict__
 // Wave-level reduction first (batch ids are sorted, so a wavefront almost always holds one batch element), then
 // one float atomic per wavefront and coordinate -- torch's scatter_reduce on three addresses took 1.3 ms here.
 __device__ __forceinline__ void atomic_min_f(float* addr, float v) {
-  // order-preserving integer view of a float: positive floats as signed ints, negative ones reversed
-  if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  // order-preserving integer view of a float: positive floats as signed ints, negative ones reversed.  The branch
+  // is taken on the SIGN BIT, not on v >= 0: -0.0f compares equal to zero but its bits are INT_MIN, which as a
+  // signed operand would overwrite a negative minimum (and never replace the -inf start value of a maximum).
+  if (__float_as_int(v) >= 0) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
   else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 __device__ __forceinline__ void atomic_max_f(float* addr, float v) {
-  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 

@@ -41,12 +41,18 @@ def get_precision() -> str:
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
-def _stream() -> C.c_void_p:
-    """The current HIP stream of the current device (the raw query: ``torch.cuda.current_stream()`` builds a Python
-    object through several device-index lookups, ~20 us per call)."""
+def _stream(device) -> C.c_void_p:
+    """The current HIP stream of ``device``, which must be the current device: the library launches on the stream it
+    is handed and never switches devices itself, so tensors on another GPU than the current one would be launched
+    on the wrong device's stream.  (The raw query: ``torch.cuda.current_stream()`` builds a Python object through
+    several device-index lookups, ~20 us per call.)"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx != torch.cuda.current_device():
+        raise ValueError(f"tensors live on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: "
+                         "call inside `with torch.cuda.device(tensor.device):` (one process per GPU is the intended use)")
     if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(_raw_stream(idx))
+    return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
 
 def _ptr(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, device=None) -> C.c_void_p:
@@ -92,7 +98,7 @@ def compute_keys(pts, batch_ids, aabb_min, num_cells, cell_size) -> torch.Tensor
     _lib.check(lib.se3_compute_keys(_ptr(pts, torch.float32, "pts"), _ptr(b, torch.int32, "batch_ids", dev),
                                     _ptr(mn, torch.float32, "aabb_min", dev), _ptr(nc, torch.int32, "num_cells"),
                                     _ptr(cs, torch.float32, "cell_size"), n, _ptr(keys, torch.int64, "keys"),
-                                    _stream()), "se3_compute_keys")
+                                    _stream(dev)), "se3_compute_keys")
     return keys
 
 
@@ -121,7 +127,7 @@ def batch_aabb(pts, batch_ids, n_batches: Optional[int] = None) -> Tuple[torch.T
     mx = torch.empty((n_batches, 3), dtype=torch.float32, device=pts.device)
     _lib.check(lib.se3_batch_aabb(_ptr(pts, torch.float32, "pts"), _ptr(b, torch.int32, "batch_ids", pts.device),
                                   pts.shape[0], n_batches, _ptr(mn, torch.float32, "aabb_min"),
-                                  _ptr(mx, torch.float32, "aabb_max"), _stream()), "se3_batch_aabb")
+                                  _ptr(mx, torch.float32, "aabb_max"), _stream(pts.device)), "se3_batch_aabb")
     return mn, mx
 
 
@@ -137,7 +143,7 @@ def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float, n_batches: Opti
     _lib.check(lib.se3_ball_query_grid(
         _ptr(pts_src, torch.float32, "pts_src"), _ptr(batch_src, torch.int32, "batch_src", dev), pts_src.shape[0],
         n_batches, float(radius), C.c_void_p(box[0].data_ptr()), C.c_void_p(box[1].data_ptr()),
-        _ptr(num_cells, torch.int32, "num_cells"), _stream()), "se3_ball_query_grid")
+        _ptr(num_cells, torch.int32, "num_cells"), _stream(dev)), "se3_ball_query_grid")
     return box[0], num_cells
 
 
@@ -167,14 +173,14 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
     _lib.check(lib.se3_ball_query_count(
         _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
         _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius),
-        n_src, n_dst, C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(ends, i32, "ends"), _stream()),
+        n_src, n_dst, C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(ends, i32, "ends"), _stream(dev)),
         "se3_ball_query_count")
     n_edges = int(ends[-1].item())
     neighbors = torch.empty((n_edges, 2), dtype=torch.int32, device=dev)
     _lib.check(lib.se3_ball_query_store(
         _ptr(pts_dst, f32, "pts_dst"), _ptr(bd, i32, "batch_dst"), float(radius), n_src, n_dst,
         C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(ends, i32, "ends"), n_edges,
-        _ptr(neighbors, i32, "neighbors"), _stream()), "se3_ball_query_store")
+        _ptr(neighbors, i32, "neighbors"), _stream(dev)), "se3_ball_query_store")
     return neighbors, ends
 
 
@@ -207,7 +213,7 @@ def csr_transpose(neighbors_i32: torch.Tensor, n_src: int) -> Tuple[torch.Tensor
     ws = _workspace(lib.se3_csr_transpose_workspace_bytes(e), dev)
     _lib.check(lib.se3_csr_transpose(_ptr(neighbors_i32, torch.int32, "neighbors"), e, n_src,
                                      C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(t_samples, torch.int32, "t_samples"),
-                                     _ptr(t_ends, torch.int32, "t_ends"), _stream()), "se3_csr_transpose")
+                                     _ptr(t_ends, torch.int32, "t_ends"), _stream(dev)), "se3_csr_transpose")
     return t_samples, t_ends
 
 
@@ -248,7 +254,7 @@ def grid_subsample(pts, batch_ids, cell_size: float, n_batches: Optional[int] = 
         _ptr(pts, torch.float32, "pts"), _ptr(b, i32, "batch_ids", dev), n, n_batches, float(cell_size),
         C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(cell_ids, i32, "cell_ids"), _ptr(sorted_ids, i32, "sorted_ids"),
         _ptr(cell_ends, i32, "cell_ends"), _ptr(n_cells, i32, "n_cells"), _ptr(cell_pts, torch.float32, "cell_pts"),
-        _ptr(cell_bid, i32, "cell_batch_ids"), _stream()), "se3_grid_subsample")
+        _ptr(cell_bid, i32, "cell_batch_ids"), _stream(dev)), "se3_grid_subsample")
     m = int(n_cells.item())  # the level size has to reach the host: every later allocation depends on it
     return GridCells(cell_ids, sorted_ids, cell_ends[:m], m, cell_pts[:m], cell_bid[:m])
 
@@ -264,7 +270,7 @@ def _segment_pool(cells: GridCells, x2, mode: int, want_arg: bool):
     arg = torch.empty((cells.n_cells, c), dtype=torch.int32, device=x2.device) if want_arg else None
     _lib.check(lib.se3_segment_pool(_ptr(x2, torch.float32, "src"), _ptr(cells.sorted_ids, torch.int32, "sorted_ids"),
                                     _ptr(cells.cell_ends, torch.int32, "cell_ends"), cells.n_cells, c, mode,
-                                    _ptr(out, torch.float32, "out"), _ptr(arg, torch.int32, "arg"), _stream()),
+                                    _ptr(out, torch.float32, "out"), _ptr(arg, torch.int32, "arg"), _stream(x2.device)),
                "se3_segment_pool")
     return out, arg
 
@@ -275,7 +281,7 @@ def _segment_unpool(cells: GridCells, v2, arg, mode: int):
     out = torch.empty((n, c), dtype=torch.float32, device=v2.device)
     _lib.check(lib.se3_segment_unpool(_ptr(v2, torch.float32, "cell_vals"), _ptr(cells.cell_ids, torch.int32, "cell_ids"),
                                       _ptr(cells.cell_ends, torch.int32, "cell_ends"), _ptr(arg, torch.int32, "arg"),
-                                      n, c, mode, _ptr(out, torch.float32, "out"), _stream()), "se3_segment_unpool")
+                                      n, c, mode, _ptr(out, torch.float32, "out"), _stream(v2.device)), "se3_segment_unpool")
     return out
 
 
@@ -327,7 +333,7 @@ class FramePool(torch.autograd.Function):
         out = torch.empty((n, c), dtype=torch.float32, device=x2.device)
         arg = torch.empty((n, c), dtype=torch.int32, device=x2.device) if mode in (1, 2) else None
         _lib.check(lib.se3_frame_pool(_ptr(x2, torch.float32, "x"), n, n_frames, c, mode, _ptr(out, torch.float32, "out"),
-                                      _ptr(arg, torch.int32, "arg"), _stream()), "se3_frame_pool")
+                                      _ptr(arg, torch.int32, "arg"), _stream(x2.device)), "se3_frame_pool")
         ctx.mode, ctx.arg, ctx.f, ctx.shape = mode, arg, n_frames, x.shape
         return out.reshape((n,) + tuple(x.shape[1:]))
 
@@ -338,7 +344,7 @@ class FramePool(torch.autograd.Function):
         n, c = g2.shape
         gx = torch.empty((n * ctx.f, c), dtype=torch.float32, device=g2.device)
         _lib.check(lib.se3_frame_unpool(_ptr(g2, torch.float32, "grad_out"), _ptr(ctx.arg, torch.int32, "arg"), n, ctx.f, c,
-                                        ctx.mode, _ptr(gx, torch.float32, "grad_x"), _stream()), "se3_frame_unpool")
+                                        ctx.mode, _ptr(gx, torch.float32, "grad_x"), _stream(g2.device)), "se3_frame_unpool")
         return gx.reshape(ctx.shape), None, None
 
 
@@ -377,7 +383,7 @@ def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: s
     f32, i32 = torch.float32, torch.int32
     if method == "scan" or (method == "auto" and n < KNN_GRID_MIN_POINTS) or n == 0:
         _lib.check(lib.se3_knn_query(_ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), n, int(k),
-                                     _ptr(out, i32, "out"), _stream()), "se3_knn_query")
+                                     _ptr(out, i32, "out"), _stream(dev)), "se3_knn_query")
         return out
     mn, mx = batch_aabb(pts, b, n_batches)
     counts = torch.bincount(b.to(torch.int64), minlength=mn.shape[0])
@@ -389,7 +395,7 @@ def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: s
     _lib.check(lib.se3_knn_query_grid(
         _ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), _ptr(mn, f32, "aabb_min"), _ptr(num_cells, i32, "num_cells"),
         _ptr(cell3, f32, "cell_size"), n, int(k), _ptr(out, i32, "out"), C.c_void_p(ws.data_ptr()), ws.numel(),
-        _stream()), "se3_knn_query_grid")
+        _stream(dev)), "se3_knn_query_grid")
     return out
 
 
@@ -418,7 +424,7 @@ def pca_frames(pts, knn_ids, axis_fixed=None) -> torch.Tensor:
     nf = 4 if axis < 0 else 2
     frames = torch.empty((n, nf, 9), dtype=torch.float32, device=pts.device)
     _lib.check(lib.se3_pca_frames(_ptr(pts, torch.float32, "pts"), _ptr(ids, torch.int32, "knn", pts.device), n, k, axis,
-                                  _ptr(frames, torch.float32, "frames"), _stream()), "se3_pca_frames")
+                                  _ptr(frames, torch.float32, "frames"), _stream(pts.device)), "se3_pca_frames")
     return frames
 
 
@@ -506,7 +512,7 @@ def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weigh
                                _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
                                _ptr(rho_t, f32, "norm_neigh_dist_"), _ptr(nu_t, f32, "norm_num_neighs_"),
                                C.byref(shp), _ptr(out, f32, "out"), _ptr(t_save, f32, "t_save"),
-                               C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "se3conv_fwd")
+                               C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)), "se3conv_fwd")
     return out, t_save
 
 
@@ -535,7 +541,7 @@ def se3conv_backward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weig
                                _ptr(rho_t, f32, "rho"), _ptr(nu_t, f32, "nu"), _ptr(t_save, f32, "t_save"),
                                _ptr(g, f32, "grad_out", dev), C.byref(shp), _ptr(d_x, f32, "grad_feat"),
                                _ptr(d_a, f32, "grad_axes"), _ptr(d_b, f32, "grad_biases"),
-                               _ptr(d_w, f32, "grad_weights"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                               _ptr(d_w, f32, "grad_weights"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)),
                "se3conv_bwd")
     return d_x, d_a, d_b, d_w
 
@@ -586,7 +592,7 @@ def rot_tensors(geom: ConvGeometry, rho):
     rho_t = _scalar(rho, "rho", dev)
     _lib.check(lib.se3_rot_tensors(*_geom_ptrs(geom), _ptr(rho_t, torch.float32, "rho"), C.byref(shp),
                                    _ptr(desc, torch.float32, "desc"), _ptr(fe_nb, torch.int32, "fe_neighbors"),
-                                   _ptr(fe_ends, torch.int32, "fe_ends"), _stream()), "se3_rot_tensors")
+                                   _ptr(fe_ends, torch.int32, "fe_ends"), _stream(dev)), "se3_rot_tensors")
     return desc, fe_nb, fe_ends
 
 
@@ -607,7 +613,7 @@ class FeatBasisProj(torch.autograd.Function):
         _lib.check(lib.se3_feat_basis_proj(_ptr(basis, f32, "pt_basis", dev), _ptr(feat, f32, "pt_features"),
                                            _ptr(nb, i32, "neighbors", dev), _ptr(ends, i32, "start_ids", dev),
                                            nb.shape[0], rows, feat.shape[0], ch, kb, _ptr(out, f32, "out"),
-                                           _stream()), "se3_feat_basis_proj")
+                                           _stream(dev)), "se3_feat_basis_proj")
         return out
 
     @staticmethod
@@ -622,6 +628,6 @@ class FeatBasisProj(torch.autograd.Function):
         _lib.check(lib.se3_feat_basis_proj_grad(
             _ptr(basis, f32, "pt_basis", dev), _ptr(feat, f32, "pt_features"), _ptr(nb, i32, "neighbors"),
             _ptr(ends, i32, "start_ids"), _ptr(g, f32, "grads", dev), nb.shape[0], ends.shape[0], feat.shape[0],
-            feat.shape[1], basis.shape[1], _ptr(g_feat, f32, "g_feat"), _ptr(g_basis, f32, "g_basis"), _stream()),
+            feat.shape[1], basis.shape[1], _ptr(g_feat, f32, "g_feat"), _ptr(g_basis, f32, "g_basis"), _stream(dev)),
             "se3_feat_basis_proj_grad")
         return g_basis.to(p_ctx.dtypes[0]), g_feat.to(p_ctx.dtypes[1]), None, None

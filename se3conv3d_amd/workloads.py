@@ -1,0 +1,128 @@
+"""Synthetic workloads of the benchmark and the size tests: clouds of stated
+(N points, k neighbours, F frames, C channels) shaped like the batches the reference's task scripts feed
+the layer.  Shared by ``bench.py``, ``tools/`` and ``tests/``; nothing here touches the oracle.
+
+  headline        one cloud of 65 536 points, F = 2 random frames, C = 64, k ~ 32  -- BASELINE.json's metric
+  scannet150k_f1  one ScanNet-like scene of 150 000 points, F = 1 frame about the fixed up axis, C = 64
+                  (tasks/SemSeg/confs/scannet/scannet20_rot_pca_SO2.yaml:5,26,40; one scene per GPU = config 5)
+  dfaust_f2       32 bodies x 2 200 points (4096 sampled, 0.04 grid), F = 2 PCA frames from 16-NN, level widths
+                  32/64/128/256 (tasks/SemSeg/confs/dfaust/dfaust_I_rot_pca_2F.yaml:4,17,37-38; seg_models.py:26-27)
+  dfaust_f4       16 bodies x 6 900 points, F = 4 PCA frames (the four sign flips of the eigenbasis)
+
+Every workload is a stack: one same-level ``PNEConvLayerRotEquiv`` per hierarchy level, levels by grid
+sub-sampling with cell doubling, radius = 2 x the cell that produced the level (seg_models.py:29-33).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+
+WORKLOADS: Dict[str, dict] = {
+    "headline": dict(points=65536, clouds=1, frames=2, widths=[64, 64, 64, 64], degree=32, fixed_axis=False, pca=False,
+                     note="4-level PNEConvLayerRotEquiv stack, N=65536, k=32, F=2, C=64"),
+    "scannet150k_f1": dict(points=150000, clouds=1, frames=1, widths=[64, 64, 64, 64], degree=32, fixed_axis=2, pca=False,
+                           note="4-level stack on one ScanNet-like scene of 150k points, F=1 about the fixed up axis, C=64"),
+    "dfaust_f2": dict(points=2200, clouds=32, frames=2, widths=[32, 64, 128, 256], degree=24, fixed_axis=False, pca=True,
+                      note="4-level stack on a DFaust-like batch: 32 bodies x 2200 points, F=2 PCA frames, C=32/64/128/256"),
+    "dfaust_f4": dict(points=6900, clouds=16, frames=4, widths=[32, 64, 128, 256], degree=24, fixed_axis=False, pca=True,
+                      note="4-level stack on 16 bodies x 6900 points, F=4 PCA frames, C=32/64/128/256"),
+}
+NUM_BASIS = 32
+
+
+def radius_for_degree(n: int, k: float) -> float:
+    """r = (3k / (4 pi N))^(1/3): expected interior degree k for N uniform points in [0,1)^3."""
+    return (3.0 * k / (4.0 * math.pi * n)) ** (1.0 / 3.0)
+
+
+def frames_config(spec: dict) -> dict:
+    cfg = {"pca": bool(spec["pca"]), "n_frames": spec["frames"], "fixed_axis": spec["fixed_axis"]}
+    if spec["pca"]:
+        cfg.update(neigh_method="knn", neigh_kwargs={"neigh_k": 16})
+    return cfg
+
+
+def build_cloud(spec: dict, device, seed: int):
+    """Points ~ U[0,1)^3 per batch element, batch ids ascending, frames per ``spec`` (seeded)."""
+    from . import pc as _pc
+
+    torch.manual_seed(seed)
+    n = spec["points"] * spec["clouds"]
+    pts = torch.rand(n, 3, device=device)
+    bid = torch.arange(spec["clouds"], device=device, dtype=torch.int32).repeat_interleave(spec["points"])
+    return _pc.PointcloudRotEquiv(pts, bid, frames_config(spec))
+
+
+def build_stack(spec: dict, device, seed: int, n_levels: int = 4) -> List[dict]:
+    """The stack of one rank: per level the cloud, its ball-query neighbourhood, a conv with converged EMA
+    buffers (rho = 1/r, nu = M/E), input features and an output gradient."""
+    from . import layers, pc as _pc
+
+    r0 = radius_for_degree(spec["points"], spec["degree"])
+    pc0 = build_cloud(spec, device, seed)
+    cells = [r0 * 2 ** i for i in range(n_levels - 1)]
+    hier = _pc.PointHierarchyRotEquiv(pc0, n_levels - 1, "grid_avg", grid_radii=cells)
+    radii = [r0 * 2 ** i for i in range(n_levels)]
+    factory = layers.PNEConvLayerRotEquivFactory(9, NUM_BASIS, "mlp_gelu")
+    f = spec["frames"]
+    levels = []
+    for lvl, (pc, r) in enumerate(zip(hier.pcs_, radii)):
+        ch = spec["widths"][lvl]
+        nbh = hier.create_neighborhood(lvl, lvl, "ball_query", bq_radius=r)
+        conv = factory.create_conv_layer(ch, ch).to(device)
+        conv.norm_neigh_dist_.fill_(1.0 / r)
+        conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.neighbors_.shape[0], 1))
+        n = pc.pts_.shape[0]
+        x = torch.randn(n * f, ch, device=device, requires_grad=True)
+        g = torch.randn(n * f, ch, device=device)
+        levels.append(dict(pc=pc, nbh=nbh, conv=conv, x=x, g=g, n=n, e=nbh.neighbors_.shape[0], r=r, c=ch, f=f))
+    return levels
+
+
+# ---- algorithmic work of one layer ---------------------------------------------------
+def layer_flops(n: int, e: int, f: int, c: int, kb: int = NUM_BASIS) -> Dict[str, int]:
+    """Algorithmic FLOPs per stage (MLP counted with its bias row)."""
+    ep, rows = e * f * f, n * f
+    dense = rows * 2 * c * kb * c
+    edge = ep * (2 * 10 * kb + 2 * c * kb)
+    pg = ep * (2 * 10 * kb + 2 * c * kb + 2 * 10 * kb)
+    return {"edge_t_fwd": edge, "gemm_out": dense, "gemm_gradT": dense, "gemm_gradW": dense, "gemm_gradX": dense,
+            "edge_t_transposed": edge, "edge_param_grad": pg}
+
+
+def stage_owned_bytes(n: int, e: int, f: int, c: int, kb: int = NUM_BASIS) -> Dict[str, int]:
+    """SURVEY.md section 8d's algorithmic bytes of one layer fwd+bwd, split over the launches that own them
+    (uncached-gather model: every point-edge touches its neighbour's F*C block once per pass; no T, no
+    E'-sized or row-sized intermediates).  The values sum to ``layer_bytes``."""
+    rows = n * f
+    geom = 8 * e + 4 * n + 12 * 2 * n + 36 * 2 * rows
+    params = 4 * (10 * kb + c * kb * c)
+    gather = 4 * e * f * c
+    act = 4 * rows * c
+    return {"edge_t_fwd": geom + gather,            # B_f: edges, ends, points, frames, gathered f
+            "gemm_out": act + params,               # out write, parameters
+            "edge_t_transposed": gather,            # dX via the source-sorted segmented reduce: gathered g
+            "gemm_gradX": act,                      # dX write
+            "edge_param_grad": geom + gather,       # B_b: geometry again, re-gather of f
+            "gemm_gradT": act + params,             # g read, parameters
+            "gemm_gradW": params}                   # parameter gradients written
+
+
+def layer_bytes(n: int, e: int, f: int, c: int, kb: int = NUM_BASIS) -> int:
+    return sum(stage_owned_bytes(n, e, f, c, kb).values())
+
+
+def stage_moved_bytes(n: int, e: int, f: int, c: int, t24: bool = True, kb: int = NUM_BASIS) -> Dict[str, int]:
+    """What each launch of the unfused pipeline has to move at least: its owned bytes plus the row-sized
+    intermediates it writes or reads (T / U in 3-byte rows when ``t24``, grad_T as 4-byte words)."""
+    rows = n * f
+    g_bytes = 4 * rows * c * kb
+    t_bytes = (3 if t24 else 4) * rows * c * kb
+    own = stage_owned_bytes(n, e, f, c, kb)
+    act = 4 * rows * c
+    return {"edge_t_fwd": own["edge_t_fwd"] + t_bytes, "gemm_out": own["gemm_out"] + t_bytes,
+            "edge_t_transposed": own["edge_param_grad"] + t_bytes, "gemm_gradX": own["gemm_gradX"] + t_bytes + own["gemm_gradW"],
+            "edge_param_grad": own["edge_param_grad"] + g_bytes, "gemm_gradT": own["gemm_gradT"] + g_bytes,
+            "gemm_gradW": own["gemm_gradW"] + t_bytes + act}

@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import se3conv3d_amd as amd
-from oracle import se3conv_oracle as O
+from se3conv3d_amd.workloads import radius_for_degree
 
 dev = torch.device("cuda", 0)
 CASES = [  # name, points per element, batch elements, frames, c_in, c_out, degree, fixed axis
@@ -25,7 +25,7 @@ for name, n_el, nb, f, ci, co, deg, axis in CASES:
     bid = torch.arange(nb, device=dev, dtype=torch.int32).repeat_interleave(n_el)
     cfg = {"pca": False, "n_frames": f, "fixed_axis": axis}
     pc = amd.pc.PointcloudRotEquiv(pts, bid, cfg)
-    r = O.radius_for_degree(n_el, deg)
+    r = radius_for_degree(n_el, deg)
     nbh = amd.pc.BQNeighborhood(pc, pc, r)
     conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(ci, co).to(dev)
     conv.norm_neigh_dist_.fill_(1.0 / r)

@@ -15,14 +15,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--precision", default="bf16x3")
-    ap.add_argument("--n", type=int, default=bench.N0)
+    ap.add_argument("--n", type=int, default=65536)
+    ap.add_argument("--workload", default="headline")
     args = ap.parse_args()
     import se3conv3d_amd as amd
-    from oracle import se3conv_oracle as O
+    from se3conv3d_amd import workloads as W
 
     amd.set_precision(args.precision)
-    bench.N0 = args.n
-    levels = bench.build_stack(amd, O, torch.device("cuda", 0), seed=0)
+    spec = dict(W.WORKLOADS[args.workload])
+    if args.workload == "headline":
+        spec["points"] = args.n
+    levels = W.build_stack(spec, torch.device("cuda", 0), seed=0, n_levels=1)
     for _ in range(args.reps):
         bench.step(levels[:1])
     torch.cuda.synchronize()

@@ -8,14 +8,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import se3conv3d_amd as amd
 from se3conv3d_amd import _lib
-from oracle import se3conv_oracle as O
 import bench
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
-levels = bench.build_stack(amd, O, dev, 0)
+from se3conv3d_amd import workloads as W
+levels = W.build_stack(W.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'headline'], dev, 0)
 for i, lv in enumerate(levels):
-    st = bench.profile_level0(lib, lv, reps=5)
+    st = bench.profile_level(lib, lv, reps=5)
     run = bench.GraphedStep([lv])
     for _ in range(5):
         run()
@@ -24,5 +24,5 @@ for i, lv in enumerate(levels):
         run()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 50 * 1e3
     tot = sum(v[0] for v in st.values())
-    print(f"level {i}: n {lv['n']:6d} rows {lv['n'] * bench.FRAMES:7d} e {lv['e']:8d}  graph replay {ms:.3f} ms   sum of stages {tot:.3f} ms")
+    print(f"level {i}: n {lv['n']:6d} rows {lv['n'] * lv['f']:7d} e {lv['e']:8d}  graph replay {ms:.3f} ms   sum of stages {tot:.3f} ms")
     print("   " + "  ".join(f"{k} {v[0] * 1e3:.0f}us" for k, v in sorted(st.items())))

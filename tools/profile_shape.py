@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import se3conv3d_amd as amd
-from oracle import se3conv_oracle as O
+from se3conv3d_amd.workloads import radius_for_degree
 from se3conv3d_amd import _lib
 
 n, f, ci, co = (int(v) for v in sys.argv[1:5])
@@ -16,13 +16,13 @@ torch.manual_seed(0)
 pts = torch.rand(n, 3, device=dev)
 bid = torch.zeros(n, dtype=torch.int32, device=dev)
 pc = amd.pc.PointcloudRotEquiv(pts, bid, {"pca": False, "n_frames": f, "fixed_axis": False})
-r = O.radius_for_degree(n, deg)
+r = radius_for_degree(n, deg)
 nbh = amd.pc.BQNeighborhood(pc, pc, r)
 conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(ci, co).to(dev)
 conv.norm_neigh_dist_.fill_(1.0 / r)
 conv.norm_num_neighs_.fill_(0.03)
 lv = dict(pc=pc, nbh=nbh, conv=conv, x=torch.randn(n * f, ci, device=dev, requires_grad=True),
           g=torch.randn(n * f, co, device=dev), n=n, e=nbh.neighbors_.shape[0], r=r)
-st = bench.profile_level0(lib, lv, 5)
+st = bench.profile_level(lib, lv, 5)
 print(f"N={n} F={f} C={ci}->{co} E={lv['e']}: sum {sum(v[0] for v in st.values()):.3f} ms")
 print("   ", {k: round(v[0], 4) for k, v in sorted(st.items())})

@@ -5,6 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import se3conv3d_amd as amd
 from oracle import se3conv_oracle as O
+from se3conv3d_amd.workloads import radius_for_degree
 
 def t(f, n=5):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -13,7 +14,7 @@ def t(f, n=5):
 
 for n in (65536, 150000):
     pts = torch.rand(n, 3, device="cuda"); bid = torch.zeros(n, dtype=torch.int32, device="cuda")
-    r = O.radius_for_degree(n, 32)
+    r = radius_for_degree(n, 32)
     knn = amd.ops.knn_query(pts, bid, 16)
     print(f"N={n}: ball_query(k~32) {t(lambda: amd.ops.ball_query(pts, pts, bid, bid, r)):.3f} ms | "
           f"knn(16) grid {t(lambda: amd.ops.knn_query(pts, bid, 16, 1, 'grid')):.3f} ms, all-pairs {t(lambda: amd.ops.knn_query(pts, bid, 16, 1, 'scan'), 2):.3f} ms | pca_frames {t(lambda: amd.ops.pca_frames(pts, knn)):.3f} ms")

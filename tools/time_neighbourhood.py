@@ -6,11 +6,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import se3conv3d_amd as amd
-from oracle import se3conv_oracle as O
+from se3conv3d_amd import workloads as W
 import bench
 
 dev = torch.device("cuda:0")
-levels = bench.build_stack(amd, O, dev, 0)
+levels = W.build_stack(W.WORKLOADS['headline'], dev, 0)
 
 def timed(fn, reps=10):
     for _ in range(3):
