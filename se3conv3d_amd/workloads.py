@@ -1,6 +1,6 @@
 """Synthetic workloads of the benchmark and the size tests: clouds of stated
 (N points, k neighbours, F frames, C channels) shaped like the batches the reference's task scripts feed
-the layer.  Shared by ``bench.py``, ``tools/`` and ``tests/``; nothing here touches the oracle.
+the layer.  Shared by ``bench.py``, ``tools/`` and ``tests/``; nothing here depends on the checker.
 
   headline        one cloud of 65 536 points, F = 2 random frames, C = 64, k ~ 32  -- BASELINE.json's metric
   scannet150k_f1  one ScanNet-like scene of 150 000 points, F = 1 frame about the fixed up axis, C = 64
