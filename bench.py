@@ -121,6 +121,29 @@ def profile_level(lib, lv, reps):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
+def usable_cores() -> int:
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands
+    a job a share of a larger host; torch with one thread per LOGICAL core of the host then thrashes -- measured 70x
+    slower than 8 threads on a 256-thread host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, q // int(fh.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline():
     """the oracle (a port of the reference's Python path, kind "port") on this box's host
     cores -- threads = all cores and 8 (MAX_NUM_THREADS of tasks/SemSeg/train_dfaust_rot.py:17); configuration 1
@@ -160,7 +183,7 @@ def cpu_baseline():
                 "fwd_s": round(mf, 4), "bwd_s": round(mb, 4), "runs": len(fwd),
                 "mpoints_per_s": round(n / (mf + mb) / 1e6, 6)}
 
-    all_cores = os.cpu_count() or 1
+    all_cores = usable_cores()
     prev = torch.get_num_threads()
     cases = []
     for threads in (all_cores, 8):
@@ -171,7 +194,7 @@ def cpu_baseline():
     return {"value": best["mpoints_per_s"], "unit": "Mpoints/s", "cores": best["threads"], "kind": "port",
             "sample": "oracle (torch CPU port of the reference's Python path) single layer, fwd and bwd timed separately, "
                       f"median of up to 5 runs inside a 15 s budget; value = headline proxy N=8192, k~{best['k_achieved']}, F=2, C=64, K=32 "
-                      f"at {best['threads']} threads ({best['fwd_s']} s fwd + {best['bwd_s']} s bwd); host has {all_cores} logical cores",
+                      f"at {best['threads']} threads ({best['fwd_s']} s fwd + {best['bwd_s']} s bwd); usable host cores (affinity / cgroup quota): {all_cores} of {os.cpu_count()} logical",
             "cases": cases}
 
 

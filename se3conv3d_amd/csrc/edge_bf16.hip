@@ -358,6 +358,225 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The wave-pair kernel as a CHUNK STREAM (two frames per point, C = 64): a resident set of workgroups, each walking a
+// contiguous range of centre points whose edge count is balanced on the device (binary search in the inclusive
+// offsets `ends`, which are prefix sums), treats the chunks of all its points as one software-pipelined sequence.
+// What a one-point workgroup pays in front of its first chunk -- three dependent memory round trips (row extent ->
+// neighbour ids -> geometry records; a wavefront lives for ~2.5 chunks, 37 % of it parked in s_waitcnt, VALU issue
+// slots 46 % used: profiles/r01_n_pmc_summary.txt) -- is paid once per workgroup here: neighbour ids run two chunks
+// ahead ACROSS points, geometry records one chunk ahead, and everything that is uniform over the workgroup (row
+// extents, the centre's own record) comes through the scalar cache into SGPRs (constant-address-space loads), which
+// also takes 12 VGPRs out of the 128 the kernel may use at 4 wavefronts per SIMD.
+// ------------------------------------------------------------------------------------------------
+using cint_p = const __attribute__((address_space(4))) int32_t*;
+using cflt_p = const __attribute__((address_space(4))) float*;
+constexpr int kStreamItemWeight = 8;  // a point costs about as much as 8 edges besides its edges (row epilogue)
+
+struct ChunkCur {  // wave-uniform position in the chunk stream (SGPRs)
+  int ctr, start, end, end2, c0;
+};
+
+__global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_stream_bf16_kernel(
+    EdgeGeom g, const uint32_t* __restrict__ feat, int64_t feat_rows, const float* __restrict__ axes_ext,
+    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int ctr_lo, int ctr_hi, int fnb_shift, int t24) {
+  constexpr int C = 64;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int kcol = lane & 31, h = lane >> 5;
+  if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
+  __syncthreads();
+  const float rho = *rho_p;
+  constexpr int row_bytes = C * 4;
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const cint_p ends_c = (cint_p)g.ends;
+  const int f_nb = g.f_nb;
+
+  // ---- this workgroup's range of centre points: equal shares of  edges + kStreamItemWeight * points
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  auto prefix = [&](int c) -> int64_t { return (int64_t)(c > 0 ? ends_c[c - 1] : 0) + (int64_t)kStreamItemWeight * c; };
+  const int64_t p_lo = prefix(ctr_lo), p_total = prefix(ctr_hi) - p_lo;
+  auto bound = [&](int j) {
+    if (j <= 0) return ctr_lo;
+    if (j >= G) return ctr_hi;
+    const int64_t t = p_lo + p_total * j / G;
+    int lo = ctr_lo, hi = ctr_hi;  // smallest c with prefix(c) >= t
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (prefix(mid) < t) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int my_lo = bound(b), my_hi = bound(b + 1);
+  if (my_lo >= my_hi) return;
+
+  auto cur_init = [&](int c) {
+    ChunkCur k;
+    k.ctr = c, k.start = c > 0 ? ends_c[c - 1] : 0, k.end = ends_c[c], k.end2 = ends_c[min(c + 1, my_hi - 1)], k.c0 = 0;
+    return k;
+  };
+  auto n_of = [&](const ChunkCur& k) { return (k.end - k.start) * f_nb; };
+  auto advance = [&](ChunkCur& k) {
+    k.c0 += 32;
+    if (k.c0 >= n_of(k)) {  // next point (also for a point without neighbours: one empty chunk)
+      k.ctr += 1, k.start = k.end, k.end = k.end2, k.c0 = 0;
+      k.end2 = ends_c[min(k.ctr + 1, my_hi - 1)];
+      if (k.ctr >= my_hi) k.end = k.start;  // past the range: empty chunks, nothing is loaded for them
+    }
+  };
+  // frame-edge of this lane in chunk k -> neighbour id (global load) / source row
+  auto fe_of = [&](const ChunkCur& k) { return max(min(k.c0 + kcol, n_of(k) - 1), 0); };
+  auto nbr_of = [&](const ChunkCur& k) {
+    if (n_of(k) <= 0) return 0;
+    const int fe = fe_of(k);
+    const int e = k.start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / f_nb);
+    return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+  };
+  auto row_of = [&](int nb, const ChunkCur& k) {
+    const int fe = fe_of(k);
+    return nb * f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % f_nb);
+  };
+  // the centre's own record (this wavefront's frame) through the scalar cache
+  auto centre_record = [&](int ctr, float yc[3], float rc[9]) {
+    const cflt_p p = (cflt_p)(g.ctr_geom + ((int64_t)ctr * 2 + wv) * 16);
+    yc[0] = p[0], yc[1] = p[1], yc[2] = p[2], rc[8] = p[3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rc[i] = p[4 + i];
+  };
+
+  ChunkCur A = cur_init(my_lo), B = A;
+  advance(B);
+  ChunkCur Cc = B;
+  advance(Cc);
+  float yc[3], rc[9], yc_n[3], rc_n[9];
+  centre_record(A.ctr, yc, rc);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) yc_n[i] = yc[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rc_n[i] = rc[i];
+  int q_a = row_of(nbr_of(A), A);
+  int ids_b = nbr_of(B);
+  float xn_nx[3], rn_nx[9];
+  load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
+  const int hb = 16 * h;
+  int buf = 0;
+  f32x16 acc[2] = {zero16(), zero16()};
+
+  while (A.ctr < my_hi) {
+    const int n_a = n_of(A);
+    const int cnt = max(min(32, n_a - A.c0), 0);
+    const int qoff = A.c0 + kcol < n_a ? q_a * row_bytes : kOobOffset;
+    float xn[3], rn[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+    const int q_b = row_of(ids_b, B);
+    ids_b = nbr_of(Cc);  // ids two chunks ahead, across points
+
+    uint32_t fw[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+        fw[s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + (32 * wv + kcol) * 4, 0, 0);
+      }
+    load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);  // geometry one chunk ahead
+    if (B.c0 == 0 && B.ctr < my_hi) centre_record(B.ctr, yc_n, rc_n);
+
+    if (!g.transposed)
+      edge_descriptor(xn, rn, yc, rc, rho, d);
+    else
+      edge_descriptor(yc, rc, xn, rn, rho, d);
+    {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
+      u32x4 a_hi, a_lo;
+      frags_from_floats(v, a_hi, a_lo);
+      const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
+      const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
+      const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s * 16 < cnt) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
+          u32x4 b_hi, b_lo;
+          frags_from_floats(pv, b_hi, b_lo);
+          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
+          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
+        }
+      }
+    }
+    __syncthreads();  // both frames' fragments of this chunk are published (the other buffer is used next chunk)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s * 16 < cnt) {
+        u32x4 fa_hi, fa_lo;
+        frags_from_words(fw[s], fa_hi, fa_lo);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const u32x4 b_hi = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
+          const u32x4 b_lo = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
+          acc[a] = mfma_bf16x3(fa_hi, fa_lo, b_hi, b_lo, acc[a]);
+        }
+      }
+    }
+    // The prefetches of this iteration (neighbour ids, next chunk's geometry) are made to land HERE, before the row
+    // stores below are issued: vmcnt retires loads and stores in issue order, and the register copies the compiler
+    // places at the loop's back edge would otherwise wait for the stores of a finished point as well (vmcnt(0)).
+    asm volatile("" : "+v"(ids_b), "+v"(xn_nx[0]), "+v"(xn_nx[1]), "+v"(xn_nx[2]), "+v"(rn_nx[0]), "+v"(rn_nx[1]),
+                 "+v"(rn_nx[2]), "+v"(rn_nx[3]), "+v"(rn_nx[4]), "+v"(rn_nx[5]), "+v"(rn_nx[6]), "+v"(rn_nx[7]),
+                 "+v"(rn_nx[8]));
+    if (A.c0 + 32 >= n_a) {
+      // last chunk of the point: acc[a] register r, lane (kcol, h) = T[row 2*ctr + a][32*wv + acc_row(r,h)][kcol]
+      const int ch0 = 32 * wv;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int64_t row_id = (int64_t)A.ctr * 2 + a;
+        if (t24) {
+          char* row = reinterpret_cast<char*>(t_out) + row_id * t24_row_bytes(C);
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int ch = ch0 + acc_row(r, h);  // even
+            uint32_t hp, lp;
+            t24_pack2(acc[a][r], acc[a][r + 1], hp, lp);
+            const int idx = (ch >> 1) * kBasis + kcol;
+            __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
+            __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2) + idx);
+          }
+        } else {
+          uint32_t* t_row = t_out + (row_id * C + ch0) * kBasis;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            uint32_t w0, w1;
+            split_pack2(acc[a][r], acc[a][r + 1], w0, w1);
+            __builtin_nontemporal_store(w0, &t_row[acc_row(r, h) * kBasis + kcol]);
+            __builtin_nontemporal_store(w1, &t_row[acc_row(r + 1, h) * kBasis + kcol]);
+          }
+        }
+        acc[a] = zero16();
+      }
+    }
+    if (B.c0 == 0) {  // the next chunk starts a new point: its centre record has arrived by now
+#pragma unroll
+      for (int i = 0; i < 3; ++i) yc[i] = yc_n[i];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) rc[i] = rc_n[i];
+    }
+    A = B, B = Cc;
+    advance(Cc);
+    q_a = q_b;
+    buf ^= 1;
+  }
+}
+
 // persistent variant (single channel pass): see edge_stream_bf16
 template <int VW, int FC, bool FULL>
 __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_stream_bf16_kernel(
@@ -814,6 +1033,31 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
     const int64_t n_range = item_hi - item_lo;
     if (n_range <= 0) return SE3_OK;
+    // chunk-stream form: two frames per point, 64 channels (the headline shape); SE3_PAIR_STREAM=0 turns it off
+    static const bool stream_on = [] {
+      const char* e = getenv("SE3_PAIR_STREAM");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    if (stream_on && two && g.f_ctr == 2 && channels == 64 && g.n_ctr < (1ll << 30)) {
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      static const int per_cu = [] {
+        const char* e = getenv("SE3_PAIR_STREAM_WGS");
+        return e ? atoi(e) : 2 * SE3_PAIR_WAVES;  // resident 128-thread workgroups per CU at SE3_PAIR_WAVES waves / SIMD
+      }();
+      const int64_t resident = (int64_t)n_cu * per_cu;
+      // short ranges lose the point of the stream: below 4 points per workgroup use fewer workgroups
+      int64_t wgs = n_range / 4 < resident ? (n_range + 3) / 4 : resident;
+      if (wgs < 1) wgs = 1;
+      hipLaunchKernelGGL(edge_t_pair_stream_bf16_kernel, dim3((unsigned)wgs), dim3(128), 0, stream, g, feat, feat_rows,
+                         axes_ext, rho, t_out, (int)item_lo, (int)item_hi, shift, t24 ? 1 : 0);
+      return check_launch();
+    }
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
 #define SE3_PAIR(CT, FULL)                                                                                              \
