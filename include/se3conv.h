@@ -274,6 +274,43 @@ int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, i
                    float* frames, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-wise glue of a block around the convolution (scope row f-3)  <-  the torch element-wise / reduction passes of
+ *   layers/ResNetFormer.py:64-88 (norm -> conv -> skip; norm -> linear -> GELU -> linear -> skip),
+ *   layers/BatchNormPC.py:22-32 (BatchNorm1d, momentum 0.2), layers/SkipConnection.py (x * gamma_ + y with
+ *   gamma_ [1,C]) and layers/DropPathPC.py:30-46 (one keep / drop decision per batch element, indexed through the
+ *   per-row batch ids -- batch_ids_considering_frames_ for clouds with frames).
+ * All tensors [rows, C] fp32 row-major; per-channel vectors [C]; C <= 1024 (C > 256 needs C % 4 == 0).  Channel
+ * sums are accumulated in fp64 in a fixed order (no atomics).  `workspace`: se3_glue_workspace_bytes(C) bytes.
+ *   se3_bn_fwd        training-mode torch.nn.BatchNorm1d: save_mean[c], save_invstd[c] = 1 / sqrt(biased var + eps),
+ *                     y = (x - mean) * invstd * weight + bias, running_mean / running_var (may be NULL) updated in place
+ *                     with `momentum` and the unbiased variance; weight / bias NULL = 1 / 0
+ *   se3_affine_act    y = act(x * scale[c] + shift[c]); scale / shift may be NULL (1 / 0); act 0 = none, 1 = exact-erf
+ *                     GELU: batch-norm apply (scale = weight * invstd, shift = bias - mean * scale), bias + GELU
+ *   se3_bn_bwd        dbeta[c] = sum dy, dgamma[c] = sum dy * xhat, dx = gamma * invstd * (dy - dbeta/N - xhat * dgamma/N)
+ *                     with xhat = (x - mean) * invstd  (gamma NULL = 1)
+ *   se3_skip_fwd      out = x * gamma[c] * gate[row_batch[r]] + y   (gate NULL: no drop path; the caller folds 1/keep
+ *                     into gate)
+ *   se3_skip_bwd      dx = g * gamma[c] * gate (dx may be NULL), dgamma[c] = sum_r g * x * gate   (dy = g)
+ *   se3_bias_gelu_bwd dz = g * GELU'(z + bias), dbias[c] = sum_r dz   (bias NULL = 0)
+ * ------------------------------------------------------------------------------------------- */
+size_t se3_glue_workspace_bytes(int32_t c);
+int se3_bn_fwd(const float* x, const float* weight, const float* bias, int64_t rows, int32_t c, float eps, float momentum,
+               float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
+               size_t workspace_bytes, void* stream);
+int se3_affine_act(const float* x, const float* scale, const float* shift, int64_t rows, int32_t c, int32_t act,
+                   float* y, void* stream);
+int se3_bn_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
+               int64_t rows, int32_t c, float* dx, float* dgamma, float* dbeta, void* workspace,
+               size_t workspace_bytes, void* stream);
+int se3_skip_fwd(const float* x, const float* y, const float* gamma, const float* gate, const int32_t* row_batch,
+                 int64_t rows, int32_t c, float* out, void* stream);
+int se3_skip_bwd(const float* g, const float* x, const float* gamma, const float* gate, const int32_t* row_batch,
+                 int64_t rows, int32_t c, float* dx, float* dgamma, void* workspace, size_t workspace_bytes,
+                 void* stream);
+int se3_bias_gelu_bwd(const float* g, const float* z, const float* bias, int64_t rows, int32_t c, float* dz,
+                      float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optional per-kernel timing for bench.py's roofline line (no reference counterpart: the reference
  * only prints wall-clock per batch, tasks/SemSeg/train_dfaust_rot.py:239-296).  When enabled, every
  * kernel launch of the fused operator is bracketed by hipEvents on its own launch stream; read

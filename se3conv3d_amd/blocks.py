@@ -1,17 +1,28 @@
-"""Block-level glue of the reference's networks around the convolution (scope row f-3, the torch part): drop path with
-frame-aware batch ids, the residual connection with its learned gain, the point-cloud batch norm and the ResNetFormer
-block.  These are thin torch modules -- the dense C x C layers are rocBLAS GEMMs, nothing here is a HIP kernel -- kept so
-that a model written against the reference runs on this package unchanged and a reference ``state_dict`` loads key
-for key (attribute names are the reference's).
+"""Block-level glue of the reference's networks around the convolution (scope row f-3): drop path with frame-aware
+batch ids, the residual connection with its learned gain, the point-cloud batch norm and the ResNetFormer block, with
+the reference's attribute names so that a reference ``state_dict`` loads key for key.  On GPU tensors the row-wise
+passes run as the library's fused kernels (csrc/glue.hip through ops.BatchNormTrain / SkipDropPath / BiasGelu): training
+batch norm in 3 launches each way, skip + layer scale + drop-path gate in one, bias + GELU behind a bias-free GEMM in
+one -- 11 launches forward for a block's glue instead of ~25 torch ones; the dense C x C products stay rocBLAS GEMMs.
+``FUSED = False`` (or SE3_BLOCKS_FUSED=0) keeps the plain torch formulation (the A/B of tools/time_block.py).
 
   DropPathPC      layers/DropPathPC.py:30-46      one keep / drop decision per batch element, scaled by 1 / keep_prob
   SkipConnection  layers/SkipConnection.py        drop_path(x * gamma_) + y, gamma_ initialised to 1e-6
   BatchNormPC     layers/BatchNormPC.py:22-32     BatchNorm1d(momentum=0.2) on the feature rows (the cloud is unused)
   ResNetFormer    layers/ResNetFormer.py:33-88    norm -> conv -> skip; norm -> linear (x2) -> GELU -> linear -> skip
 """
+import os
+
 import torch
 
+from . import ops
 from .layers import PreProcessModule
+
+FUSED = os.environ.get("SE3_BLOCKS_FUSED", "1") != "0"
+
+
+def _fused(t: torch.Tensor) -> bool:
+    return FUSED and t.is_cuda and t.dim() == 2 and t.dtype == torch.float32
 
 
 class DropPathPC(torch.nn.Module):
@@ -39,7 +50,17 @@ class SkipConnection(torch.nn.Module):
         self.gamma_ = torch.nn.Parameter(torch.full((1, p_num_features), float(p_init_gamma)))
 
     def forward(self, p_x, p_y, p_pc):
-        return self.drop_path_(p_x * self.gamma_, p_pc) + p_y
+        if not _fused(p_x) or p_x.shape != p_y.shape:
+            return self.drop_path_(p_x * self.gamma_, p_pc) + p_y
+        gate = ids = None
+        if self.drop_path_.drop_prob_ != 0.0 and self.training:
+            keep = 1.0 - self.drop_path_.drop_prob_
+            # the same draw as DropPathPC: floor(keep + u) per batch element, with the 1 / keep scale folded in
+            gate = torch.floor(keep + torch.rand((int(p_pc.batch_size_),), dtype=p_x.dtype, device=p_x.device)) / keep
+            ids = getattr(p_pc, "batch_ids_considering_frames_", None)
+            if ids is None:
+                ids = p_pc.batch_ids_
+        return ops.SkipDropPath.apply(p_x, p_y, self.gamma_, gate, ids)
 
 
 class NormLayerPC(torch.nn.Module):
@@ -54,7 +75,11 @@ class BatchNormPC(NormLayerPC):
         self.layer_ = torch.nn.BatchNorm1d(p_num_features, momentum=0.2)
 
     def forward(self, p_x, p_pc):
-        return self.layer_(p_x)
+        bn = self.layer_
+        if not (_fused(p_x) and bn.training and bn.track_running_stats and bn.momentum is not None):
+            return bn(p_x)
+        bn.num_batches_tracked.add_(1)
+        return ops.BatchNormTrain.apply(p_x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
 
 
 class Block(PreProcessModule):
@@ -87,6 +112,11 @@ class ResNetFormer(Block):
         x = self.spatial_conv_(p_pc_in=p_pc_in, p_pc_out=p_pc_in, p_in_features=self.norm_1_(p_in_features, p_pc_in),
                                p_neighborhood=p_neighborhood)
         x = self.skip_path_1_(x, p_in_features, p_pc_in)
-        y = self.linear_2_(self.act_func_(self.linear_1_(self.norm_2_(x, p_pc_in))))
+        h = self.norm_2_(x, p_pc_in)
+        if _fused(h):  # bias + GELU in one pass behind a bias-free GEMM
+            h = ops.BiasGelu.apply(torch.nn.functional.linear(h, self.linear_1_.weight), self.linear_1_.bias)
+        else:
+            h = self.act_func_(self.linear_1_(h))
+        y = self.linear_2_(h)
         skip = self.skip_conv_(x) if self.feat_input_size_ != self.feat_output_size_ else x
         return self.skip_path_2_(y, skip, p_pc_in)

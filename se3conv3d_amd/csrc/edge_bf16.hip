@@ -540,7 +540,16 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_stream_bf16_k
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int64_t row_id = (int64_t)A.ctr * 2 + a;
-        if (t24) {
+        if (t24 & 2) {  // diagnostic (SE3_PAIR_STREAM_NOSTORE, wrong results): rows are converted but not stored
+          uint32_t x = 0;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            uint32_t hp, lp;
+            t24_pack2(acc[a][r], acc[a][r + 1], hp, lp);
+            x ^= hp ^ lp;
+          }
+          if (x == 0x12345678u) t_out[0] = x;
+        } else if (t24) {
           char* row = reinterpret_cast<char*>(t_out) + row_id * t24_row_bytes(C);
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
@@ -1054,8 +1063,9 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
       // short ranges lose the point of the stream: below 4 points per workgroup use fewer workgroups
       int64_t wgs = n_range / 4 < resident ? (n_range + 3) / 4 : resident;
       if (wgs < 1) wgs = 1;
+      static const int nostore = getenv("SE3_PAIR_STREAM_NOSTORE") != nullptr ? 2 : 0;
       hipLaunchKernelGGL(edge_t_pair_stream_bf16_kernel, dim3((unsigned)wgs), dim3(128), 0, stream, g, feat, feat_rows,
-                         axes_ext, rho, t_out, (int)item_lo, (int)item_hi, shift, t24 ? 1 : 0);
+                         axes_ext, rho, t_out, (int)item_lo, (int)item_hi, shift, (t24 ? 1 : 0) | nostore);
       return check_launch();
     }
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;

@@ -631,3 +631,140 @@ class FeatBasisProj(torch.autograd.Function):
             feat.shape[1], basis.shape[1], _ptr(g_feat, f32, "g_feat"), _ptr(g_basis, f32, "g_basis"), _stream(dev)),
             "se3_feat_basis_proj_grad")
         return g_basis.to(p_ctx.dtypes[0]), g_feat.to(p_ctx.dtypes[1]), None, None
+
+
+# ------------------------------------------------------------------ row-wise glue of a block (row f-3)
+def _glue_ws(c: int, dev) -> torch.Tensor:
+    return _workspace(_lib.load().se3_glue_workspace_bytes(int(c)), dev)
+
+
+class BatchNormTrain(torch.autograd.Function):
+    """Training-mode ``torch.nn.BatchNorm1d`` on ``[rows, C]`` (layers/BatchNormPC.py:22-32): channel sums in fp64 and
+    a fixed order, running statistics updated in place, 3 launches forward and 3 backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        lib = _lib.load()
+        f32 = torch.float32
+        x2 = _as(x, f32)
+        if x2.dim() != 2:
+            raise ValueError("BatchNormTrain: expected [rows, C] features")
+        rows, c = x2.shape
+        dev = x2.device
+        y = torch.empty_like(x2)
+        mean = torch.empty(c, dtype=f32, device=dev)
+        invstd = torch.empty(c, dtype=f32, device=dev)
+        w = _as(weight, f32) if weight is not None else None
+        b = _as(bias, f32) if bias is not None else None
+        ws = _glue_ws(c, dev)
+        _lib.check(lib.se3_bn_fwd(_ptr(x2, f32, "x"), _ptr(w, f32, "weight", dev), _ptr(b, f32, "bias", dev), rows, c,
+                                  float(eps), float(momentum), _ptr(running_mean, f32, "running_mean", dev),
+                                  _ptr(running_var, f32, "running_var", dev), _ptr(y, f32, "y"), _ptr(mean, f32, "mean"),
+                                  _ptr(invstd, f32, "invstd"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)),
+                   "se3_bn_fwd")
+        ctx.save_for_backward(x2, w if w is not None else torch.empty(0, device=dev), mean, invstd)
+        ctx.has_w = w is not None
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f32 = torch.float32
+        x2, w, mean, invstd = ctx.saved_tensors
+        g2 = _as(g, f32)
+        rows, c = x2.shape
+        dev = x2.device
+        dx = torch.empty_like(x2)
+        dgamma = torch.empty(c, dtype=f32, device=dev)
+        dbeta = torch.empty(c, dtype=f32, device=dev)
+        ws = _glue_ws(c, dev)
+        _lib.check(lib.se3_bn_bwd(_ptr(g2, f32, "dy", dev), _ptr(x2, f32, "x"), _ptr(mean, f32, "mean"),
+                                  _ptr(invstd, f32, "invstd"), _ptr(w if ctx.has_w else None, f32, "weight"), rows, c,
+                                  _ptr(dx, f32, "dx"), _ptr(dgamma, f32, "dgamma"), _ptr(dbeta, f32, "dbeta"),
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)), "se3_bn_bwd")
+        ng = ctx.needs_input_grad
+        return (dx if ng[0] else None, dgamma if ng[1] else None, dbeta if ng[2] else None, None, None, None, None)
+
+
+class SkipDropPath(torch.autograd.Function):
+    """``drop_path(x * gamma_) + y`` of layers/SkipConnection.py with the per-batch gate of layers/DropPathPC.py:30-46
+    (``gate [B]`` already holds keep-mask / keep_prob, ``row_batch [rows]`` int32 maps rows to batch elements; both
+    None: no drop path) -- one launch forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, gate, row_batch):
+        lib = _lib.load()
+        f32, i32 = torch.float32, torch.int32
+        x2, y2 = _as(x, f32), _as(y, f32)
+        if x2.shape != y2.shape or x2.dim() != 2:
+            raise ValueError("SkipDropPath: x and y must be [rows, C] of the same shape")
+        rows, c = x2.shape
+        dev = x2.device
+        ga = _as(gamma, f32).reshape(-1)
+        gt = _as(gate, f32) if gate is not None else None
+        rb = _as(row_batch, i32) if gate is not None else None
+        if gt is not None and rb.shape[0] != rows:
+            raise ValueError("SkipDropPath: one batch id per row expected")
+        out = torch.empty_like(x2)
+        _lib.check(lib.se3_skip_fwd(_ptr(x2, f32, "x"), _ptr(y2, f32, "y", dev), _ptr(ga, f32, "gamma", dev),
+                                    _ptr(gt, f32, "gate", dev), _ptr(rb, i32, "row_batch", dev), rows, c,
+                                    _ptr(out, f32, "out"), _stream(dev)), "se3_skip_fwd")
+        ctx.save_for_backward(x2, ga, gt if gt is not None else torch.empty(0, device=dev),
+                              rb if rb is not None else torch.empty(0, dtype=i32, device=dev))
+        ctx.gated, ctx.gamma_shape = gt is not None, gamma.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f32, i32 = torch.float32, torch.int32
+        x2, ga, gt, rb = ctx.saved_tensors
+        g2 = _as(g, f32)
+        rows, c = x2.shape
+        dev = x2.device
+        ng = ctx.needs_input_grad
+        dx = torch.empty_like(x2) if ng[0] else None
+        dgamma = torch.empty(c, dtype=f32, device=dev)
+        ws = _glue_ws(c, dev)
+        _lib.check(lib.se3_skip_bwd(_ptr(g2, f32, "g", dev), _ptr(x2, f32, "x"), _ptr(ga, f32, "gamma"),
+                                    _ptr(gt if ctx.gated else None, f32, "gate"), _ptr(rb if ctx.gated else None, i32, "row_batch"),
+                                    rows, c, _ptr(dx, f32, "dx"), _ptr(dgamma, f32, "dgamma"), C.c_void_p(ws.data_ptr()),
+                                    ws.numel(), _stream(dev)), "se3_skip_bwd")
+        return dx, (g2 if ng[1] else None), (dgamma.reshape(ctx.gamma_shape) if ng[2] else None), None, None
+
+
+class BiasGelu(torch.autograd.Function):
+    """``GELU(z + bias)`` (exact erf, torch.nn.GELU default) behind a bias-free GEMM: the bias add, the activation and
+    the bias gradient's channel sum in one pass each way (layers/ResNetFormer.py:79-81)."""
+
+    @staticmethod
+    def forward(ctx, z, bias):
+        lib = _lib.load()
+        f32 = torch.float32
+        z2 = _as(z, f32)
+        rows, c = z2.shape
+        dev = z2.device
+        b = _as(bias, f32) if bias is not None else None
+        out = torch.empty_like(z2)
+        _lib.check(lib.se3_affine_act(_ptr(z2, f32, "z"), C.c_void_p(0), _ptr(b, f32, "bias", dev), rows, c, 1,
+                                      _ptr(out, f32, "out"), _stream(dev)), "se3_affine_act")
+        ctx.save_for_backward(z2, b if b is not None else torch.empty(0, device=dev))
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        f32 = torch.float32
+        z2, b = ctx.saved_tensors
+        g2 = _as(g, f32)
+        rows, c = z2.shape
+        dev = z2.device
+        dz = torch.empty_like(z2)
+        db = torch.empty(c, dtype=f32, device=dev)
+        ws = _glue_ws(c, dev)
+        _lib.check(lib.se3_bias_gelu_bwd(_ptr(g2, f32, "g", dev), _ptr(z2, f32, "z"), _ptr(b if ctx.has_b else None, f32, "bias"),
+                                         rows, c, _ptr(dz, f32, "dz"), _ptr(db, f32, "dbias"), C.c_void_p(ws.data_ptr()),
+                                         ws.numel(), _stream(dev)), "se3_bias_gelu_bwd")
+        return dz, (db if (ctx.has_b and ctx.needs_input_grad[1]) else None)
