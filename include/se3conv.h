@@ -284,8 +284,9 @@ int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, i
  *   se3_bn_fwd        training-mode torch.nn.BatchNorm1d: save_mean[c], save_invstd[c] = 1 / sqrt(biased var + eps),
  *                     y = (x - mean) * invstd * weight + bias, running_mean / running_var (may be NULL) updated in place
  *                     with `momentum` and the unbiased variance; weight / bias NULL = 1 / 0
- *   se3_affine_act    y = act(x * scale[c] + shift[c]); scale / shift may be NULL (1 / 0); act 0 = none, 1 = exact-erf
- *                     GELU: batch-norm apply (scale = weight * invstd, shift = bias - mean * scale), bias + GELU
+ *   se3_affine_act    y = act((x - center[c]) * scale[c] + shift[c]); center / scale / shift may be NULL (0 / 1 / 0);
+ *                     act 0 = none, 1 = exact-erf GELU: eval-mode batch norm (center = running mean, scale = weight /
+ *                     sqrt(running var + eps), shift = bias), bias + GELU behind a bias-free GEMM
  *   se3_bn_bwd        dbeta[c] = sum dy, dgamma[c] = sum dy * xhat, dx = gamma * invstd * (dy - dbeta/N - xhat * dgamma/N)
  *                     with xhat = (x - mean) * invstd  (gamma NULL = 1)
  *   se3_skip_fwd      out = x * gamma[c] * gate[row_batch[r]] + y   (gate NULL: no drop path; the caller folds 1/keep
@@ -297,8 +298,8 @@ size_t se3_glue_workspace_bytes(int32_t c);
 int se3_bn_fwd(const float* x, const float* weight, const float* bias, int64_t rows, int32_t c, float eps, float momentum,
                float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
                size_t workspace_bytes, void* stream);
-int se3_affine_act(const float* x, const float* scale, const float* shift, int64_t rows, int32_t c, int32_t act,
-                   float* y, void* stream);
+int se3_affine_act(const float* x, const float* center, const float* scale, const float* shift, int64_t rows, int32_t c,
+                   int32_t act, float* y, void* stream);
 int se3_bn_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
                int64_t rows, int32_t c, float* dx, float* dgamma, float* dbeta, void* workspace,
                size_t workspace_bytes, void* stream);

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libse3conv_hip.so")
+LIB_PATH = os.path.join(_PKG, "lib", f"libse3conv_hip{os.environ.get('SE3_LIB_SUFFIX', '')}.so")  # suffix: variant builds, see build.py
 
 SE3_OK = 0
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
@@ -67,7 +67,7 @@ SIGNATURES = {
     "se3_pca_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_glue_workspace_bytes": (_SZ, [_I32]),
     "se3_bn_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _SZ, _P]),
-    "se3_affine_act": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "se3_affine_act": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _SZ, _P]),
     "se3_skip_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "se3_skip_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),

@@ -21,6 +21,12 @@ from .layers import PreProcessModule
 FUSED = os.environ.get("SE3_BLOCKS_FUSED", "1") != "0"
 
 
+def _num_batches(p_pc) -> int:
+    """Batch count as a host integer: the clouds of this package cache it (no device read-back per call, and none
+    inside a graph capture); a foreign cloud object is asked once per call like the reference does."""
+    return p_pc.num_batches() if hasattr(p_pc, "num_batches") else int(p_pc.batch_size_)
+
+
 def _fused(t: torch.Tensor) -> bool:
     return FUSED and t.is_cuda and t.dim() == 2 and t.dtype == torch.float32
 
@@ -36,7 +42,7 @@ class DropPathPC(torch.nn.Module):
         keep = 1.0 - self.drop_prob_
         # one uniform draw per batch element, keep where keep + u >= 1; rows of a cloud with frames carry the batch id
         # of their point (batch_ids_considering_frames_)
-        gate = torch.floor(keep + torch.rand((int(p_pc.batch_size_),), dtype=p_x.dtype, device=p_x.device))
+        gate = torch.floor(keep + torch.rand((_num_batches(p_pc),), dtype=p_x.dtype, device=p_x.device))
         ids = getattr(p_pc, "batch_ids_considering_frames_", None)
         if ids is None:
             ids = p_pc.batch_ids_
@@ -56,7 +62,7 @@ class SkipConnection(torch.nn.Module):
         if self.drop_path_.drop_prob_ != 0.0 and self.training:
             keep = 1.0 - self.drop_path_.drop_prob_
             # the same draw as DropPathPC: floor(keep + u) per batch element, with the 1 / keep scale folded in
-            gate = torch.floor(keep + torch.rand((int(p_pc.batch_size_),), dtype=p_x.dtype, device=p_x.device)) / keep
+            gate = torch.floor(keep + torch.rand((_num_batches(p_pc),), dtype=p_x.dtype, device=p_x.device)) / keep
             ids = getattr(p_pc, "batch_ids_considering_frames_", None)
             if ids is None:
                 ids = p_pc.batch_ids_

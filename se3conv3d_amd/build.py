@@ -16,8 +16,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
+# SE3_LIB_SUFFIX=_x builds (and _lib.py loads) lib/libse3conv_hip_x.so with its objects under lib/obj_x/: variant and
+# ablation builds (SE3_CXXFLAGS) of tools/*.sh never overwrite the library the tests and the bench ship with
+SUFFIX = os.environ.get("SE3_LIB_SUFFIX", "")
 LIBDIR = os.path.join(PKG, "lib")
-LIB = os.path.join(LIBDIR, "libse3conv_hip.so")
+OBJDIR = os.path.join(LIBDIR, "obj" + SUFFIX) if SUFFIX else LIBDIR
+LIB = os.path.join(LIBDIR, f"libse3conv_hip{SUFFIX}.so")
 SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "edge_bwd_bf16.hip", "gemm.hip", "gemm_bf16.hip", "fused_bf16.hip", "prep.hip", "frames.hip", "glue.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_bf16_body.h"), os.path.join(os.path.dirname(PKG), "include", "se3conv.h")]
 ARCH = "gfx950"
@@ -48,9 +52,9 @@ def _fingerprint() -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    stamp = os.path.join(LIBDIR, "build_flags.sha256")
+    stamp = os.path.join(OBJDIR, "build_flags.sha256")
     fp = _fingerprint()
     try:
         with open(stamp) as fh:
@@ -61,7 +65,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])

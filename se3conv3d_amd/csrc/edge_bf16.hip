@@ -377,12 +377,18 @@ struct ChunkCur {  // wave-uniform position in the chunk stream (SGPRs)
   int ctr, start, end, end2, c0;
 };
 
-__global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_stream_bf16_kernel(
+#ifndef SE3_STREAM_WAVES
+#define SE3_STREAM_WAVES SE3_PAIR_WAVES  // wavefronts per SIMD the register budget is set for (5 needs SE3_STREAM_PHIBUF=1)
+#endif
+#ifndef SE3_STREAM_PHIBUF
+#define SE3_STREAM_PHIBUF 2  // 2: phi fragments double buffered in LDS (18 KB per workgroup, one barrier per chunk, at most
+#endif                       // 8 workgroups per CU); 1: single buffer, two barriers per chunk, 10 KB per workgroup
+__global__ __launch_bounds__(128, SE3_STREAM_WAVES) void edge_t_pair_stream_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int ctr_lo, int ctr_hi, int fnb_shift, int t24) {
   constexpr int C = 64;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
+  __shared__ __attribute__((aligned(16))) uint32_t lds_phi[SE3_STREAM_PHIBUF][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int kcol = lane & 31, h = lane >> 5;
@@ -582,7 +588,8 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_pair_stream_bf16_k
     A = B, B = Cc;
     advance(Cc);
     q_a = q_b;
-    buf ^= 1;
+    if (SE3_STREAM_PHIBUF == 2) buf ^= 1;
+    else __syncthreads();  // single buffer: every fragment of this chunk has been read before the next chunk's are written
   }
 }
 
@@ -1042,10 +1049,11 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
     const int64_t n_range = item_hi - item_lo;
     if (n_range <= 0) return SE3_OK;
-    // chunk-stream form: two frames per point, 64 channels (the headline shape); SE3_PAIR_STREAM=0 turns it off
+    // chunk-stream form (opt-in, SE3_PAIR_STREAM=1: measured equal to one workgroup per point):
+    // two frames per point, 64 channels
     static const bool stream_on = [] {
       const char* e = getenv("SE3_PAIR_STREAM");
-      return e == nullptr || atoi(e) != 0;
+      return e != nullptr && atoi(e) != 0;
     }();
     if (stream_on && two && g.f_ctr == 2 && channels == 64 && g.n_ctr < (1ll << 30)) {
       static int n_cu = 0;
@@ -1057,7 +1065,7 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
       }
       static const int per_cu = [] {
         const char* e = getenv("SE3_PAIR_STREAM_WGS");
-        return e ? atoi(e) : 2 * SE3_PAIR_WAVES;  // resident 128-thread workgroups per CU at SE3_PAIR_WAVES waves / SIMD
+        return e ? atoi(e) : 2 * SE3_STREAM_WAVES;  // resident 128-thread workgroups per CU at SE3_STREAM_WAVES waves / SIMD
       }();
       const int64_t resident = (int64_t)n_cu * per_cu;
       // short ranges lose the point of the stream: below 4 points per workgroup use fewer workgroups

@@ -3,7 +3,7 @@
 // layers/SkipConnection.py, layers/DropPathPC.py:30-46) as one kernel per step:
 //   se3_bn_fwd          training-mode BatchNorm1d in 3 launches: channel sums (fp64, fixed order) -> mean / invstd /
 //                       running statistics -> y = x * scale + shift
-//   se3_affine_act      y = act(x * scale[c] + shift[c])           eval-mode BN apply (act = none), bias + GELU (scale = NULL)
+//   se3_affine_act      y = act((x - center[c]) * scale[c] + shift[c])   eval-mode BN apply (act = none), bias + GELU
 //   se3_bn_bwd_*        the two reductions and the element-wise pass of the batch-norm gradient
 //   se3_skip_fwd/bwd    out = x * gamma[c] * gate[batch(row)] + y   SkipConnection + DropPathPC (frame-aware batch ids)
 //   se3_bias_gelu_bwd   dz = g * GELU'(z + b), db = sum dz
@@ -108,10 +108,8 @@ __global__ void reduce_channel_partials_kernel(const double* __restrict__ partia
 // batch-norm statistics from the block partials (fp64 all the way to the variance): mean, invstd, the affine map
 // y = x * scale + shift, and the running statistics of torch.nn.BatchNorm1d (unbiased variance, momentum m)
 __global__ void bn_finalize_kernel(const double* __restrict__ partials, int n_blocks, int c, int64_t rows,
-                                   const float* __restrict__ weight, const float* __restrict__ bias, float eps,
-                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
+                                   const float* __restrict__ weight, float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   double s = 0.0, ss = 0.0;
@@ -121,29 +119,32 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partials, int n_bl
   double var = rows > 0 ? ss / n - mu * mu : 0.0;
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
-  const float w = weight ? weight[ch] : 1.0f, b0 = bias ? bias[ch] : 0.0f;
   mean[ch] = (float)mu, invstd[ch] = is;
-  scale[ch] = w * is, shift[ch] = b0 - (float)mu * w * is;
+  scale[ch] = (weight ? weight[ch] : 1.0f) * is;
   if (running_mean) running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * (float)mu;
   if (running_var) running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
 }
 
 template <int VEC>
 __global__ __launch_bounds__(kGlueThreads) void affine_act_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ center,
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, int64_t rows, int c,
                                                                    int act, float* __restrict__ y) {
+  // y = act((x - center) * scale + shift): the centred form keeps batch norm exact where the variance is tiny next to
+  // the mean (x * scale + (shift - mean * scale) cancels there)
   const RowWalk w = row_walk<VEC>(c);
   if (w.row0 < 0) return;
-  float sc[VEC], sh[VEC];
+  float ce[VEC], sc[VEC], sh[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) sc[i] = scale ? scale[w.col + i] : 1.0f, sh[i] = shift ? shift[w.col + i] : 0.0f;
+  for (int i = 0; i < VEC; ++i)
+    ce[i] = center ? center[w.col + i] : 0.0f, sc[i] = scale ? scale[w.col + i] : 1.0f, sh[i] = shift ? shift[w.col + i] : 0.0f;
   for (int64_t r = (int64_t)blockIdx.x * w.rpb + w.row0; r < rows; r += (int64_t)gridDim.x * w.rpb) {
     float v[VEC];
     load_vec<VEC>(x + r * c + w.col, v);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float t = fmaf(v[i], sc[i], sh[i]);
+      const float t = fmaf(v[i] - ce[i], sc[i], sh[i]);
       v[i] = act == 1 ? gelu_exact(t) : t;
     }
     store_vec<VEC>(y + r * c + w.col, v);
@@ -331,26 +332,25 @@ extern "C" int se3_bn_fwd(const float* x, const float* weight, const float* bias
   hipStream_t stream = (hipStream_t)stream_;
   const int vec = glue_vec(c), blocks = glue_blocks(rows, c, vec);
   double* partials = (double*)workspace;
-  // scale / shift of the apply pass live behind the partial sums
+  // the scale of the apply pass lives behind the partial sums
   float* scale = (float*)((char*)workspace + (size_t)2 * kGlueMaxBlocks * c * sizeof(double));
-  float* shift = scale + c;
   SE3_GLUE_DISPATCH(bn_stats_kernel, x, rows, (int)c, partials);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, (const double*)partials, blocks,
-                     (int)c, rows, weight, bias, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale,
-                     shift);
-  if (rows > 0) SE3_GLUE_DISPATCH(affine_act_kernel, x, (const float*)scale, (const float*)shift, rows, (int)c, 0, y);
+                     (int)c, rows, weight, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale);
+  if (rows > 0)
+    SE3_GLUE_DISPATCH(affine_act_kernel, x, (const float*)save_mean, (const float*)scale, bias, rows, (int)c, 0, y);
   return check_launch();
 }
 
-extern "C" int se3_affine_act(const float* x, const float* scale, const float* shift, int64_t rows, int32_t c,
-                              int32_t act, float* y, void* stream_) {
+extern "C" int se3_affine_act(const float* x, const float* center, const float* scale, const float* shift, int64_t rows,
+                              int32_t c, int32_t act, float* y, void* stream_) {
   if (!glue_shape_ok(rows, c) || (act != 0 && act != 1)) return SE3_ERR_INVALID_ARGUMENT;
   if (c > kGlueThreads && c % 4 != 0) return SE3_ERR_UNSUPPORTED;
   if (rows == 0) return SE3_OK;
   if (!x || !y) return SE3_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
   const int vec = glue_vec(c), blocks = glue_blocks(rows, c, vec);
-  SE3_GLUE_DISPATCH(affine_act_kernel, x, scale, shift, rows, (int)c, (int)act, y);
+  SE3_GLUE_DISPATCH(affine_act_kernel, x, center, scale, shift, rows, (int)c, (int)act, y);
   return check_launch();
 }
 

@@ -747,7 +747,7 @@ class BiasGelu(torch.autograd.Function):
         dev = z2.device
         b = _as(bias, f32) if bias is not None else None
         out = torch.empty_like(z2)
-        _lib.check(lib.se3_affine_act(_ptr(z2, f32, "z"), C.c_void_p(0), _ptr(b, f32, "bias", dev), rows, c, 1,
+        _lib.check(lib.se3_affine_act(_ptr(z2, f32, "z"), C.c_void_p(0), C.c_void_p(0), _ptr(b, f32, "bias", dev), rows, c, 1,
                                       _ptr(out, f32, "out"), _stream(dev)), "se3_affine_act")
         ctx.save_for_backward(z2, b if b is not None else torch.empty(0, device=dev))
         ctx.has_b = b is not None

@@ -1,0 +1,186 @@
+"""GPU: the BACKWARD pass at BASELINE.json's full sizes against the oracle (the forward slices live in
+test_gpu_parity.py).  The oracle cannot run 2 M edges, but every gradient of the operator restricts exactly:
+
+  * dX of a set P of source points only depends on the edges that leave P: the oracle runs on the sub-problem
+    (sources P, samples = every point with an edge from P, those edges) and must reproduce rows P of the full dX;
+  * dA / dbeta / dW are sums over output rows: with grad_out zeroed outside a set R of samples they equal the
+    gradients of the sub-problem (samples R, sources = every point with an edge into R) -- the GPU still walks the
+    whole cloud (every tile, every partial sum), the oracle only the sub-problem;
+  * at full size the three parameter gradients are tied to the forward through directional derivatives
+    (central differences of <out, g> along a random direction, fp64 dot products).
+
+Headline (N=65 536, k~31, F=2, C=64), ScanNet-like (150 000 points, F=1, fixed axis; 3->64 and 64->64) and the
+DFaust F=2 batch (32 bodies x 2 200 points, PCA frames, C_in=1 -> 32: small enough for the oracle as a whole).
+Both arithmetic modes; tolerances as in test_gpu_parity.py (north star 1e-4)."""
+import pytest
+import torch
+
+from conftest import canon_edges, rel_err
+from oracle import se3conv_oracle as O
+from se3conv3d_amd.workloads import radius_for_degree
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOLS = {"fp32": 2e-5, "bf16x3": 5e-5}
+
+
+@pytest.fixture(scope="module", params=["bf16x3", "fp32"])
+def amd(built_library, request):
+    import se3conv3d_amd
+
+    se3conv3d_amd.set_precision(request.param)
+    yield se3conv3d_amd
+    se3conv3d_amd.set_precision("bf16x3")
+
+
+def tol(amd):
+    return TOLS[amd.get_precision()]
+
+
+def make_layer(amd, pc, r, c_in, c_out, seed):
+    torch.manual_seed(seed)
+    nbh = amd.pc.BQNeighborhood(pc, pc, r)
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c_in, c_out).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r)
+    conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / nbh.neighbors_.shape[0])
+    with torch.no_grad():
+        conv.proj_biases_.uniform_(-0.5, 0.5)
+    f = pc.n_frames_
+    x = torch.randn(pc.pts_.shape[0] * f, c_in, device=DEV)
+    g = torch.randn(pc.pts_.shape[0] * f, c_out, device=DEV)
+    return nbh, conv, x, g
+
+
+def gpu_backward(conv, pc, nbh, x, g):
+    for p in conv.parameters():
+        p.grad = None
+    xg = x.clone().requires_grad_(True)
+    out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=xg, p_neighborhood=nbh)
+    out.backward(g)
+    return out.detach(), xg.grad, conv.proj_axes_.grad.clone(), conv.proj_biases_.grad.clone(), conv.conv_weights_.grad.clone()
+
+
+def rows_of(points: torch.Tensor, f: int) -> torch.Tensor:
+    return (points[:, None] * f + torch.arange(f, device=points.device)[None, :]).reshape(-1)
+
+
+def oracle_subproblem(pc, conv, nb_sub, samples, sources, x_rows, g_rows):
+    """Oracle forward+backward on the sub-graph: `nb_sub` [E,2] in ORIGINAL ids sorted by sample; samples / sources are
+    the sorted unique ids that occur in it."""
+    f = pc.n_frames_
+    s_map = torch.full((pc.pts_.shape[0],), -1, dtype=torch.int64)
+    p_map = torch.full((pc.pts_.shape[0],), -1, dtype=torch.int64)
+    s_map[samples] = torch.arange(samples.shape[0])
+    p_map[sources] = torch.arange(sources.shape[0])
+    nb = torch.stack((s_map[nb_sub[:, 0]], p_map[nb_sub[:, 1]]), 1)
+    assert int(nb.min()) >= 0 and bool((nb[1:, 0] >= nb[:-1, 0]).all())
+    pts, fr = pc.pts_.cpu(), pc.local_frames_.cpu()
+    cpu = lambda t: t.detach().cpu()
+    return O.conv_forward_backward(pts[sources], pts[samples], fr[sources], fr[samples], nb, x_rows, cpu(conv.proj_axes_),
+                                   cpu(conv.proj_biases_), cpu(conv.conv_weights_), cpu(conv.norm_neigh_dist_),
+                                   cpu(conv.norm_num_neighs_), g_rows)
+
+
+def check_dx_slice(amd, pc, nbh, conv, x, g, dx_full, p0, count):
+    f = pc.n_frames_
+    nb = nbh.neighbors_.cpu()
+    m = (nb[:, 1] >= p0) & (nb[:, 1] < p0 + count)
+    nb_sub = nb[m]
+    sources = torch.arange(p0, p0 + count)
+    samples = torch.unique(nb_sub[:, 0])
+    ref = oracle_subproblem(pc, conv, nb_sub, samples, sources, x.cpu()[rows_of(sources, f)], g.cpu()[rows_of(samples, f)])
+    got = dx_full[rows_of(sources.to(DEV), f)]
+    assert rel_err(got, ref[1]) < tol(amd), ("dX slice", p0, rel_err(got, ref[1]))
+
+
+def check_param_grads_masked(amd, pc, nbh, conv, x, g, samples):
+    """Full-size backward with grad_out zeroed outside `samples` == the oracle on the sub-problem of those samples."""
+    f = pc.n_frames_
+    samples = torch.sort(samples.cpu()).values
+    g_m = torch.zeros_like(g)
+    rows = rows_of(samples.to(DEV), f)
+    g_m[rows] = g[rows]
+    _, _, da, db, dw = gpu_backward(conv, pc, nbh, x, g_m)
+    nb = nbh.neighbors_.cpu()
+    keep = torch.zeros(pc.pts_.shape[0], dtype=torch.bool)
+    keep[samples] = True
+    nb_sub = nb[keep[nb[:, 0]]]
+    sources = torch.unique(nb_sub[:, 1])
+    ref = oracle_subproblem(pc, conv, nb_sub, samples, sources, x.cpu()[rows_of(sources, f)], g.cpu()[rows_of(samples, f)])
+    for name, u, v in (("dA", da, ref[2]), ("dbeta", db, ref[3]), ("dW", dw, ref[4])):
+        assert rel_err(u, v) < tol(amd), (name, rel_err(u, v))
+
+
+def check_directional(amd, pc, nbh, conv, x, g, grads, eps=2e-2, tol_fd=4e-3):
+    """<dP, delta> against the central difference of <out, g> along delta, for A, beta and W at full size."""
+    _, _, da, db, dw = grads
+    gd = g.double()
+    for name, p, dp in (("A", conv.proj_axes_, da), ("beta", conv.proj_biases_, db), ("W", conv.conv_weights_, dw)):
+        torch.manual_seed(5)
+        delta = torch.randn_like(p) * p.detach().abs().mean().clamp_min(1e-3)
+        vals = []
+        with torch.no_grad():
+            for sgn in (1.0, -1.0):
+                p.add_(sgn * eps * delta)
+                o = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
+                vals.append(float((o.double() * gd).sum()))
+                p.sub_(sgn * eps * delta)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float((dp.double() * delta.double()).sum())
+        assert abs(fd - an) <= tol_fd * max(abs(fd), abs(an), 1e-6), (name, fd, an)
+
+
+def full_checks(amd, pc, r, c_in, c_out, seed):
+    nbh, conv, x, g = make_layer(amd, pc, r, c_in, c_out, seed)
+    n = pc.pts_.shape[0]
+    grads = gpu_backward(conv, pc, nbh, x, g)
+    assert all(bool(torch.isfinite(t).all()) for t in grads)
+    for p0 in (0, n // 2 + 17, n - 48):          # first, interior and last source rows
+        check_dx_slice(amd, pc, nbh, conv, x, g, grads[1], p0, 48)
+    torch.manual_seed(seed + 1)
+    check_param_grads_masked(amd, pc, nbh, conv, x, g, torch.randperm(n)[:96])          # samples spread over the cloud
+    check_param_grads_masked(amd, pc, nbh, conv, x, g, torch.arange(n - 40, n))         # the last rows
+    check_directional(amd, pc, nbh, conv, x, g, grads)
+
+
+def test_headline_backward_against_oracle(amd):
+    torch.manual_seed(0)
+    n, f = 65536, 2
+    pc = amd.pc.PointcloudRotEquiv(torch.rand(n, 3, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV),
+                                   {"pca": False, "n_frames": f, "fixed_axis": False})
+    full_checks(amd, pc, radius_for_degree(n, 32), 64, 64, seed=10)
+
+
+@pytest.mark.parametrize("c_in,c_out", [(3, 64), (64, 64)])
+def test_scannet150k_backward_against_oracle(amd, c_in, c_out):
+    torch.manual_seed(1)
+    n = 150000
+    pts = torch.rand(n, 3, device=DEV) * torch.tensor([8.0, 6.0, 2.5], device=DEV)
+    pc = amd.pc.PointcloudRotEquiv(pts, torch.zeros(n, dtype=torch.int32, device=DEV),
+                                   {"pca": False, "n_frames": 1, "fixed_axis": 2})
+    full_checks(amd, pc, 0.12, c_in, c_out, seed=20 + c_in)
+
+
+def test_dfaust_f2_batch_against_oracle(amd):
+    """configs[1]: 32 bodies x 2 200 points (4096 sampled -> 0.04 grid), F = 2 PCA frames from 16-NN, the network's
+    first convolution C_in = 1 -> 32 (tasks/SemSeg/confs/dfaust/dfaust_I_rot_pca_2F.yaml:4,17,37-38) -- whole batch
+    against the oracle: edge sets bit-exact, output and every gradient within tolerance."""
+    torch.manual_seed(3)
+    bodies, n_per, f = 32, 2200, 2
+    n = bodies * n_per
+    pts = torch.rand(n, 3, device=DEV)
+    bid = torch.arange(bodies, dtype=torch.int32, device=DEV).repeat_interleave(n_per)
+    pc = amd.pc.PointcloudRotEquiv(pts, bid, {"pca": True, "n_frames": f, "fixed_axis": False, "neigh_method": "knn",
+                                              "neigh_kwargs": {"neigh_k": 16}})
+    assert pc.local_frames_.shape == (n, f, 9)
+    r = radius_for_degree(n_per, 14)
+    nbh, conv, x, g = make_layer(amd, pc, r, 1, 32, seed=30)
+    nb_ref, ends_ref = O.ball_query(pts.cpu(), pts.cpu(), bid.cpu(), bid.cpu(), r)
+    assert torch.equal(nbh.start_ids_.cpu(), ends_ref) and torch.equal(canon_edges(nbh.neighbors_), canon_edges(nb_ref))
+    got = gpu_backward(conv, pc, nbh, x, g)
+    cpu = lambda t: t.detach().cpu()
+    ref = O.conv_forward_backward(pts.cpu(), pts.cpu(), pc.local_frames_.cpu(), pc.local_frames_.cpu(), nb_ref, x.cpu(),
+                                  cpu(conv.proj_axes_), cpu(conv.proj_biases_), cpu(conv.conv_weights_),
+                                  cpu(conv.norm_neigh_dist_), cpu(conv.norm_num_neighs_), g.cpu())
+    for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), got, ref):
+        assert rel_err(u, v) < tol(amd), (name, rel_err(u, v))

@@ -9,6 +9,7 @@ re-running a slice of the parity suite in a child process with the variable set:
   SE3_NO_T24=1      T and U as packed hi/lo words instead of the 3-byte row format (what C < 64 always uses)
   SE3_OVERLAP=1     backward branches on two streams at every size (default: 4 k - 32 k output rows only)
   SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
+  SE3_PAIR_STREAM=1 wave-pair edge kernel as a chunk stream over edge-balanced point ranges (edge_t_pair_stream_bf16_kernel)
 
 One child at a time; each child is an ordinary `pytest -m gpu` run over the golden / random-shape / headline
 tests of tests/test_gpu_parity.py.
@@ -25,7 +26,7 @@ SLICE = "golden or random_shapes or headline_subset or features_only or empty_ro
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("var", ["SE3_BWD_MERGE", "SE3_NO_PAIR", "SE3CONV_FUSED", "SE3_PG_SINGLE", "SE3_PAIR_PERSIST=64",
-                                 "SE3_NO_T24", "SE3_OVERLAP", "SE3_BWD_BRANCH_ORDER"])
+                                 "SE3_NO_T24", "SE3_OVERLAP", "SE3_BWD_BRANCH_ORDER", "SE3_PAIR_STREAM"])
 def test_variant_passes_parity_slice(var):
     env = dict(os.environ)
     name, _, value = var.partition("=")
