@@ -93,27 +93,52 @@ __global__ __launch_bounds__(kGlueThreads) void bn_stats_kernel(const float* __r
   block_channel_sums<VEC, 2>(acc, w, c, partials);
 }
 
-// out[q][ch] = sum over blocks of partials[q][block][ch]  (fixed order)
-__global__ void reduce_channel_partials_kernel(const double* __restrict__ partials, int n_blocks, int c, int nq,
-                                               float* __restrict__ out0, float* __restrict__ out1) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq * c) return;
-  const int q = i / c, ch = i - q * c;
-  double s = 0.0;
-  for (int b = 0; b < n_blocks; ++b) s += partials[((int64_t)q * n_blocks + b) * c + ch];
-  float* out = q == 0 ? out0 : out1;
-  if (out) out[ch] = (float)s;
+// Second stage of the channel sums: one 256-thread block per channel, thread t adds the partials of blocks t, t + 256, ...
+// and the block folds the 256 values in a fixed tree (a single thread walking all partials is a chain of ~1000
+// dependent-latency loads: 0.1 ms per reduction at 1024 partial blocks).
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
 }
 
-// batch-norm statistics from the block partials (fp64 all the way to the variance): mean, invstd, the affine map
-// y = x * scale + shift, and the running statistics of torch.nn.BatchNorm1d (unbiased variance, momentum m)
-__global__ void bn_finalize_kernel(const double* __restrict__ partials, int n_blocks, int c, int64_t rows,
-                                   const float* __restrict__ weight, float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+// out[q][ch] = sum over blocks of partials[q][block][ch]
+__global__ __launch_bounds__(256) void reduce_channel_partials_kernel(const double* __restrict__ partials, int n_blocks,
+                                                                       int c, int nq, float* __restrict__ out0,
+                                                                       float* __restrict__ out1) {
+  __shared__ double red[256];
+  const int ch = blockIdx.x;
+  for (int q = 0; q < nq; ++q) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) s += partials[((int64_t)q * n_blocks + b) * c + ch];
+    s = block_sum_256(s, red);
+    float* out = q == 0 ? out0 : out1;
+    if (threadIdx.x == 0 && out) out[ch] = (float)s;
+  }
+}
+
+// batch-norm statistics from the block partials (fp64 all the way to the variance): mean, invstd, the scale of the
+// apply pass, and the running statistics of torch.nn.BatchNorm1d (unbiased variance, momentum m); block = channel
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, int n_blocks, int c,
+                                                           int64_t rows, const float* __restrict__ weight, float eps,
+                                                           float momentum, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* __restrict__ scale) {
+  __shared__ double red[256];
+  const int ch = blockIdx.x;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < n_blocks; ++b) s += partials[(int64_t)b * c + ch], ss += partials[((int64_t)n_blocks + b) * c + ch];
+  for (int b = threadIdx.x; b < n_blocks; b += 256)
+    s += partials[(int64_t)b * c + ch], ss += partials[((int64_t)n_blocks + b) * c + ch];
+  s = block_sum_256(s, red);
+  ss = block_sum_256(ss, red);
+  if (threadIdx.x != 0) return;
   const double n = (double)rows;
   const double mu = rows > 0 ? s / n : 0.0;
   double var = rows > 0 ? ss / n - mu * mu : 0.0;
@@ -301,8 +326,7 @@ inline bool glue_shape_ok(int64_t rows, int c) { return rows >= 0 && c >= 1 && c
 inline int glue_vec(int c) { return (c % 4 == 0 && c / 4 <= kGlueThreads) ? 4 : 1; }
 inline int finish_channel_sums(double* partials, int blocks, int c, int nq, float* out0, float* out1,
                                hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_channel_partials_kernel, dim3((nq * c + 255) / 256), dim3(256), 0, stream, partials, blocks, c,
-                     nq, out0, out1);
+  hipLaunchKernelGGL(reduce_channel_partials_kernel, dim3(c), dim3(256), 0, stream, partials, blocks, c, nq, out0, out1);
   return check_launch();
 }
 
@@ -335,7 +359,7 @@ extern "C" int se3_bn_fwd(const float* x, const float* weight, const float* bias
   // the scale of the apply pass lives behind the partial sums
   float* scale = (float*)((char*)workspace + (size_t)2 * kGlueMaxBlocks * c * sizeof(double));
   SE3_GLUE_DISPATCH(bn_stats_kernel, x, rows, (int)c, partials);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, stream, (const double*)partials, blocks,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, stream, (const double*)partials, blocks,
                      (int)c, rows, weight, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale);
   if (rows > 0)
     SE3_GLUE_DISPATCH(affine_act_kernel, x, (const float*)save_mean, (const float*)scale, bias, rows, (int)c, 0, y);
@@ -374,10 +398,10 @@ extern "C" int se3_bn_bwd(const float* dy, const float* x, const float* mean, co
 
 extern "C" int se3_skip_fwd(const float* x, const float* y, const float* gamma, const float* gate,
                             const int32_t* row_batch, int64_t rows, int32_t c, float* out, void* stream_) {
-  if (!glue_shape_ok(rows, c) || !gamma || (gate && !row_batch)) return SE3_ERR_INVALID_ARGUMENT;
+  if (!glue_shape_ok(rows, c)) return SE3_ERR_INVALID_ARGUMENT;
   if (c > kGlueThreads && c % 4 != 0) return SE3_ERR_UNSUPPORTED;
   if (rows == 0) return SE3_OK;
-  if (!x || !y || !out) return SE3_ERR_INVALID_ARGUMENT;
+  if (!x || !y || !out || !gamma || (gate && !row_batch)) return SE3_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
   const int vec = glue_vec(c), blocks = glue_blocks(rows, c, vec);
   SE3_GLUE_DISPATCH(skip_fwd_kernel, x, y, gamma, gate, row_batch, rows, (int)c, out);
@@ -387,7 +411,7 @@ extern "C" int se3_skip_fwd(const float* x, const float* y, const float* gamma, 
 extern "C" int se3_skip_bwd(const float* g, const float* x, const float* gamma, const float* gate,
                             const int32_t* row_batch, int64_t rows, int32_t c, float* dx, float* dgamma, void* workspace,
                             size_t workspace_bytes, void* stream_) {
-  if (!glue_shape_ok(rows, c) || !gamma || !dgamma || !workspace || (gate && !row_batch) || (rows > 0 && (!g || !x)))
+  if (!glue_shape_ok(rows, c) || !gamma || !dgamma || !workspace || (rows > 0 && (!g || !x || (gate && !row_batch))))
     return SE3_ERR_INVALID_ARGUMENT;
   if (c > kGlueThreads && c % 4 != 0) return SE3_ERR_UNSUPPORTED;
   if (workspace_bytes < se3_glue_workspace_bytes(c)) return SE3_ERR_WORKSPACE;
