@@ -167,6 +167,18 @@ int se3_ball_query_store(const float* pts_dst, const int32_t* batch_dst, float r
                          size_t workspace_bytes, const int32_t* ends, int64_t n_edges,
                          int32_t* neighbors, void* stream);
 
+/* The same query in ONE call without a host round trip (what lets neighbourhood builds be captured into a HIP graph and
+ * keeps the host running ahead in eager mode; the reference synchronises four times per query, ball_query.cu:46,49,50 +
+ * store_neighbors.cu:264): the caller passes an edge buffer of `capacity` rows, e.g. sized from the previous step.
+ *   info [2] int32 (device): info[0] = true number of edges E, info[1] = 1 when E > capacity.
+ * On overflow the list is truncated: `ends` are clamped to `capacity`, so consumers never read past the buffer, the
+ * first `capacity` edges (sample-major order) are present, and the caller reruns with a larger buffer once it has seen
+ * the flag.  Rows [E, capacity) of `neighbors` are left untouched. */
+int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                           const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells, float radius,
+                           int64_t n_src, int64_t n_dst, void* workspace, size_t workspace_bytes, int64_t capacity,
+                           int32_t* neighbors, int32_t* ends, int32_t* info, void* stream);
+
 /* Source-major (transposed) copy of an edge list, used by the backward pass in place of the
  * reference's global float atomics on the feature gradient (feat_basis_proj_grads.cu:126,140):
  * t_samples[E] = sample id of every edge, grouped by source point (ascending sample inside a

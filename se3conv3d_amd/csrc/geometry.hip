@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
                                                               const int2* __restrict__ ranges, int64_t n_dst,
                                                               int32_t* __restrict__ counts,
                                                               const int32_t* __restrict__ ends,
-                                                              int32_t* __restrict__ neighbors) {
+                                                              int32_t* __restrict__ neighbors, int limit) {
+  // limit: rows of `neighbors` (bounded variant: slots at or beyond it are dropped; INT_MAX otherwise)
   const int lane = threadIdx.x & 63;
   const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n_dst) return;
@@ -141,8 +142,10 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
     const unsigned long long mask = __ballot(hit);
     if (STORE && hit) {
       const int slot = base + found + __popcll(mask & ((1ull << lane) - 1ull));
-      neighbors[(int64_t)slot * 2] = (int32_t)s;
-      neighbors[(int64_t)slot * 2 + 1] = id;
+      if (slot < limit) {
+        neighbors[(int64_t)slot * 2] = (int32_t)s;
+        neighbors[(int64_t)slot * 2 + 1] = id;
+      }
     }
     found += __popcll(mask);
   }
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(256) void scan_all_kernel(const float* __restrict__
                                                        float4* __restrict__ recs, const float* __restrict__ pts_dst,
                                                        const int32_t* __restrict__ batch_dst, float inv_r, int n_src,
                                                        int64_t n_dst, int32_t* __restrict__ counts,
-                                                       const int32_t* __restrict__ ends, int32_t* __restrict__ neighbors) {
+                                                       const int32_t* __restrict__ ends, int32_t* __restrict__ neighbors,
+                                                       int limit) {
   const int lane = threadIdx.x & 63;
   if (!STORE) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -189,12 +193,24 @@ __global__ __launch_bounds__(256) void scan_all_kernel(const float* __restrict__
     const unsigned long long mask = __ballot(hit);
     if (STORE && hit) {
       const int slot = base + found + __popcll(mask & ((1ull << lane) - 1ull));
-      neighbors[(int64_t)slot * 2] = (int32_t)s;
-      neighbors[(int64_t)slot * 2 + 1] = id;
+      if (slot < limit) {
+        neighbors[(int64_t)slot * 2] = (int32_t)s;
+        neighbors[(int64_t)slot * 2 + 1] = id;
+      }
     }
     found += __popcll(mask);
   }
   if (!STORE && lane == 0) counts[s] = found;
+}
+
+// Bounded variant: info[0] = true edge total, info[1] = 1 when it exceeds the caller's buffer; the offsets are clamped
+// to the buffer so that no consumer ever walks past it.
+__global__ void clamp_ends_kernel(int32_t* __restrict__ ends, int64_t n_dst, int capacity, int32_t* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_dst) return;
+  const int e = ends[i];  // every thread touches its own element only
+  if (i == n_dst - 1) info[0] = e, info[1] = e > capacity ? 1 : 0;
+  if (e > capacity) ends[i] = capacity;
 }
 
 // Per-batch bounding boxes (BallQuery.py:35-36 / BoundingBox.py:17-18 use torch_scatter's scatter_min/max).
@@ -557,7 +573,7 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
     const int64_t blocks = std::max((n_dst + 3) / 4, (n_src + 255) / 256);
     hipLaunchKernelGGL(scan_all_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, pts_src, batch_src,
                        (float4*)(ws + l.spts), pts_dst, batch_dst, 1.0f / radius, (int)n_src, n_dst, counts,
-                       (const int32_t*)nullptr, (int32_t*)nullptr);
+                       (const int32_t*)nullptr, (int32_t*)nullptr, 0);
     if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
       return SE3_ERR_LAUNCH;
     return check_launch();
@@ -584,10 +600,29 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
   hipLaunchKernelGGL(find_ranges_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
                      aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges);
   hipLaunchKernelGGL(scan_candidates_kernel<false>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, stream, pts_dst,
-                     1.0f / radius, spts, ranges, n_dst, counts, (const int32_t*)nullptr, (int32_t*)nullptr);
+                     1.0f / radius, spts, ranges, n_dst, counts, (const int32_t*)nullptr, (int32_t*)nullptr, 0);
   temp_bytes = l.temp_bytes;
   if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
     return SE3_ERR_LAUNCH;
+  return check_launch();
+}
+
+static int ball_query_store_impl(const float* pts_dst, const int32_t* batch_dst, float radius, int64_t n_src,
+                                 int64_t n_dst, const void* workspace, size_t workspace_bytes, const int32_t* ends,
+                                 int32_t* neighbors, int limit, void* stream) {
+  const BqLayout l = bq_layout(n_src, n_dst);
+  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+  const char* ws = (const char*)workspace;
+  if (n_src <= kBqScanAllMax) {  // the count phase took the all-pairs path (and left the source records)
+    if (!batch_dst) return SE3_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(scan_all_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, (const int32_t*)nullptr, (float4*)(ws + l.spts), pts_dst, batch_dst,
+                       1.0f / radius, (int)n_src, n_dst, (int32_t*)nullptr, ends, neighbors, limit);
+    return check_launch();
+  }
+  hipLaunchKernelGGL(scan_candidates_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
+                     (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit);
   return check_launch();
 }
 
@@ -597,20 +632,25 @@ extern "C" int se3_ball_query_store(const float* pts_dst, const int32_t* batch_d
   if (n_src < 0 || n_dst < 0 || n_edges < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_dst == 0 || n_edges == 0) return SE3_OK;
   if (!pts_dst || !workspace || !ends || !neighbors) return SE3_ERR_INVALID_ARGUMENT;
-  const BqLayout l = bq_layout(n_src, n_dst);
-  if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
-  const char* ws = (const char*)workspace;
-  if (n_src <= kBqScanAllMax) {  // the count phase took the all-pairs path (and left the source records)
-    if (!batch_dst) return SE3_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(scan_all_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)nullptr, (const int32_t*)nullptr, (float4*)(ws + l.spts), pts_dst, batch_dst,
-                       1.0f / radius, (int)n_src, n_dst, (int32_t*)nullptr, ends, neighbors);
-    return check_launch();
-  }
-  hipLaunchKernelGGL(scan_candidates_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
-                     (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors);
-  return check_launch();
+  return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes, ends, neighbors,
+                               0x7fffffff, stream);
+}
+
+extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                      const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                                      float radius, int64_t n_src, int64_t n_dst, void* workspace, size_t workspace_bytes,
+                                      int64_t capacity, int32_t* neighbors, int32_t* ends, int32_t* info, void* stream) {
+  if (capacity < 0 || capacity >= (1ll << 31) || !info) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_dst == 0) return hipMemsetAsync(info, 0, 2 * sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  if (capacity > 0 && !neighbors) return SE3_ERR_INVALID_ARGUMENT;
+  if (int rc = se3_ball_query_count(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
+                                    workspace, workspace_bytes, ends, stream))
+    return rc;
+  hipLaunchKernelGGL(clamp_ends_kernel, dim3(blocks_for(n_dst)), dim3(256), 0, (hipStream_t)stream, ends, n_dst,
+                     (int)capacity, info);
+  if (capacity == 0) return check_launch();
+  return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes, ends, neighbors,
+                               (int)capacity, stream);
 }
 
 namespace {

@@ -76,8 +76,9 @@ class IConvLayer(PreProcessModule, ABC):
                     mean_len = torch.mean(torch.sqrt(torch.sum(diff ** 2, -1))).item()
                     new_dist = torch.tensor(1.0 / (2.0 * mean_len), dtype=torch.float32)
                 self.norm_neigh_dist_ = 0.9 * self.norm_neigh_dist_ + 0.1 * new_dist
-                new_num = torch.tensor(p_neighborhood.start_ids_.shape[0] / p_neighborhood.neighbors_.shape[0],
-                                       dtype=torch.float32)
+                n_edges = p_neighborhood.num_edges() if hasattr(p_neighborhood, "num_edges") else \
+                    p_neighborhood.neighbors_.shape[0]
+                new_num = torch.tensor(p_neighborhood.start_ids_.shape[0] / n_edges, dtype=torch.float32)
                 self.norm_num_neighs_ = 0.9 * self.norm_num_neighs_ + 0.1 * new_num
         return self.__compute_convolution__(p_pc_in, p_pc_out, p_in_features, p_neighborhood)
 

@@ -184,6 +184,39 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
     return neighbors, ends
 
 
+def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, capacity: int,
+                       n_batches: Optional[int] = None):
+    """The same query without the host round trip for the edge count (``se3_ball_query_bounded``): the caller sizes the
+    edge buffer (``capacity`` rows, e.g. 1.25 x the previous step's count).  Returns ``(neighbors [capacity,2] int32,
+    ends [M] int32, info [2] int32 on the device)`` with ``info[0]`` = true edge count and ``info[1]`` = 1 when it did
+    not fit (the list is then truncated and ``ends`` clamped: rerun with a larger buffer).  Capturable in a HIP graph
+    when ``n_batches`` is given."""
+    lib = _lib.load()
+    pts_src = _as(pts_src, torch.float32)
+    pts_dst = _as(pts_dst, torch.float32)
+    if pts_src.dim() != 2 or pts_src.shape[1] != 3 or pts_dst.dim() != 2 or pts_dst.shape[1] != 3:
+        raise ValueError("ball_query: only [N,3] point sets are supported")
+    if not (radius > 0) or capacity < 0:
+        raise ValueError("ball_query_bounded: radius must be positive and capacity non-negative")
+    dev = pts_src.device
+    bs, bd = _as(batch_src, torch.int32), _as(batch_dst, torch.int32)
+    n_src, n_dst = pts_src.shape[0], pts_dst.shape[0]
+    f32, i32 = torch.float32, torch.int32
+    neighbors = torch.empty((int(capacity), 2), dtype=i32, device=dev)
+    ends = torch.empty(n_dst, dtype=i32, device=dev)
+    info = torch.zeros(2, dtype=i32, device=dev)
+    if n_dst == 0:
+        return neighbors, ends, info
+    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
+    ws = _workspace(lib.se3_ball_query_workspace_bytes(n_src, n_dst), dev)
+    _lib.check(lib.se3_ball_query_bounded(
+        _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
+        _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius), n_src,
+        n_dst, C.c_void_p(ws.data_ptr()), ws.numel(), int(capacity), _ptr(neighbors, i32, "neighbors"),
+        _ptr(ends, i32, "ends"), _ptr(info, i32, "info"), _stream(dev)), "se3_ball_query_bounded")
+    return neighbors, ends, info
+
+
 class BallQuery(torch.autograd.Function):
     """Drop-in for ``point_cloud_lib.custom_ops.BallQuery`` (BallQuery.py:11-53).  Like the
     reference it returns ``neighbors`` as int64 (ball_query.cu:99-101 promotes through ``cat``)

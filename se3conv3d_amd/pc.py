@@ -195,11 +195,18 @@ class Neighborhood(ABC):
 
 class BQNeighborhood(Neighborhood):
     """Ball-query neighbourhood: ``neighbors_ [E,2]`` (col0 sample, col1 source) int64 like the
-    reference, ``start_ids_ [M]`` = inclusive end offsets, ``radius_``."""
+    reference, ``start_ids_ [M]`` = inclusive end offsets, ``radius_``.
 
-    def __init__(self, p_pc_src, p_samples, p_radius, p_max_neighbors=0):
+    ``p_capacity`` (extension): build into an edge buffer of that many rows without reading the edge count back to the
+    host -- no synchronisation, capturable in a HIP graph.  ``neighbors_`` then has ``p_capacity`` rows of which the
+    first ``num_edges()`` are edges (``start_ids_`` never points past them); ``overflowed()`` tells whether the buffer
+    was too small (the list is then truncated: rebuild with a larger one)."""
+
+    def __init__(self, p_pc_src, p_samples, p_radius, p_max_neighbors=0, p_capacity=None):
         self.radius_ = p_radius
         self.max_neighbors_ = p_max_neighbors
+        self.capacity_ = p_capacity
+        self.edge_info_ = None
         # a cloud against itself: (s, p) is an edge iff (p, s) is -- the operator's backward then needs no
         # source-major copy of the edge list (ops.ConvGeometry.transpose)
         self.symmetric_ = p_pc_src is p_samples and p_max_neighbors == 0
@@ -211,10 +218,24 @@ class BQNeighborhood(Neighborhood):
         # same call as ops.BallQuery.apply (which stays for code that uses the op directly), without the autograd node --
         # the edge list carries no gradient -- and keeping the int32 list the native kernels read next to the
         # int64 ``neighbors_`` the reference exposes
-        nb, self.start_ids_ = ops.ball_query(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
-                                             self.samples_.batch_ids_, self.radius_, self.pc_src_.num_batches())
+        if self.capacity_ is not None:
+            nb, self.start_ids_, self.edge_info_ = ops.ball_query_bounded(
+                self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_, self.samples_.batch_ids_, self.radius_,
+                int(self.capacity_), self.pc_src_.num_batches())
+        else:
+            nb, self.start_ids_ = ops.ball_query(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
+                                                 self.samples_.batch_ids_, self.radius_, self.pc_src_.num_batches())
         self.neighbors_i32_ = nb
         self.neighbors_ = nb.to(torch.int64)
+
+    def num_edges(self) -> int:
+        """Number of edges as a host integer (one device read-back for a capacity-bounded build)."""
+        if self.edge_info_ is None:
+            return int(self.neighbors_.shape[0])
+        return min(int(self.edge_info_[0]), int(self.capacity_))
+
+    def overflowed(self) -> bool:
+        return self.edge_info_ is not None and bool(self.edge_info_[1] != 0)
 
 
 class KnnNeighborhood(Neighborhood):

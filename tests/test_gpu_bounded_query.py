@@ -1,0 +1,98 @@
+"""GPU: the capacity-bounded ball query (se3_ball_query_bounded: no host round trip for the edge count, SURVEY.md
+section 8 row a10 / the reference's syncs at ball_query.cu:46,49-50) -- same edge sets as the two-phase query, the
+edge count and the overflow flag on the device, truncation that never lets a consumer read past the buffer, and a
+neighbourhood + convolution step captured into one HIP graph."""
+import pytest
+import torch
+
+from conftest import canon_edges, rel_err
+from oracle import se3conv_oracle as O
+from se3conv3d_amd.workloads import radius_for_degree
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def amd(built_library):
+    import se3conv3d_amd as amd
+    amd.set_precision("bf16x3")
+    return amd
+
+
+@pytest.mark.parametrize("n_src,n_dst,batches,r", [(6000, 1500, 3, 0.09), (1500, 2500, 2, 0.12), (40, 500, 1, 0.4)])
+def test_bounded_equals_two_phase_and_oracle(amd, n_src, n_dst, batches, r):
+    g = torch.Generator().manual_seed(n_src)
+    ps, pd = torch.rand(n_src, 3, generator=g), torch.rand(n_dst, 3, generator=g)
+    bs = torch.sort(torch.randint(0, batches, (n_src,), generator=g, dtype=torch.int32)).values
+    bd = torch.sort(torch.randint(0, batches, (n_dst,), generator=g, dtype=torch.int32)).values
+    bs[-1] = batches - 1
+    nb_r, ends_r = O.ball_query(ps, pd, bs, bd, r)
+    e = nb_r.shape[0]
+    args = (ps.to(DEV), pd.to(DEV), bs.to(DEV), bd.to(DEV), r)
+    nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=e + 100, n_batches=batches)
+    assert info.tolist() == [e, 0] and nb.shape == (e + 100, 2)
+    assert torch.equal(ends.cpu(), ends_r) and torch.equal(canon_edges(nb[:e]), canon_edges(nb_r))
+    nb2, ends2 = amd.ops.ball_query(*args, batches)
+    assert torch.equal(nb[:e], nb2) and torch.equal(ends, ends2)          # same deterministic order as the two-phase call
+    # exact fit, then too small: the flag is raised, the offsets are clamped, the head of the list is intact
+    nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=e, n_batches=batches)
+    assert info.tolist() == [e, 0] and torch.equal(nb, nb2)
+    cap = e // 2
+    sentinel = torch.full((cap + 7, 2), -7, dtype=torch.int32, device=DEV)
+    nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=cap, n_batches=batches)
+    assert info.tolist() == [e, 1]
+    assert torch.equal(ends.cpu(), torch.clamp(ends_r, max=cap)) and torch.equal(nb, nb2[:cap])
+    del sentinel
+    nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=0, n_batches=batches)
+    assert info.tolist() == [e, 1 if e else 0] and int(ends.max()) == 0
+
+
+def test_neighbourhood_and_conv_step_in_one_graph(amd):
+    torch.manual_seed(0)
+    n, f, c = 6000, 2, 64
+    pc = amd.pc.PointcloudRotEquiv(torch.rand(n, 3, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV),
+                                   {"pca": False, "n_frames": f, "fixed_axis": False})
+    pc.num_batches()
+    r = radius_for_degree(n, 24)
+    ref_nbh = amd.pc.BQNeighborhood(pc, pc, r)
+    e = ref_nbh.num_edges()
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c, c).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r), conv.norm_num_neighs_.fill_(n / e)
+    x = torch.randn(n * f, c, device=DEV, requires_grad=True)
+    g = torch.randn(n * f, c, device=DEV)
+    out_ref = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=ref_nbh)
+    out_ref.backward(g)
+    dx_ref, dw_ref = x.grad.clone(), conv.conv_weights_.grad.clone()
+
+    holder = {}
+
+    def step():
+        x.grad = None
+        conv.zero_grad(set_to_none=True)
+        nbh = amd.pc.BQNeighborhood(pc, pc, r, p_capacity=int(e * 1.25))
+        out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
+        out.backward(g)
+        holder.update(nbh=nbh, out=out)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):       # fails if anything on the path synchronises with the host
+        step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    nbh = holder["nbh"]
+    assert nbh.num_edges() == e and not nbh.overflowed() and nbh.neighbors_.shape[0] == int(e * 1.25)
+    assert torch.equal(holder["out"], out_ref.detach()) and torch.equal(x.grad, dx_ref)
+    assert torch.equal(conv.conv_weights_.grad, dw_ref)
+    # a truncated neighbourhood still runs (results are those of the truncated graph) and says so
+    small = amd.pc.BQNeighborhood(pc, pc, r, p_capacity=e // 3)
+    assert small.overflowed() and small.num_edges() == e // 3
+    out_small = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x.detach(), p_neighborhood=small)
+    assert bool(torch.isfinite(out_small).all())
