@@ -59,7 +59,10 @@ typedef struct se3conv_shape {
   int32_t f_out;   /* frames per output point                               */
   int32_t c_in;    /* input feature channels                                */
   int32_t c_out;   /* output feature channels                               */
-  int32_t num_basis; /* K = p_num_basis; the MFMA kernels implement K == 32 */
+  int32_t num_basis; /* K = p_num_basis; the MFMA kernels implement K == 32 (SE3_ERR_UNSUPPORTED otherwise).  The sum
+                      * over k is separable: other K (the reference's CUDA op takes 8, 16, 32, 64,
+                      * feat_basis_utils.cuh:35-41) are slices of 32 padded with basis functions whose conv weights are
+                      * zero -- the host-side module does exactly that (se3conv3d_amd/layers.py) */
   int32_t precision; /* SE3_PRECISION_*: arithmetic of the contractions (inputs/outputs are fp32)  */
 } se3conv_shape;
 

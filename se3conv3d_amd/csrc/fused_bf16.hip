@@ -126,12 +126,19 @@ __global__ __launch_bounds__(512, 2) void conv_fused_bf16_kernel(EdgeGeom g, con
 // wavefronts idle at the tile barriers behind the slowest item; that costs more than the 2 x 1.07 GB HBM
 // round trip it removes.  Kept (and tested: SE3CONV_FUSED=1) as the starting point for a variant with
 // >= 64 rows per weight pass; off by default.
+// Small levels are a different matter: below a few thousand rows every launch is latency, not throughput, and one
+// launch instead of two (edge kernel + GEMM, plus a split-K reduction) wins.  SE3CONV_FUSED=1 forces the fused kernel
+// at every size, SE3CONV_FUSED=0 turns it off, SE3CONV_FUSED_ROWS=n moves the row limit (default kFusedMaxRows).
+constexpr int64_t kFusedMaxRows = 4096;
 bool conv_fused_bf16_supported(const EdgeGeom& g, int gathered_channels) {
-  static const bool enabled = [] {
+  static const int64_t max_rows = [] {
     const char* e = getenv("SE3CONV_FUSED");
-    return e && e[0] == '1';
+    if (e && e[0] == '1') return (int64_t)1 << 62;
+    if (e && e[0] == '0') return (int64_t)0;
+    const char* r = getenv("SE3CONV_FUSED_ROWS");
+    return r ? (int64_t)atoll(r) : kFusedMaxRows;
   }();
-  return enabled && gathered_channels == kCg && g.f_ctr % 2 == 0;
+  return g.n_ctr * g.f_ctr <= max_rows && gathered_channels == kCg && g.f_ctr % 2 == 0;
 }
 
 int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int64_t feat_rows,

@@ -123,6 +123,31 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     return geom
 
 
+_KB = 32  # basis functions per call of the MFMA operator (include/se3conv.h: num_basis == 32)
+
+
+def _conv_any_num_basis(feat, axes, biases, weights, geom, rho, nu):
+    """The operator for any number of basis functions K on the K = 32 kernels.  The sum over k is separable, so
+    K > 32 is the sum of the operator over slices of 32 basis functions, and a slice shorter than 32 is padded with
+    basis functions whose conv weights are zero (their value GELU(beta_k) is multiplied by W[:, k, :] = 0: exact).
+    The reference's CUDA op accepts K in {8, 16, 32, 64} (feat_basis_utils.cuh:35-41); every shipped configuration
+    uses 32.  Gradients flow through the slicing / padding by autograd (zero rows and columns drop out)."""
+    k = axes.shape[1]
+    if k == _KB:
+        return ops.SE3ConvFunction.apply(feat, axes, biases, weights, geom, rho, nu)
+    out = None
+    for k0 in range(0, k, _KB):
+        a, b, w = axes[:, k0:k0 + _KB], biases[k0:k0 + _KB], weights[:, k0:k0 + _KB, :]
+        pad = _KB - a.shape[1]
+        if pad:
+            a = torch.cat([a, a.new_zeros((a.shape[0], pad))], dim=1)
+            b = torch.cat([b, b.new_zeros((pad,))], dim=0)
+            w = torch.cat([w, w.new_zeros((w.shape[0], pad, w.shape[2]))], dim=1)
+        part = ops.SE3ConvFunction.apply(feat, a.contiguous(), b.contiguous(), w.contiguous(), geom, rho, nu)
+        out = part if out is None else out + part
+    return out
+
+
 class PNEConvLayerRotEquiv(IConvLayer):
     """SE(3)-equivariant continuous point convolution (reference class of the same name).
 
@@ -178,8 +203,8 @@ class PNEConvLayerRotEquiv(IConvLayer):
             if PNEConvLayerRotEquiv.rel_rot_type != "6D" or self.dims_ != 9:
                 raise NotImplementedError("only the 9-D descriptor (3 offsets + '6D' relative rotation) is implemented")
             geom = _geometry_of(p_pc_in, p_pc_out, p_neighborhood)
-            return ops.SE3ConvFunction.apply(p_in_features, self.proj_axes_, self.proj_biases_, self.conv_weights_,
-                                             geom, self.norm_neigh_dist_, self.norm_num_neighs_)
+            return _conv_any_num_basis(p_in_features, self.proj_axes_, self.proj_biases_, self.conv_weights_, geom,
+                                       self.norm_neigh_dist_, self.norm_num_neighs_)
         elif "kp" in self.pne_type_:
             raise Exception("KPNE convolution not implemeted yet for Rot Equiv.")
         raise Exception(f"unknown pne type {self.pne_type_}")
@@ -252,8 +277,8 @@ class PNEConvLayer(IConvLayer):
             except AttributeError:
                 pass
         axes9 = torch.cat([self.proj_axes_, self.proj_axes_.new_zeros((6, self.num_basis_))], dim=0)
-        return ops.SE3ConvFunction.apply(p_in_features, axes9, self.proj_biases_, self.conv_weights_, geom,
-                                         self.norm_neigh_dist_, self.norm_num_neighs_)
+        return _conv_any_num_basis(p_in_features, axes9, self.proj_biases_, self.conv_weights_, geom,
+                                   self.norm_neigh_dist_, self.norm_num_neighs_)
 
 
 class PNEConvLayerFactory(IConvLayerFactory):

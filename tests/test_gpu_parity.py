@@ -544,3 +544,36 @@ def test_symmetric_neighbourhood_needs_no_transposed_copy(amd):
     out.backward(go)
     assert rel_err(gx_sym, x2.grad) < 2e-6
 
+
+
+@pytest.mark.parametrize("kb", [8, 16, 64, 40])
+def test_other_basis_counts_against_oracle(amd, kb):
+    """K in {8, 16, 64} (the set of the reference's CUDA op, feat_basis_utils.cuh:35-41) and an odd one: the module runs
+    them as zero-padded / summed slices of 32 basis functions on the K = 32 kernels -- output and all gradients against
+    the oracle evaluated with the true K."""
+    g = torch.Generator().manual_seed(kb)
+    n, f, c_in, c_out = 500, 2, 64, 48
+    pts = torch.rand(n, 3, generator=g)
+    bid = torch.zeros(n, dtype=torch.int32)
+    fr = O.random_frames(n, f, g)
+    r = O.radius_for_degree(n, 14)
+    nb_ref, _ = O.ball_query(pts, pts, bid, bid, r)
+    a, b, w = O.init_parameters(9, c_in, c_out, kb, g)
+    b = torch.rand(kb, generator=g) - 0.5
+    x = torch.randn(n * f, c_in, generator=g)
+    go = torch.randn(n * f, c_out, generator=g)
+    rho, nu = torch.tensor(1.0 / r), torch.tensor(n / nb_ref.shape[0])
+    ref = O.conv_forward_backward(pts, pts, fr, fr, nb_ref, x, a, b, w, rho, nu, go)
+    pc = amd.pc.PointcloudRotEquiv.from_frames(pts.to(DEV), bid.to(DEV), fr.to(DEV))
+    nbh = amd.pc.BQNeighborhood(pc, pc, r)
+    conv = amd.PNEConvLayerRotEquivFactory(9, kb, "mlp_gelu").create_conv_layer(c_in, c_out)
+    conv.load_state_dict({"proj_axes_": a, "proj_biases_": b, "conv_weights_": w, "norm_neigh_dist_": rho,
+                          "norm_num_neighs_": nu})
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=xg, p_neighborhood=nbh)
+    out.backward(go.to(DEV))
+    got = (out, xg.grad, conv.proj_axes_.grad, conv.proj_biases_.grad, conv.conv_weights_.grad)
+    assert conv.proj_axes_.grad.shape == (9, kb) and conv.conv_weights_.grad.shape == (c_in, kb, c_out)
+    for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), got, ref):
+        assert rel_err(u, v) < tol(amd), (kb, name, rel_err(u, v))
