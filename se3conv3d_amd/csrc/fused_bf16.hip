@@ -126,10 +126,11 @@ __global__ __launch_bounds__(512, 2) void conv_fused_bf16_kernel(EdgeGeom g, con
 // wavefronts idle at the tile barriers behind the slowest item; that costs more than the 2 x 1.07 GB HBM
 // round trip it removes.  Kept (and tested: SE3CONV_FUSED=1) as the starting point for a variant with
 // >= 64 rows per weight pass; off by default.
-// Small levels are a different matter: below a few thousand rows every launch is latency, not throughput, and one
-// launch instead of two (edge kernel + GEMM, plus a split-K reduction) wins.  SE3CONV_FUSED=1 forces the fused kernel
-// at every size, SE3CONV_FUSED=0 turns it off, SE3CONV_FUSED_ROWS=n moves the row limit (default kFusedMaxRows).
-constexpr int64_t kFusedMaxRows = 4096;
+// Small levels (where launches are latency, not throughput) do not favour it either: at 2 652 / 254 output rows the
+// fused launch takes 32 / 28 us against 15 + 20 / 9 + 16 us for edge kernel + GEMM (its k loop over the 2048-deep weight
+// planes is one serial chain per tile; the GEMM splits k over the grid), profiles/r02_levels_fused.txt.
+// SE3CONV_FUSED=1 forces the fused kernel at every size, SE3CONV_FUSED_ROWS=n uses it up to n output rows (default 0).
+constexpr int64_t kFusedMaxRows = 0;
 bool conv_fused_bf16_supported(const EdgeGeom& g, int gathered_channels) {
   static const int64_t max_rows = [] {
     const char* e = getenv("SE3CONV_FUSED");

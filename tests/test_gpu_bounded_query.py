@@ -64,6 +64,9 @@ def test_neighbourhood_and_conv_step_in_one_graph(amd):
     out_ref = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=ref_nbh)
     out_ref.backward(g)
     dx_ref, dw_ref = x.grad.clone(), conv.conv_weights_.grad.clone()
+    # drop the eager autograd graph: it was built on the default stream, and the AccumulateGrad nodes it keeps alive
+    # would be reused -- with that stream -- by the captured backward (torch's capture rule: warm up on a side stream)
+    out_ref = out_ref.detach().clone()
 
     holder = {}
 
@@ -89,7 +92,7 @@ def test_neighbourhood_and_conv_step_in_one_graph(amd):
     torch.cuda.synchronize()
     nbh = holder["nbh"]
     assert nbh.num_edges() == e and not nbh.overflowed() and nbh.neighbors_.shape[0] == int(e * 1.25)
-    assert torch.equal(holder["out"], out_ref.detach()) and torch.equal(x.grad, dx_ref)
+    assert torch.equal(holder["out"], out_ref) and torch.equal(x.grad, dx_ref)
     assert torch.equal(conv.conv_weights_.grad, dw_ref)
     # a truncated neighbourhood still runs (results are those of the truncated graph) and says so
     small = amd.pc.BQNeighborhood(pc, pc, r, p_capacity=e // 3)
