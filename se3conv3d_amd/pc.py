@@ -100,6 +100,7 @@ class PointcloudRotEquiv(Pointcloud):
         self.neigh_cache_ = {}
         self.local_frames_pca_cache_ = {}
         self.local_frames_config_ = p_ref_frames_config
+        self.standard_knn_ = standard_knn
         self.ref_frames_pts = ref_frames_pts
         frames = self.get_local_ref_frames()
         self.n_frames_ = frames.shape[1]
@@ -111,7 +112,8 @@ class PointcloudRotEquiv(Pointcloud):
         key = str(p_neigh_method) + str(kwargs.get("neigh_k" if p_neigh_method == "knn" else "bq_radius"))
         if key not in self.neigh_cache_:
             if p_neigh_method == "knn":
-                self.neigh_cache_[key] = KnnNeighborhood(self, self, kwargs["neigh_k"], p_keep_empty=True)
+                self.neigh_cache_[key] = KnnNeighborhood(self, self, kwargs["neigh_k"], p_keep_empty=True,
+                                                         p_standard_knn=getattr(self, "standard_knn_", False))
             elif p_neigh_method == "ball_query":
                 self.neigh_cache_[key] = BQNeighborhood(self, self, kwargs["bq_radius"])
             else:
@@ -123,7 +125,23 @@ class PointcloudRotEquiv(Pointcloud):
         if not hasattr(self, "neigh_cache_"):
             self.neigh_cache_, self.local_frames_pca_cache_ = {}, {}
         if self.ref_frames_pts is not None:
-            raise NotImplementedError("global reference frames from ref_frames_pts are not on the accelerated path")
+            # PointcloudRotEquiv.py:80-128: a cloud with ONE point per batch element (classification heads) takes its
+            # frames from the whole element's points, `ref_frames_pts [(B m), 3]`: the PCA of all m points
+            # (sample_global_reference_frames_pca, RotationFunctions.py:265-304) or plain random frames
+            n_el = self.pts_.shape[0]
+            if cfg.get("pca", False):
+                if cfg.get("fixed_axis"):
+                    raise NotImplementedError("Sampling global ref frames with fixed axes is not implemented")  # as the reference
+                if "se3-all" not in self.local_frames_pca_cache_:
+                    ref = torch.as_tensor(self.ref_frames_pts, dtype=torch.float32, device=self.pts_.device).reshape(-1, 3)
+                    if n_el == 0 or ref.shape[0] % n_el:
+                        raise ValueError("ref_frames_pts must hold the same number of points for every batch element")
+                    m = ref.shape[0] // n_el
+                    # the covariance of "the k listed points" with every element listing all of its own points
+                    ids = torch.arange(n_el * m, dtype=torch.int32, device=ref.device).reshape(n_el, m)
+                    self.local_frames_pca_cache_["se3-all"] = ops.pca_frames(ref, ids, None)
+                return self._shuffled_pca_frames(cfg["n_frames"])
+            return sample_reference_frames(1, cfg["n_frames"], axis_fixed=cfg.get("fixed_axis"), device=self.pts_.device)
         if cfg.get("pca", False):
             # PointcloudRotEquiv.py:131-167: all PCA frames once ("se3-all"), then a random permutation per point
             # (torch.multinomial without replacement) and the first n_frames
@@ -131,14 +149,19 @@ class PointcloudRotEquiv(Pointcloud):
                 nbh = self.get_ref_frame_neighborhood(cfg["neigh_method"], **cfg["neigh_kwargs"])
                 self.local_frames_pca_cache_["se3-all"] = sample_reference_frames_pca(
                     self.pts_, nbh, axis_fixed=cfg.get("fixed_axis"), device=self.pts_.device)
-            all_frames = self.local_frames_pca_cache_["se3-all"]
-            n_points, n_all = all_frames.shape[0], all_frames.shape[1]
-            weights = torch.ones(n_all, device=self.pts_.device).expand(n_points, -1)
-            perm = torch.multinomial(weights, num_samples=n_all, replacement=False)
-            shuffled = torch.gather(all_frames, 1, perm[:, :, None].expand(-1, -1, all_frames.shape[-1]))
-            return shuffled[:, : cfg["n_frames"], :]
+            return self._shuffled_pca_frames(cfg["n_frames"])
         return sample_reference_frames(self.pts_.shape[0], cfg["n_frames"], axis_fixed=cfg.get("fixed_axis"),
                                        device=self.pts_.device)
+
+    def _shuffled_pca_frames(self, n_frames):
+        """A random permutation of the cached PCA frames per point (torch.multinomial without replacement), first
+        ``n_frames`` kept (PointcloudRotEquiv.py:100-117, 146-167)."""
+        all_frames = self.local_frames_pca_cache_["se3-all"]
+        n_points, n_all = all_frames.shape[0], all_frames.shape[1]
+        weights = torch.ones(n_all, device=self.pts_.device).expand(n_points, -1)
+        perm = torch.multinomial(weights, num_samples=n_all, replacement=False)
+        shuffled = torch.gather(all_frames, 1, perm[:, :, None].expand(-1, -1, all_frames.shape[-1]))
+        return shuffled[:, :n_frames, :]
 
     @classmethod
     def from_frames(cls, p_pts, p_batch_ids, p_frames, p_ref_frames_config=None):
@@ -244,10 +267,14 @@ class KnnNeighborhood(Neighborhood):
     ``start_ids_`` = ``(arange + 1) * k`` when empty slots are kept."""
 
     def __init__(self, p_pc_src, p_samples, p_k, p_keep_empty=False, p_standard_knn=False):
-        if p_pc_src is not p_samples or p_k > 32 or p_standard_knn:
+        # p_standard_knn (the evaluation scripts pass it, test_scannet_rot.py:110): the reference then takes
+        # torch_cluster.knn instead of its own sweep kernel -- another EXACT k-NN; the search here is exact already,
+        # so the flag only changes which of several equidistant candidates may come first there
+        if p_pc_src is not p_samples or p_k > 32:
             raise NotImplementedError("only the self-kNN path with k <= 32 (PCA frame construction) is implemented")
         self.k_ = p_k
         self.keep_empty_ = p_keep_empty
+        self.standard_knn_ = p_standard_knn
         super().__init__(p_pc_src, p_samples)
 
     def __compute_neighborhood__(self):

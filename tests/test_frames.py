@@ -166,3 +166,48 @@ def test_pointcloud_with_pca_frames_runs_the_layer(built_library):
     with torch.no_grad():
         out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
     assert out.shape == (n * 2, 32) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.gpu
+def test_global_frames_from_ref_frames_pts_and_standard_knn(built_library):
+    """PointcloudRotEquiv(ref_frames_pts=...) (pc/PointcloudRotEquiv.py:80-128: one point per batch element, frames
+    from the PCA of the whole element, RotationFunctions.py:265-304) against a direct eigen-decomposition of the
+    element's scatter matrix, and `standard_knn=True` (test_scannet_rot.py:110) giving the frames of the default."""
+    import se3conv3d_amd as amd
+
+    torch.manual_seed(6)
+    b, m = 5, 700
+    ref = torch.randn(b, m, 3) * torch.tensor([3.0, 1.5, 0.5]) @ O.quaternion_to_matrix(
+        torch.nn.functional.normalize(torch.randn(4), dim=0)).t() + torch.randn(b, 1, 3)
+    centres = ref.mean(1)
+    cfg = {"pca": True, "n_frames": 4, "fixed_axis": False, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
+    pc = amd.pc.PointcloudRotEquiv(centres.to(DEV), torch.arange(b, dtype=torch.int32, device=DEV), cfg,
+                                   ref_frames_pts=ref.reshape(-1, 3).to(DEV))
+    assert pc.local_frames_.shape == (b, 4, 9) and pc.batch_ids_considering_frames_.shape == (b * 4,)
+    allf = pc.local_frames_pca_cache_["se3-all"].cpu().reshape(b, 4, 3, 3)
+    pcen = (ref - ref.mean(1, keepdim=True)).double()
+    _, vec = torch.linalg.eigh(pcen.transpose(1, 2) @ pcen)          # ascending eigenvalues, columns = axes
+    for i in range(b):
+        f0 = allf[i, 0].double()
+        assert abs(float(torch.linalg.det(f0)) - 1.0) < 1e-5
+        for c in range(3):                                            # every axis up to sign
+            assert abs(float((f0[:, c] * vec[i][:, c]).sum())) > 1 - 1e-4
+        signs = torch.tensor([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], dtype=torch.double)
+        for k in range(4):                                            # the four proper sign flips, in the reference's order
+            assert float((allf[i, k].double() - f0 * signs[k][None, :]).abs().max()) < 1e-6
+    # the kept frames are a permutation of the four
+    d = (pc.local_frames_.cpu()[:, :, None, :] - allf.reshape(b, 1, 4, 9)).abs().amax(-1)
+    assert bool((d.amin(2) == 0).all()) and sorted(d.argmin(2)[0].tolist()) == [0, 1, 2, 3]
+    with pytest.raises(NotImplementedError):
+        amd.pc.PointcloudRotEquiv(centres.to(DEV), torch.arange(b, dtype=torch.int32, device=DEV), dict(cfg, fixed_axis=2),
+                                  ref_frames_pts=ref.reshape(-1, 3).to(DEV))
+    rnd = amd.pc.PointcloudRotEquiv(centres.to(DEV), torch.arange(b, dtype=torch.int32, device=DEV),
+                                    {"pca": False, "n_frames": 2, "fixed_axis": False}, ref_frames_pts=ref.reshape(-1, 3).to(DEV))
+    assert rnd.local_frames_.shape == (1, 2, 9)                       # the reference samples for n_origins = 1 here
+    # standard_knn: same exact neighbour sets, hence the same PCA frames
+    n = 3000
+    pts = torch.rand(n, 3, device=DEV)
+    bid = torch.zeros(n, dtype=torch.int32, device=DEV)
+    a = amd.pc.PointcloudRotEquiv(pts, bid, cfg)
+    s = amd.pc.PointcloudRotEquiv(pts, bid, cfg, standard_knn=True)
+    assert torch.equal(a.local_frames_pca_cache_["se3-all"], s.local_frames_pca_cache_["se3-all"])
