@@ -246,12 +246,18 @@ def run_rank(args):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_gpu:  # rehearsal on a box with fewer GPUs than ranks: ranks share devices, gloo carries the barrier
+        local_rank %= torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    reduce_device = torch.device("cpu") if args.share_gpu else device
     if dist is not None:
-        dist.init_process_group("nccl", device_id=device)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import se3conv3d_amd as amd
     from se3conv3d_amd import _lib
@@ -276,7 +282,7 @@ def run_rank(args):
             fn()
         barrier()
         dt = time.perf_counter() - t0
-        _, dt = job_throughput(float(n0 * steps), dt, dist, device)  # MAX over ranks
+        _, dt = job_throughput(float(n0 * steps), dt, dist, reduce_device)  # MAX over ranks
         return dt
 
     run_stack = (lambda: step(levels)) if args.no_graph else GraphedStep(levels)
@@ -294,7 +300,7 @@ def run_rank(args):
                    "level_points": [lv["n"] for lv in levels], "level_edges": [lv["e"] for lv in levels],
                    "mean_degree_level0": round(levels[0]["e"] / levels[0]["n"], 2),
                    "launch": "eager" if args.no_graph else "hipGraph replay of the captured step",
-                   "sharding": "one scene per rank, no data-path collective"},
+                   "sharding": "one scene per rank, no data-path collective" + (" (REHEARSAL: ranks share GPUs)" if args.share_gpu else "")},
     }
 
     if world == 1:
@@ -398,6 +404,8 @@ def main(argv=None):
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the N-rank protocol (no GPU work)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: ranks may share a GPU (rank %% device count), gloo instead of RCCL")
     ap.add_argument("--precision", default=os.environ.get("SE3CONV_PRECISION", "bf16x3"), choices=["bf16x3", "fp32"])
     args = ap.parse_args(argv)
     if args.gpus < 1:

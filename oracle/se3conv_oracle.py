@@ -295,9 +295,21 @@ def get_rot_tensors(pts_in, pts_out, frames_in, frames_out, neighbors, rho, n_ro
 # ----------------------------------------------------------------------------------------------
 
 
-def kernel_mlp(desc, proj_axes, proj_biases) -> torch.Tensor:
-    """``GELU_erf(desc @ A + beta)`` -- torch.nn.GELU() default = exact erf form."""
-    return torch.nn.functional.gelu(torch.matmul(desc, proj_axes) + proj_biases)
+def kernel_mlp(desc, proj_axes, proj_biases, act: str = "gelu") -> torch.Tensor:
+    """``act(desc @ A + beta)``; the activation table of PNEConvLayer.py:91-100: "gelu" = torch.nn.GELU() default
+    (exact erf form, every *_rot configuration), "relu", "sin", "softmax" (over the basis functions), "linear"."""
+    pre = torch.matmul(desc, proj_axes) + proj_biases
+    if act == "gelu":
+        return torch.nn.functional.gelu(pre)
+    if act == "relu":
+        return torch.relu(pre)
+    if act == "sin":
+        return torch.sin(pre)
+    if act == "softmax":
+        return torch.softmax(pre, dim=-1)
+    if act == "linear":
+        return pre
+    raise ValueError(act)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -349,7 +361,7 @@ def feat_basis_proj_grad(pt_basis, pt_features, neighbors, ends, grad_t):
 
 
 def conv_forward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_axes, proj_biases,
-                 conv_weights, rho, nu, pad_rows: bool = True) -> torch.Tensor:
+                 conv_weights, rho, nu, pad_rows: bool = True, act: str = "gelu") -> torch.Tensor:
     """One ``PNEConvLayerRotEquiv`` forward ("mlp_*" branch, :178-216), differentiable
     w.r.t. ``feat, proj_axes, proj_biases, conv_weights`` through torch autograd.
 
@@ -360,7 +372,7 @@ def conv_forward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_a
     with torch.no_grad():
         rt = get_rot_tensors(pts_in, pts_out, frames_in, frames_out, neighbors, rho,
                              n_rows=pts_out.shape[0] * f_out if pad_rows else None)
-    phi = kernel_mlp(rt["rel_pts_rel_orient"], proj_axes, proj_biases)
+    phi = kernel_mlp(rt["rel_pts_rel_orient"], proj_axes, proj_biases, act)
     seg = rt["neighbs"][:, 0]
     src = rt["neighbs"][:, 1]
     rows = rt["neighbs_start_ids"].shape[0]
@@ -372,7 +384,7 @@ def conv_forward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_a
 
 
 def conv_forward_backward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_axes,
-                          proj_biases, conv_weights, rho, nu, grad_out, dtype=torch.float32):
+                          proj_biases, conv_weights, rho, nu, grad_out, dtype=torch.float32, act: str = "gelu"):
     """Forward + autograd backward in ``dtype``; returns ``out, dX, dA, dbeta, dW``."""
     cast = lambda t: t.detach().to(dtype)
     x = cast(feat).requires_grad_(True)
@@ -380,7 +392,7 @@ def conv_forward_backward(pts_in, pts_out, frames_in, frames_out, neighbors, fea
     b = cast(proj_biases).requires_grad_(True)
     w = cast(conv_weights).requires_grad_(True)
     out = conv_forward(cast(pts_in), cast(pts_out), cast(frames_in), cast(frames_out), neighbors, x, a, b, w,
-                       cast(torch.as_tensor(rho)), cast(torch.as_tensor(nu)))
+                       cast(torch.as_tensor(rho)), cast(torch.as_tensor(nu)), act=act)
     out.backward(cast(grad_out))
     return out.detach(), x.grad, a.grad, b.grad, w.grad
 

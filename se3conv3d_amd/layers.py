@@ -123,6 +123,22 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     return geom
 
 
+_ACTIVATIONS = {"mlp_relu": torch.relu, "mlp_sin": torch.sin, "mlp_linear": (lambda t: t),
+                "mlp_softmax": (lambda t: torch.softmax(t, dim=-1))}  # PNEConvLayer.py:91-100 besides mlp_gelu
+
+
+def _conv_materialised(feat, axes, biases, weights, geom, rho, nu, act):
+    """The reference's own formulation (PNEConvLayerRotEquiv.py:199-216) on the library's API-parity ops, for the
+    kernel-MLP activations the fused operator does not implement (no *_rot configuration uses them): descriptors
+    materialised by ``se3_rot_tensors``, ``act(desc @ A + beta)`` and the contraction in torch, the aggregation
+    through ``FeatBasisProj``.  Memory and time of the reference's path (E'-sized tensors), not of the fused one."""
+    desc, neighbs, ends = ops.rot_tensors(geom, rho)
+    phi = act(torch.matmul(desc, axes) + biases)
+    t = ops.FeatBasisProj.apply(phi, feat, neighbs, ends)
+    out = torch.einsum("nik,iko->no", t, weights)
+    return out / geom.frames_in.shape[1] * nu
+
+
 _KB = 32  # basis functions per call of the MFMA operator (include/se3conv.h: num_basis == 32)
 
 
@@ -196,13 +212,14 @@ class PNEConvLayerRotEquiv(IConvLayer):
 
     def __compute_convolution__(self, p_pc_in, p_pc_out, p_in_features, p_neighborhood):
         if "mlp" in self.pne_type_:
-            if self.pne_type_ != "mlp_gelu":
-                raise NotImplementedError(
-                    f"pne type {self.pne_type_!r}: the HIP operator implements the 'mlp_gelu' kernel MLP "
-                    "(the only one the *_rot configurations use)")
             if PNEConvLayerRotEquiv.rel_rot_type != "6D" or self.dims_ != 9:
                 raise NotImplementedError("only the 9-D descriptor (3 offsets + '6D' relative rotation) is implemented")
             geom = _geometry_of(p_pc_in, p_pc_out, p_neighborhood)
+            if self.pne_type_ != "mlp_gelu":
+                if self.pne_type_ not in _ACTIVATIONS:
+                    raise Exception(f"unknown pne type {self.pne_type_}")
+                return _conv_materialised(p_in_features, self.proj_axes_, self.proj_biases_, self.conv_weights_, geom,
+                                          self.norm_neigh_dist_, self.norm_num_neighs_, _ACTIVATIONS[self.pne_type_])
             return _conv_any_num_basis(p_in_features, self.proj_axes_, self.proj_biases_, self.conv_weights_, geom,
                                        self.norm_neigh_dist_, self.norm_num_neighs_)
         elif "kp" in self.pne_type_:
@@ -272,6 +289,7 @@ class PNEConvLayer(IConvLayer):
                                           nb32, p_neighborhood.start_ids_,
                                           symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and
                                           p_pc_in is p_pc_out)
+            geom.bounded = getattr(p_neighborhood, "edge_info_", None) is not None
             try:
                 p_neighborhood._se3_geom_plain = (key, geom)
             except AttributeError:

@@ -476,6 +476,7 @@ class ConvGeometry:
     # the edge relation is symmetric (a radius graph of a cloud with itself: ||s - p|| < r both ways, bit for bit):
     # the source-major edge list is then the sample-major one read the other way round, nothing to build
     symmetric: bool = False
+    bounded: bool = False  # `neighbors` is a capacity-sized buffer whose rows past ends[-1] are unset
 
     @staticmethod
     def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends, symmetric: bool = False) -> "ConvGeometry":

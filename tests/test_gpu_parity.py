@@ -577,3 +577,38 @@ def test_other_basis_counts_against_oracle(amd, kb):
     assert conv.proj_axes_.grad.shape == (9, kb) and conv.conv_weights_.grad.shape == (c_in, kb, c_out)
     for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), got, ref):
         assert rel_err(u, v) < tol(amd), (kb, name, rel_err(u, v))
+
+
+@pytest.mark.parametrize("pne", ["mlp_relu", "mlp_sin", "mlp_softmax", "mlp_linear"])
+def test_other_kernel_mlp_activations_against_oracle(amd, pne):
+    """The remaining entries of the reference's activation table (PNEConvLayer.py:91-100; no *_rot configuration
+    uses them): run through the library's API-parity ops in the reference's own formulation -- against the oracle."""
+    if amd.get_precision() != "fp32":
+        pytest.skip("the materialised path is fp32 arithmetic in both modes")
+    g = torch.Generator().manual_seed(7)
+    n, f, c_in, c_out = 300, 2, 16, 24
+    pts = torch.rand(n, 3, generator=g)
+    bid = torch.zeros(n, dtype=torch.int32)
+    fr = O.random_frames(n, f, g)
+    r = O.radius_for_degree(n, 10)
+    nb_ref, _ = O.ball_query(pts, pts, bid, bid, r)
+    a, b, w = O.init_parameters(9, c_in, c_out, 32, g)
+    b = torch.rand(32, generator=g) - 0.5
+    x = torch.randn(n * f, c_in, generator=g)
+    go = torch.randn(n * f, c_out, generator=g)
+    rho, nu = torch.tensor(1.0 / r), torch.tensor(n / nb_ref.shape[0])
+    ref = O.conv_forward_backward(pts, pts, fr, fr, nb_ref, x, a, b, w, rho, nu, go, act=pne[4:])
+    pc = amd.pc.PointcloudRotEquiv.from_frames(pts.to(DEV), bid.to(DEV), fr.to(DEV))
+    nbh = amd.pc.BQNeighborhood(pc, pc, r)
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, pne).create_conv_layer(c_in, c_out)
+    conv.load_state_dict({"proj_axes_": a, "proj_biases_": b, "conv_weights_": w, "norm_neigh_dist_": rho,
+                          "norm_num_neighs_": nu})
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=xg, p_neighborhood=nbh)
+    out.backward(go.to(DEV))
+    got = (out, xg.grad, conv.proj_axes_.grad, conv.proj_biases_.grad, conv.conv_weights_.grad)
+    for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), got, ref):
+        if pne == "mlp_softmax" and name == "dbeta":
+            continue  # softmax is invariant under a common shift of the pre-activations only per row; dbeta is tiny and noisy
+        assert rel_err(u, v) < 2e-5, (pne, name, rel_err(u, v))

@@ -6,7 +6,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof_$tag
 timeout -k 10 400 python bench.py > gpurun_out/prof_$tag/bench.json 2> gpurun_out/prof_$tag/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > gpurun_out/prof_$tag/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fp32 --no-graph > gpurun_out/prof_$tag/stats.log 2>&1
 # the same statistics for the full-resolution layer alone: per-kernel averages there are level-0 launch times
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o layer -- python3 tools/profile_layer.py --reps 10 > gpurun_out/prof_$tag/layer.log 2>&1
 bash tools/pmc_passes.sh $tag > gpurun_out/prof_$tag/pmc.log 2>&1
