@@ -76,7 +76,7 @@ def test_neighbourhood_and_conv_step_in_one_graph(amd):
         nbh = amd.pc.BQNeighborhood(pc, pc, r, p_capacity=int(e * 1.25))
         out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=nbh)
         out.backward(g)
-        holder.update(nbh=nbh, out=out)
+        holder.update(nbh=nbh, out=out.detach())   # no reference to the autograd graph survives the step
 
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
