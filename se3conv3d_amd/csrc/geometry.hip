@@ -92,16 +92,19 @@ __global__ void find_ranges_kernel(const float* __restrict__ pts_dst, const int3
   }
 }
 
-// One wavefront per sample.  STORE = false: counts[s] = #hits.  STORE = true: neighbors[base + j] =
-// (s, source id) for the j-th hit in candidate order.
-template <bool STORE>
+// One wavefront per sample.  MODE 0: counts[s] = #hits.  MODE 1: neighbors[base + j] = (s, source id) for the j-th hit
+// in candidate order, base from the inclusive offsets `ends`.  MODE 2 (capacity-bounded call): the same, slots at or
+// beyond `limit` dropped, the sample's own offset clamped to `limit` in place (its neighbour reads ends[s-1] either
+// way and clamps what it reads), the last sample records the true total and the overflow flag in `info`, and
+// `sources` (optional) receives the source ids alone -- the source-major list of a cloud against itself.
+template <int MODE>
 __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __restrict__ pts_dst, float inv_r,
                                                               const float4* __restrict__ spts,
                                                               const int2* __restrict__ ranges, int64_t n_dst,
-                                                              int32_t* __restrict__ counts,
-                                                              const int32_t* __restrict__ ends,
-                                                              int32_t* __restrict__ neighbors, int limit) {
-  // limit: rows of `neighbors` (bounded variant: slots at or beyond it are dropped; INT_MAX otherwise)
+                                                              int32_t* __restrict__ counts, int32_t* __restrict__ ends,
+                                                              int32_t* __restrict__ neighbors, int limit,
+                                                              int32_t* __restrict__ sources, int32_t* __restrict__ info) {
+  constexpr bool STORE = MODE != 0;
   const int lane = threadIdx.x & 63;
   const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= n_dst) return;
@@ -118,6 +121,14 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
   int found = 0;
   int base = 0;
   if (STORE) base = s > 0 ? ends[s - 1] : 0;
+  if (MODE == 2) {
+    base = min(base, limit);
+    if (lane == 0) {
+      const int e = ends[s];
+      if (s == n_dst - 1) info[0] = e, info[1] = e > limit ? 1 : 0;
+      if (e > limit) ends[s] = limit;
+    }
+  }
   for (int c0 = 0; c0 < total; c0 += 64) {
     const int c = c0 + lane;
     bool hit = false;
@@ -145,6 +156,7 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
       if (slot < limit) {
         neighbors[(int64_t)slot * 2] = (int32_t)s;
         neighbors[(int64_t)slot * 2 + 1] = id;
+        if (MODE == 2 && sources) sources[slot] = id;
       }
     }
     found += __popcll(mask);
@@ -156,15 +168,20 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
 // keys, sort or windows, i.e. 3 launches instead of 16 where the launches are all there is to the cost.  Same
 // predicate, same batch test; hits of a sample come out in ascending source id.
 constexpr int64_t kBqScanAllMax = 2048;
-// STORE = false also leaves (x, y, z, batch id) records of the sources in the workspace: the store phase of the C ABI
-// is not handed the source arrays again.
-template <bool STORE>
+// MODE 0 (count) also leaves (x, y, z, batch id) records of the sources in the workspace: the store phase of the C ABI
+// is not handed the source arrays again.  MODE 1: store behind the caller's inclusive offsets.  MODE 2 (bounded call):
+// the same with clamping / info / sources as scan_candidates_kernel<2>.  MODE 3 (bounded call, few samples): no scan
+// launch at all -- every wavefront sums the counts in front of its sample itself (n_dst / 64 loads per lane), writes the
+// sample's clamped inclusive offset, stores, and the last sample records total + overflow flag.
+constexpr int64_t kBqInlinePrefixMax = 4096;
+template <int MODE>
 __global__ __launch_bounds__(256) void scan_all_kernel(const float* __restrict__ pts_src, const int32_t* __restrict__ batch_src,
                                                        float4* __restrict__ recs, const float* __restrict__ pts_dst,
                                                        const int32_t* __restrict__ batch_dst, float inv_r, int n_src,
                                                        int64_t n_dst, int32_t* __restrict__ counts,
-                                                       const int32_t* __restrict__ ends, int32_t* __restrict__ neighbors,
-                                                       int limit) {
+                                                       int32_t* __restrict__ ends, int32_t* __restrict__ neighbors,
+                                                       int limit, int32_t* __restrict__ sources, int32_t* __restrict__ info) {
+  constexpr bool STORE = MODE != 0;
   const int lane = threadIdx.x & 63;
   if (!STORE) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,7 +192,28 @@ __global__ __launch_bounds__(256) void scan_all_kernel(const float* __restrict__
   const float sx = pts_dst[s * 3], sy = pts_dst[s * 3 + 1], sz = pts_dst[s * 3 + 2];
   const int sb = batch_dst[s];
   int found = 0;
-  const int base = STORE ? (s > 0 ? ends[s - 1] : 0) : 0;
+  int base = 0;
+  if (MODE == 1 || MODE == 2) base = s > 0 ? ends[s - 1] : 0;
+  if (MODE == 2) {  // offsets from the scan: clamp in place like scan_candidates_kernel<2>
+    base = min(base, limit);
+    if (lane == 0) {
+      const int e = ends[s];
+      if (s == n_dst - 1) info[0] = e, info[1] = e > limit ? 1 : 0;
+      if (e > limit) ends[s] = limit;
+    }
+  }
+  if (MODE == 3) {
+    int acc = 0;
+    for (int64_t j = lane; j < s; j += 64) acc += counts[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    const int e = acc + counts[s];
+    base = min(acc, limit);
+    if (lane == 0) {
+      ends[s] = min(e, limit);
+      if (s == n_dst - 1) info[0] = e, info[1] = e > limit ? 1 : 0;
+    }
+  }
   for (int c0 = 0; c0 < n_src; c0 += 64) {
     const int id = c0 + lane;
     bool hit = false;
@@ -196,21 +234,12 @@ __global__ __launch_bounds__(256) void scan_all_kernel(const float* __restrict__
       if (slot < limit) {
         neighbors[(int64_t)slot * 2] = (int32_t)s;
         neighbors[(int64_t)slot * 2 + 1] = id;
+        if (MODE >= 2 && sources) sources[slot] = id;
       }
     }
     found += __popcll(mask);
   }
   if (!STORE && lane == 0) counts[s] = found;
-}
-
-// Bounded variant: info[0] = true edge total, info[1] = 1 when it exceeds the caller's buffer; the offsets are clamped
-// to the buffer so that no consumer ever walks past it.
-__global__ void clamp_ends_kernel(int32_t* __restrict__ ends, int64_t n_dst, int capacity, int32_t* __restrict__ info) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_dst) return;
-  const int e = ends[i];  // every thread touches its own element only
-  if (i == n_dst - 1) info[0] = e, info[1] = e > capacity ? 1 : 0;
-  if (e > capacity) ends[i] = capacity;
 }
 
 // Per-batch bounding boxes (BallQuery.py:35-36 / BoundingBox.py:17-18 use torch_scatter's scatter_min/max).
@@ -228,9 +257,11 @@ __device__ __forceinline__ void atomic_max_f(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-__global__ void batch_aabb_init_kernel(float* __restrict__ mn, float* __restrict__ mx, int count) {
+__global__ void batch_aabb_init_kernel(float* __restrict__ mn, float* __restrict__ mx, int count,
+                                       int32_t* __restrict__ num_cells) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) mn[i] = __int_as_float(0x7f800000), mx[i] = __int_as_float(0xff800000);  // +inf / -inf
+  if (num_cells && i < 3) num_cells[i] = 0;  // the grid-parameter kernel behind this one takes maxima into it
 }
 
 // A wavefront keeps running minima / maxima in its lanes for as long as the points it reads belong to one batch
@@ -454,13 +485,10 @@ extern "C" int se3_compute_keys(const float* pts, const int32_t* batch_ids, cons
   return check_launch();
 }
 
-extern "C" int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float* aabb_min,
-                              float* aabb_max, void* stream_) {
-  if (n < 0 || n_batches < 1) return SE3_ERR_INVALID_ARGUMENT;
-  if (!aabb_min || !aabb_max || (n > 0 && (!pts || !batch_ids))) return SE3_ERR_INVALID_ARGUMENT;
-  hipStream_t stream = (hipStream_t)stream_;
+static int batch_aabb_impl(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float* aabb_min,
+                           float* aabb_max, int32_t* num_cells_to_zero, hipStream_t stream) {
   hipLaunchKernelGGL(batch_aabb_init_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, aabb_min, aabb_max,
-                     n_batches * 3);
+                     n_batches * 3, num_cells_to_zero);
   if (n > 0) {
     int64_t blocks = (n + 4095) / 4096;  // 16 groups of 64 points per wavefront before it issues its 6 atomics
     if (blocks > 256) blocks = 256;
@@ -468,6 +496,13 @@ extern "C" int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_
                        aabb_max);
   }
   return check_launch();
+}
+
+extern "C" int se3_batch_aabb(const float* pts, const int32_t* batch_ids, int64_t n, int32_t n_batches, float* aabb_min,
+                              float* aabb_max, void* stream_) {
+  if (n < 0 || n_batches < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (!aabb_min || !aabb_max || (n > 0 && (!pts || !batch_ids))) return SE3_ERR_INVALID_ARGUMENT;
+  return batch_aabb_impl(pts, batch_ids, n, n_batches, aabb_min, aabb_max, nullptr, (hipStream_t)stream_);
 }
 
 namespace {
@@ -491,8 +526,8 @@ extern "C" int se3_ball_query_grid(const float* pts_src, const int32_t* batch_sr
   if (n_src < 0 || n_batches < 1 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (!aabb_min || !aabb_max_scratch || !num_cells) return SE3_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
-  if (hipMemsetAsync(num_cells, 0, 3 * sizeof(int32_t), stream) != hipSuccess) return SE3_ERR_LAUNCH;
-  if (int rc = se3_batch_aabb(pts_src, batch_src, n_src, n_batches, aabb_min, aabb_max_scratch, stream_)) return rc;
+  if (n_src > 0 && (!pts_src || !batch_src)) return SE3_ERR_INVALID_ARGUMENT;
+  if (int rc = batch_aabb_impl(pts_src, batch_src, n_src, n_batches, aabb_min, aabb_max_scratch, num_cells, stream)) return rc;
   hipLaunchKernelGGL(grid_params_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, aabb_min,
                      aabb_max_scratch, n_batches, radius, -1e-6f, num_cells);
   return check_launch();
@@ -552,10 +587,12 @@ extern "C" size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst) {
   return bq_layout(n_src, n_dst).total;
 }
 
-extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
-                                    const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
-                                    float radius, int64_t n_src, int64_t n_dst, void* workspace,
-                                    size_t workspace_bytes, int32_t* ends, void* stream_) {
+// skip_scan: the all-pairs path of the bounded call with few samples leaves the per-sample counts in the workspace and
+// lets the store kernel form the offsets itself (scan_all_kernel<3>)
+static int ball_query_count_impl(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                 const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                                 float radius, int64_t n_src, int64_t n_dst, void* workspace,
+                                 size_t workspace_bytes, int32_t* ends, bool skip_scan, void* stream_) {
   if (n_src < 0 || n_dst < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_src >= (1ll << 31) || n_dst >= (1ll << 31) / 9) return SE3_ERR_UNSUPPORTED;
   if (n_dst == 0) return SE3_OK;
@@ -571,9 +608,10 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
     int32_t* counts = (int32_t*)(ws + l.counts);
     size_t temp_bytes = l.temp_bytes;
     const int64_t blocks = std::max((n_dst + 3) / 4, (n_src + 255) / 256);
-    hipLaunchKernelGGL(scan_all_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, pts_src, batch_src,
+    hipLaunchKernelGGL(scan_all_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, pts_src, batch_src,
                        (float4*)(ws + l.spts), pts_dst, batch_dst, 1.0f / radius, (int)n_src, n_dst, counts,
-                       (const int32_t*)nullptr, (int32_t*)nullptr, 0);
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr, (int32_t*)nullptr);
+    if (skip_scan) return check_launch();
     if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
       return SE3_ERR_LAUNCH;
     return check_launch();
@@ -599,30 +637,51 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
   }
   hipLaunchKernelGGL(find_ranges_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
                      aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges);
-  hipLaunchKernelGGL(scan_candidates_kernel<false>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, stream, pts_dst,
-                     1.0f / radius, spts, ranges, n_dst, counts, (const int32_t*)nullptr, (int32_t*)nullptr, 0);
+  hipLaunchKernelGGL(scan_candidates_kernel<0>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, stream, pts_dst,
+                     1.0f / radius, spts, ranges, n_dst, counts, (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr,
+                     (int32_t*)nullptr);
   temp_bytes = l.temp_bytes;
   if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
     return SE3_ERR_LAUNCH;
   return check_launch();
 }
 
+extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                    const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                                    float radius, int64_t n_src, int64_t n_dst, void* workspace,
+                                    size_t workspace_bytes, int32_t* ends, void* stream) {
+  return ball_query_count_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
+                               workspace, workspace_bytes, ends, false, stream);
+}
+
+// mode 1: two-phase store; 2: bounded (clamp, info, sources); 3: bounded all-pairs with the offsets formed in the kernel
 static int ball_query_store_impl(const float* pts_dst, const int32_t* batch_dst, float radius, int64_t n_src,
-                                 int64_t n_dst, const void* workspace, size_t workspace_bytes, const int32_t* ends,
-                                 int32_t* neighbors, int limit, void* stream) {
+                                 int64_t n_dst, const void* workspace, size_t workspace_bytes, int32_t* ends,
+                                 int32_t* neighbors, int limit, int mode, int32_t* sources, int32_t* info, void* stream) {
   const BqLayout l = bq_layout(n_src, n_dst);
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   const char* ws = (const char*)workspace;
+  const dim3 grid((unsigned)((n_dst + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
   if (n_src <= kBqScanAllMax) {  // the count phase took the all-pairs path (and left the source records)
     if (!batch_dst) return SE3_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(scan_all_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)nullptr, (const int32_t*)nullptr, (float4*)(ws + l.spts), pts_dst, batch_dst,
-                       1.0f / radius, (int)n_src, n_dst, (int32_t*)nullptr, ends, neighbors, limit);
+    float4* recs = (float4*)(ws + l.spts);
+    int32_t* counts = (int32_t*)(ws + l.counts);
+#define SE3_SCAN_ALL(M)                                                                                                 \
+  hipLaunchKernelGGL(scan_all_kernel<M>, grid, block, 0, st, (const float*)nullptr, (const int32_t*)nullptr, recs, pts_dst, \
+                     batch_dst, 1.0f / radius, (int)n_src, n_dst, counts, ends, neighbors, limit, sources, info)
+    if (mode == 1) SE3_SCAN_ALL(1);
+    else if (mode == 2) SE3_SCAN_ALL(2);
+    else SE3_SCAN_ALL(3);
+#undef SE3_SCAN_ALL
     return check_launch();
   }
-  hipLaunchKernelGGL(scan_candidates_kernel<true>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
-                     (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit);
+  if (mode == 1)
+    hipLaunchKernelGGL(scan_candidates_kernel<1>, grid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
+                       (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info);
+  else
+    hipLaunchKernelGGL(scan_candidates_kernel<2>, grid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
+                       (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info);
   return check_launch();
 }
 
@@ -632,25 +691,25 @@ extern "C" int se3_ball_query_store(const float* pts_dst, const int32_t* batch_d
   if (n_src < 0 || n_dst < 0 || n_edges < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_dst == 0 || n_edges == 0) return SE3_OK;
   if (!pts_dst || !workspace || !ends || !neighbors) return SE3_ERR_INVALID_ARGUMENT;
-  return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes, ends, neighbors,
-                               0x7fffffff, stream);
+  return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes,
+                               const_cast<int32_t*>(ends), neighbors, 0x7fffffff, 1, nullptr, nullptr, stream);
 }
 
 extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
                                       const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
                                       float radius, int64_t n_src, int64_t n_dst, void* workspace, size_t workspace_bytes,
-                                      int64_t capacity, int32_t* neighbors, int32_t* ends, int32_t* info, void* stream) {
+                                      int64_t capacity, int32_t* neighbors, int32_t* sources, int32_t* ends, int32_t* info,
+                                      void* stream) {
   if (capacity < 0 || capacity >= (1ll << 31) || !info) return SE3_ERR_INVALID_ARGUMENT;
   if (n_dst == 0) return hipMemsetAsync(info, 0, 2 * sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
   if (capacity > 0 && !neighbors) return SE3_ERR_INVALID_ARGUMENT;
-  if (int rc = se3_ball_query_count(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
-                                    workspace, workspace_bytes, ends, stream))
+  const bool inline_prefix = n_src <= kBqScanAllMax && n_dst <= kBqInlinePrefixMax;
+  if (int rc = ball_query_count_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
+                                     workspace, workspace_bytes, ends, inline_prefix, stream))
     return rc;
-  hipLaunchKernelGGL(clamp_ends_kernel, dim3(blocks_for(n_dst)), dim3(256), 0, (hipStream_t)stream, ends, n_dst,
-                     (int)capacity, info);
-  if (capacity == 0) return check_launch();
+  // one store launch also clamps the offsets to the buffer and records total + overflow flag
   return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes, ends, neighbors,
-                               (int)capacity, stream);
+                               (int)capacity, inline_prefix ? 3 : 2, sources, info, stream);
 }
 
 namespace {
@@ -868,8 +927,7 @@ extern "C" int se3_grid_subsample(const float* pts, const int32_t* batch_ids, in
   int32_t* ids = (int32_t*)(ws + l.ids);
   int32_t* flags = (int32_t*)(ws + l.flags);
   int32_t* ranks = (int32_t*)(ws + l.ranks);
-  if (hipMemsetAsync(num_cells, 0, 3 * sizeof(int32_t), stream) != hipSuccess) return SE3_ERR_LAUNCH;
-  if (int rc = se3_batch_aabb(pts, batch_ids, n, n_batches, box_min, box_max, stream_)) return rc;
+  if (int rc = batch_aabb_impl(pts, batch_ids, n, n_batches, box_min, box_max, num_cells, stream)) return rc;
   hipLaunchKernelGGL(grid_params_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, box_min, box_max,
                      n_batches, cell_size, 1e-6f, num_cells);
   hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, pts, batch_ids, box_min, num_cells,

@@ -106,16 +106,19 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     """int32/fp32 view of the clouds + neighbourhood, cached on the neighbourhood object (it also
     carries the lazily built source-major edge list used by backward)."""
     cache = getattr(p_neighborhood, "_se3_geom", None)
-    key = (id(p_pc_in), id(p_pc_out), p_neighborhood.neighbors_.data_ptr(), p_pc_in.local_frames_.data_ptr(),
+    nb32 = getattr(p_neighborhood, "neighbors_i32_", None)  # the library's own list when it built the neighbourhood
+    if nb32 is None:
+        nb32 = p_neighborhood.neighbors_
+    key = (id(p_pc_in), id(p_pc_out), nb32.data_ptr(), p_pc_in.local_frames_.data_ptr(),
            p_pc_out.local_frames_.data_ptr(), p_pc_in.pts_.data_ptr(), p_pc_out.pts_.data_ptr())
     if cache is not None and cache[0] == key:
         return cache[1]
-    nb32 = getattr(p_neighborhood, "neighbors_i32_", None)  # the library's own list when it built the neighbourhood
-    if nb32 is None or nb32.shape[0] != p_neighborhood.neighbors_.shape[0]:
-        nb32 = p_neighborhood.neighbors_
     geom = ops.ConvGeometry.build(p_pc_in.pts_, p_pc_out.pts_, p_pc_in.local_frames_, p_pc_out.local_frames_,
                                   nb32, p_neighborhood.start_ids_,
                                   symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and p_pc_in is p_pc_out)
+    geom.bounded = getattr(p_neighborhood, "edge_info_", None) is not None
+    if geom.symmetric:
+        geom.sources = getattr(p_neighborhood, "sources_i32_", None)
     try:
         p_neighborhood._se3_geom = (key, geom)
     except AttributeError:
@@ -132,6 +135,9 @@ def _conv_materialised(feat, axes, biases, weights, geom, rho, nu, act):
     kernel-MLP activations the fused operator does not implement (no *_rot configuration uses them): descriptors
     materialised by ``se3_rot_tensors``, ``act(desc @ A + beta)`` and the contraction in torch, the aggregation
     through ``FeatBasisProj``.  Memory and time of the reference's path (E'-sized tensors), not of the fused one."""
+    if getattr(geom, "bounded", False):
+        raise NotImplementedError("a capacity-bounded neighbourhood (rows past the edge count are unset) cannot feed "
+                                  "the materialised path: build the neighbourhood without p_capacity")
     desc, neighbs, ends = ops.rot_tensors(geom, rho)
     phi = act(torch.matmul(desc, axes) + biases)
     t = ops.FeatBasisProj.apply(phi, feat, neighbs, ends)
@@ -278,18 +284,20 @@ class PNEConvLayer(IConvLayer):
         pc_in = _IdentityFramed(p_pc_in)
         pc_out = pc_in if p_pc_out is p_pc_in else _IdentityFramed(p_pc_out)
         cache = getattr(p_neighborhood, "_se3_geom_plain", None)
-        key = (p_pc_in.pts_.data_ptr(), p_pc_out.pts_.data_ptr(), p_neighborhood.neighbors_.data_ptr())
+        nb32 = getattr(p_neighborhood, "neighbors_i32_", None)
+        if nb32 is None:
+            nb32 = p_neighborhood.neighbors_
+        key = (p_pc_in.pts_.data_ptr(), p_pc_out.pts_.data_ptr(), nb32.data_ptr())
         if cache is not None and cache[0] == key:
             geom = cache[1]
         else:
-            nb32 = getattr(p_neighborhood, "neighbors_i32_", None)
-            if nb32 is None or nb32.shape[0] != p_neighborhood.neighbors_.shape[0]:
-                nb32 = p_neighborhood.neighbors_
             geom = ops.ConvGeometry.build(pc_in.pts_, pc_out.pts_, pc_in.local_frames_, pc_out.local_frames_,
                                           nb32, p_neighborhood.start_ids_,
                                           symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and
                                           p_pc_in is p_pc_out)
             geom.bounded = getattr(p_neighborhood, "edge_info_", None) is not None
+            if geom.symmetric:
+                geom.sources = getattr(p_neighborhood, "sources_i32_", None)
             try:
                 p_neighborhood._se3_geom_plain = (key, geom)
             except AttributeError:

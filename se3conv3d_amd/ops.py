@@ -185,12 +185,13 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
 
 
 def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, capacity: int,
-                       n_batches: Optional[int] = None):
+                       n_batches: Optional[int] = None, want_sources: bool = False):
     """The same query without the host round trip for the edge count (``se3_ball_query_bounded``): the caller sizes the
     edge buffer (``capacity`` rows, e.g. 1.25 x the previous step's count).  Returns ``(neighbors [capacity,2] int32,
     ends [M] int32, info [2] int32 on the device)`` with ``info[0]`` = true edge count and ``info[1]`` = 1 when it did
     not fit (the list is then truncated and ``ends`` clamped: rerun with a larger buffer).  Capturable in a HIP graph
-    when ``n_batches`` is given."""
+    when ``n_batches`` is given.  ``want_sources``: a fourth result, the source ids as a dense ``[capacity]`` array
+    (the source-major edge list of a cloud against itself)."""
     lib = _lib.load()
     pts_src = _as(pts_src, torch.float32)
     pts_dst = _as(pts_dst, torch.float32)
@@ -203,18 +204,21 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
     n_src, n_dst = pts_src.shape[0], pts_dst.shape[0]
     f32, i32 = torch.float32, torch.int32
     neighbors = torch.empty((int(capacity), 2), dtype=i32, device=dev)
+    sources = torch.empty(int(capacity), dtype=i32, device=dev) if want_sources else None
     ends = torch.empty(n_dst, dtype=i32, device=dev)
-    info = torch.zeros(2, dtype=i32, device=dev)
     if n_dst == 0:
-        return neighbors, ends, info
+        info = torch.zeros(2, dtype=i32, device=dev)
+        return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)
+    info = torch.empty(2, dtype=i32, device=dev)  # both words are written by the store pass
     mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
     ws = _workspace(lib.se3_ball_query_workspace_bytes(n_src, n_dst), dev)
     _lib.check(lib.se3_ball_query_bounded(
         _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
         _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius), n_src,
         n_dst, C.c_void_p(ws.data_ptr()), ws.numel(), int(capacity), _ptr(neighbors, i32, "neighbors"),
-        _ptr(ends, i32, "ends"), _ptr(info, i32, "info"), _stream(dev)), "se3_ball_query_bounded")
-    return neighbors, ends, info
+        _ptr(sources, i32, "sources"), _ptr(ends, i32, "ends"), _ptr(info, i32, "info"), _stream(dev)),
+        "se3_ball_query_bounded")
+    return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)
 
 
 class BallQuery(torch.autograd.Function):
@@ -477,6 +481,7 @@ class ConvGeometry:
     # the source-major edge list is then the sample-major one read the other way round, nothing to build
     symmetric: bool = False
     bounded: bool = False  # `neighbors` is a capacity-sized buffer whose rows past ends[-1] are unset
+    sources: Optional[torch.Tensor] = None  # column 1 of `neighbors` as a dense array when the ball query wrote one
 
     @staticmethod
     def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends, symmetric: bool = False) -> "ConvGeometry":
@@ -497,7 +502,8 @@ class ConvGeometry:
         """Source-major edge list ``(t_samples [E], t_ends [N_in])`` for the feature gradient."""
         if self._transpose is None:
             if self.symmetric:  # samples of source p = sources of sample p
-                self._transpose = (self.neighbors[:, 1].contiguous(), self.ends)
+                src = self.sources if self.sources is not None else self.neighbors[:, 1].contiguous()
+                self._transpose = (src, self.ends)
             else:
                 self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0])
         return self._transpose

@@ -239,26 +239,45 @@ class BQNeighborhood(Neighborhood):
         if self.max_neighbors_ != 0:
             raise NotImplementedError("max_neighbors > 0 (random sub-sampling) is not used by any model path")
         # same call as ops.BallQuery.apply (which stays for code that uses the op directly), without the autograd node --
-        # the edge list carries no gradient -- and keeping the int32 list the native kernels read next to the
-        # int64 ``neighbors_`` the reference exposes
+        # the edge list carries no gradient.  The kernels read the int32 list (``neighbors_i32_``); the int64
+        # ``neighbors_`` the reference exposes is materialised on first access only (33 MB at the headline shape).
+        self.sources_i32_ = None
         if self.capacity_ is not None:
-            nb, self.start_ids_, self.edge_info_ = ops.ball_query_bounded(
-                self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_, self.samples_.batch_ids_, self.radius_,
-                int(self.capacity_), self.pc_src_.num_batches())
+            res = ops.ball_query_bounded(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
+                                         self.samples_.batch_ids_, self.radius_, int(self.capacity_),
+                                         self.pc_src_.num_batches(), want_sources=self.symmetric_)
+            nb, self.start_ids_, self.edge_info_ = res[:3]
+            if self.symmetric_:
+                self.sources_i32_ = res[3]
         else:
             nb, self.start_ids_ = ops.ball_query(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
                                                  self.samples_.batch_ids_, self.radius_, self.pc_src_.num_batches())
         self.neighbors_i32_ = nb
-        self.neighbors_ = nb.to(torch.int64)
+        self._neighbors64 = None
+
+    @property
+    def neighbors_(self):
+        if getattr(self, "_neighbors64", None) is None and getattr(self, "neighbors_i32_", None) is not None:
+            self._neighbors64 = self.neighbors_i32_.to(torch.int64)
+        return self._neighbors64
+
+    @neighbors_.setter
+    def neighbors_(self, value):  # the base class initialises it to None; code may also attach its own list
+        self._neighbors64 = value
+        if value is not None:
+            self.neighbors_i32_ = None
 
     def num_edges(self) -> int:
         """Number of edges as a host integer (one device read-back for a capacity-bounded build)."""
-        if self.edge_info_ is None:
-            return int(self.neighbors_.shape[0])
-        return min(int(self.edge_info_[0]), int(self.capacity_))
+        info = getattr(self, "edge_info_", None)
+        if info is None:
+            nb = self.neighbors_i32_ if getattr(self, "neighbors_i32_", None) is not None else self._neighbors64
+            return int(nb.shape[0])
+        return min(int(info[0]), int(self.capacity_))
 
     def overflowed(self) -> bool:
-        return self.edge_info_ is not None and bool(self.edge_info_[1] != 0)
+        info = getattr(self, "edge_info_", None)
+        return info is not None and bool(info[1] != 0)
 
 
 class KnnNeighborhood(Neighborhood):

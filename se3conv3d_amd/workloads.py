@@ -73,11 +73,11 @@ def build_stack(spec: dict, device, seed: int, n_levels: int = 4) -> List[dict]:
         nbh = hier.create_neighborhood(lvl, lvl, "ball_query", bq_radius=r)
         conv = factory.create_conv_layer(ch, ch).to(device)
         conv.norm_neigh_dist_.fill_(1.0 / r)
-        conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.neighbors_.shape[0], 1))
+        conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.num_edges(), 1))
         n = pc.pts_.shape[0]
         x = torch.randn(n * f, ch, device=device, requires_grad=True)
         g = torch.randn(n * f, ch, device=device)
-        levels.append(dict(pc=pc, nbh=nbh, conv=conv, x=x, g=g, n=n, e=nbh.neighbors_.shape[0], r=r, c=ch, f=f))
+        levels.append(dict(pc=pc, nbh=nbh, conv=conv, x=x, g=g, n=n, e=nbh.num_edges(), r=r, c=ch, f=f))
     return levels
 
 

@@ -44,6 +44,9 @@ def test_bounded_equals_two_phase_and_oracle(amd, n_src, n_dst, batches, r):
     assert info.tolist() == [e, 1]
     assert torch.equal(ends.cpu(), torch.clamp(ends_r, max=cap)) and torch.equal(nb, nb2[:cap])
     del sentinel
+    # the optional dense list of source ids = column 1 of the edge list (the source-major list of a symmetric graph)
+    nb, ends, info, src = amd.ops.ball_query_bounded(*args, capacity=e + 5, n_batches=batches, want_sources=True)
+    assert torch.equal(src[:e], nb2[:, 1]) and torch.equal(nb[:e], nb2)
     nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=0, n_batches=batches)
     assert info.tolist() == [e, 1 if e else 0] and int(ends.max()) == 0
 
