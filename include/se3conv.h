@@ -177,13 +177,17 @@ int se3_ball_query_store(const float* pts_dst, const int32_t* batch_dst, float r
  * On overflow the list is truncated: `ends` are clamped to `capacity`, so consumers never read past the buffer, the
  * first `capacity` edges (sample-major order) are present, and the caller reruns with a larger buffer once it has seen
  * the flag.  Rows [E, capacity) of `neighbors` are left untouched.
+ *   n_batches (host): number of batch elements (0 = unknown); for 1 or 2 the search uses 32-bit cell keys of its own (a
+ *   fixed stride of 1024 cells per dimension instead of the reference's cell-count products: 4 radix passes instead
+ *   of 8 -- only the edge set is defined, and it is the same).
  *   sources [capacity] int32 (optional, may be NULL): column 1 of `neighbors` as a dense array -- for a cloud against
  *   itself the radius graph is symmetric, so this IS the source-major list `t_samples` se3conv_bwd wants (with
  *   `t_ends` = `ends`), written by the same store pass instead of a strided copy afterwards. */
 int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
                            const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells, float radius,
-                           int64_t n_src, int64_t n_dst, void* workspace, size_t workspace_bytes, int64_t capacity,
-                           int32_t* neighbors, int32_t* sources, int32_t* ends, int32_t* info, void* stream);
+                           int64_t n_src, int64_t n_dst, int32_t n_batches, void* workspace, size_t workspace_bytes,
+                           int64_t capacity, int32_t* neighbors, int32_t* sources, int32_t* ends, int32_t* info,
+                           void* stream);
 
 /* Source-major (transposed) copy of an edge list, used by the backward pass in place of the
  * reference's global float atomics on the feature gradient (feat_basis_proj_grads.cu:126,140):

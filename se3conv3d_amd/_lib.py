@@ -52,7 +52,7 @@ SIGNATURES = {
     "se3_ball_query_workspace_bytes": (_SZ, [_I64, _I64]),
     "se3_ball_query_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _SZ, _P, _P]),
     "se3_ball_query_store": (C.c_int, [_P, _P, _F, _I64, _I64, _P, _SZ, _P, _I64, _P, _P]),
-    "se3_ball_query_bounded": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _SZ, _I64, _P, _P, _P, _P, _P]),
+    "se3_ball_query_bounded": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _I32, _P, _SZ, _I64, _P, _P, _P, _P, _P]),
     "se3_csr_transpose_workspace_bytes": (_SZ, [_I64]),
     "se3_csr_transpose": (C.c_int, [_P, _I64, _I64, _P, _SZ, _P, _P, _P]),
     "se3_rot_tensors": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SHP, _P, _P, _P, _P]),

@@ -92,6 +92,63 @@ __global__ void find_ranges_kernel(const float* __restrict__ pts_dst, const int3
   }
 }
 
+// ---- 32-bit keys for the ball query (one or two batch elements) ---------------------------------------------------
+// The reference's key (grid_utils.cuh:79-93) multiplies the true cell counts; how many bits it needs is only known on
+// the device, so the radix sort has to walk all 64 (8 passes over 8-byte keys; at 9 k points those passes are latency:
+// ~10 us each).  The ball query's own keys need not be the reference's -- only the edge SET is defined -- so for
+// n_batches <= 2 they are built with a fixed stride of 1024 cells per dimension: 30 + 1 bits, 4 passes over 4-byte
+// keys.  Cell indices beyond 1023 are clamped to 1023 (points of the far cells share one cell: candidates are a
+// superset there, the distance test decides), so any extent / radius ratio stays exact.
+constexpr int kBq32Cells = 1024;
+__device__ __forceinline__ uint32_t key32_of(const int cell[3], int b) {
+  return ((((uint32_t)b * kBq32Cells + (uint32_t)cell[0]) * kBq32Cells) + (uint32_t)cell[1]) * kBq32Cells + (uint32_t)cell[2];
+}
+__global__ void compute_keys32_kernel(const float* __restrict__ pts, const int32_t* __restrict__ batch_ids,
+                                      const float* __restrict__ aabb_min, const int32_t* __restrict__ num_cells,
+                                      float cell_scalar, int64_t n, uint32_t* __restrict__ keys,
+                                      int32_t* __restrict__ iota) {
+  const int nc[3] = {min(num_cells[0], kBq32Cells), min(num_cells[1], kBq32Cells), min(num_cells[2], kBq32Cells)};
+  const float inv[3] = {1.0f / cell_scalar, 1.0f / cell_scalar, 1.0f / cell_scalar};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int cell[3], b;
+    cell_of(pts, batch_ids, aabb_min, nc, inv, i, cell, b);
+    keys[i] = key32_of(cell, b);
+    iota[i] = (int32_t)i;
+  }
+}
+__device__ __forceinline__ int lower_bound_key32(const uint32_t* __restrict__ keys, int n, uint32_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__global__ void find_ranges32_kernel(const float* __restrict__ pts_dst, const int32_t* __restrict__ batch_dst,
+                                     const float* __restrict__ aabb_min, const int32_t* __restrict__ num_cells,
+                                     float radius, const uint32_t* __restrict__ skeys, int n_src, int64_t n_dst,
+                                     int2* __restrict__ ranges) {
+  const int nc[3] = {min(num_cells[0], kBq32Cells), min(num_cells[1], kBq32Cells), min(num_cells[2], kBq32Cells)};
+  const float inv_r = 1.0f / radius;
+  const float inv[3] = {inv_r, inv_r, inv_r};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst * 9; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = i / 9;
+    const int o = (int)(i - s * 9);
+    int cell[3], b;
+    cell_of(pts_dst, batch_dst, aabb_min, nc, inv, s, cell, b);
+    const int x = cell[0] + o / 3 - 1, y = cell[1] + o % 3 - 1;
+    int2 r = make_int2(0, 0);
+    if (x >= 0 && x < nc[0] && y >= 0 && y < nc[1]) {
+      const int z0 = max(cell[2] - 1, 0), z1 = min(cell[2] + 1, nc[2] - 1);
+      const int c0[3] = {x, y, z0};
+      const uint32_t base = key32_of(c0, b);
+      r.x = lower_bound_key32(skeys, n_src, base);
+      r.y = lower_bound_key32(skeys, n_src, base + (uint32_t)(z1 - z0) + 1u);
+    }
+    ranges[i] = r;
+  }
+}
+
 // One wavefront per sample.  MODE 0: counts[s] = #hits.  MODE 1: neighbors[base + j] = (s, source id) for the j-th hit
 // in candidate order, base from the inclusive offsets `ends`.  MODE 2 (capacity-bounded call): the same, slots at or
 // beyond `limit` dropped, the sample's own offset clamped to `limit` in place (its neighbour reads ends[s-1] either
@@ -462,6 +519,10 @@ BqLayout bq_layout(int64_t n_src, int64_t n_dst) {
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (const int64_t*)nullptr, (int64_t*)nullptr,
                                      (const int32_t*)nullptr, (int32_t*)nullptr, (int)ns);
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, (const int32_t*)nullptr, (int32_t*)nullptr, (int)nd);
+  size_t t_sort32 = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                           (const int32_t*)nullptr, (int32_t*)nullptr, (int)ns);
+  if (t_sort32 > t_sort) t_sort = t_sort32;
   l.temp_bytes = t_sort > t_scan ? t_sort : t_scan;
   l.temp = take(l.temp_bytes);
   l.total = off;
@@ -592,7 +653,7 @@ extern "C" size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst) {
 static int ball_query_count_impl(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
                                  const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
                                  float radius, int64_t n_src, int64_t n_dst, void* workspace,
-                                 size_t workspace_bytes, int32_t* ends, bool skip_scan, void* stream_) {
+                                 size_t workspace_bytes, int32_t* ends, bool skip_scan, int key_bits, void* stream_) {
   if (n_src < 0 || n_dst < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_src >= (1ll << 31) || n_dst >= (1ll << 31) / 9) return SE3_ERR_UNSUPPORTED;
   if (n_dst == 0) return SE3_OK;
@@ -625,18 +686,35 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
   int32_t* counts = (int32_t*)(ws + l.counts);
   size_t temp_bytes = l.temp_bytes;
 
-  if (n_src > 0) {
-    // cell size = radius in every dimension (BallQuery.py:39-40)
-    hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src, aabb_min,
-                       num_cells, (const float*)nullptr, radius, n_src, keys, ids);
-    if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n_src, 0, 64,
-                                           stream) != hipSuccess)
-      return SE3_ERR_LAUNCH;
-    hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, sids, n_src,
-                       spts);
+  // key_bits > 0 (the bounded call, which knows the batch count): 32-bit keys with a fixed cell stride, see key32_of
+  if (key_bits > 0) {
+    uint32_t* keys32 = (uint32_t*)keys;
+    uint32_t* skeys32 = (uint32_t*)skeys;
+    if (n_src > 0) {
+      hipLaunchKernelGGL(compute_keys32_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src,
+                         aabb_min, num_cells, radius, n_src, keys32, ids);
+      if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys32, skeys32, ids, sids, (int)n_src, 0, key_bits,
+                                             stream) != hipSuccess)
+        return SE3_ERR_LAUNCH;
+      hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, sids,
+                         n_src, spts);
+    }
+    hipLaunchKernelGGL(find_ranges32_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
+                       aabb_min, num_cells, radius, skeys32, (int)n_src, n_dst, ranges);
+  } else {
+    if (n_src > 0) {
+      // cell size = radius in every dimension (BallQuery.py:39-40)
+      hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src, aabb_min,
+                         num_cells, (const float*)nullptr, radius, n_src, keys, ids);
+      if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n_src, 0, 64,
+                                             stream) != hipSuccess)
+        return SE3_ERR_LAUNCH;
+      hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, sids, n_src,
+                         spts);
+    }
+    hipLaunchKernelGGL(find_ranges_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
+                       aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges);
   }
-  hipLaunchKernelGGL(find_ranges_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
-                     aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges);
   hipLaunchKernelGGL(scan_candidates_kernel<0>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, stream, pts_dst,
                      1.0f / radius, spts, ranges, n_dst, counts, (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr,
                      (int32_t*)nullptr);
@@ -651,7 +729,7 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
                                     float radius, int64_t n_src, int64_t n_dst, void* workspace,
                                     size_t workspace_bytes, int32_t* ends, void* stream) {
   return ball_query_count_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
-                               workspace, workspace_bytes, ends, false, stream);
+                               workspace, workspace_bytes, ends, false, 0, stream);
 }
 
 // mode 1: two-phase store; 2: bounded (clamp, info, sources); 3: bounded all-pairs with the offsets formed in the kernel
@@ -697,15 +775,19 @@ extern "C" int se3_ball_query_store(const float* pts_dst, const int32_t* batch_d
 
 extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
                                       const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
-                                      float radius, int64_t n_src, int64_t n_dst, void* workspace, size_t workspace_bytes,
-                                      int64_t capacity, int32_t* neighbors, int32_t* sources, int32_t* ends, int32_t* info,
-                                      void* stream) {
+                                      float radius, int64_t n_src, int64_t n_dst, int32_t n_batches, void* workspace,
+                                      size_t workspace_bytes, int64_t capacity, int32_t* neighbors, int32_t* sources,
+                                      int32_t* ends, int32_t* info, void* stream) {
   if (capacity < 0 || capacity >= (1ll << 31) || !info) return SE3_ERR_INVALID_ARGUMENT;
   if (n_dst == 0) return hipMemsetAsync(info, 0, 2 * sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
   if (capacity > 0 && !neighbors) return SE3_ERR_INVALID_ARGUMENT;
   const bool inline_prefix = n_src <= kBqScanAllMax && n_dst <= kBqInlinePrefixMax;
+  // one or two batch elements: 30 + 1 key bits (key32_of; the window's upper bound base + 3 then cannot wrap);
+  // more: the 64-bit keys of the two-phase path
+  int key_bits = 0;
+  if (n_batches >= 1 && n_batches <= 2) key_bits = 30 + (n_batches > 1 ? 1 : 0);
   if (int rc = ball_query_count_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
-                                     workspace, workspace_bytes, ends, inline_prefix, stream))
+                                     workspace, workspace_bytes, ends, inline_prefix, key_bits, stream))
     return rc;
   // one store launch also clamps the offsets to the buffer and records total + overflow flag
   return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes, ends, neighbors,

@@ -215,7 +215,7 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
     _lib.check(lib.se3_ball_query_bounded(
         _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
         _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius), n_src,
-        n_dst, C.c_void_p(ws.data_ptr()), ws.numel(), int(capacity), _ptr(neighbors, i32, "neighbors"),
+        n_dst, int(n_batches or 0), C.c_void_p(ws.data_ptr()), ws.numel(), int(capacity), _ptr(neighbors, i32, "neighbors"),
         _ptr(sources, i32, "sources"), _ptr(ends, i32, "ends"), _ptr(info, i32, "info"), _stream(dev)),
         "se3_ball_query_bounded")
     return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)

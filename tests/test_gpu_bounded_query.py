@@ -20,7 +20,14 @@ def amd(built_library):
     return amd
 
 
-@pytest.mark.parametrize("n_src,n_dst,batches,r", [(6000, 1500, 3, 0.09), (1500, 2500, 2, 0.12), (40, 500, 1, 0.4)])
+@pytest.mark.parametrize("n_src,n_dst,batches,r", [
+    (6000, 1500, 3, 0.09),      # grid search, 64-bit keys (more than two batch elements)
+    (6000, 1500, 2, 0.09),      # grid search, 32-bit keys with the fixed cell stride
+    (5000, 5000, 1, 0.0007),    # 1400 cells per axis: indices beyond 1023 are clamped, the edge set must not change
+    (9000, 9000, 1, 0.05),
+    (1500, 2500, 2, 0.12),      # all-pairs search, offsets formed inside the store kernel
+    (1500, 6000, 1, 0.12),      # all-pairs search, more samples than the inline prefix takes: scan launch
+    (40, 500, 1, 0.4)])
 def test_bounded_equals_two_phase_and_oracle(amd, n_src, n_dst, batches, r):
     g = torch.Generator().manual_seed(n_src)
     ps, pd = torch.rand(n_src, 3, generator=g), torch.rand(n_dst, 3, generator=g)
