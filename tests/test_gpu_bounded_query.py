@@ -31,6 +31,8 @@ def amd(built_library):
 def test_bounded_equals_two_phase_and_oracle(amd, n_src, n_dst, batches, r):
     g = torch.Generator().manual_seed(n_src)
     ps, pd = torch.rand(n_src, 3, generator=g), torch.rand(n_dst, 3, generator=g)
+    if r < 0.01:
+        pd = ps.clone()      # a cloud against itself: at least the self edges exist whatever the radius
     bs = torch.sort(torch.randint(0, batches, (n_src,), generator=g, dtype=torch.int32)).values
     bd = torch.sort(torch.randint(0, batches, (n_dst,), generator=g, dtype=torch.int32)).values
     bs[-1] = batches - 1
