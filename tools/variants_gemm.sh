@@ -1,4 +1,5 @@
 set -u
+export SE3_LIB_SUFFIX=_ab  # variant builds go to lib/libse3conv_hip_ab.so (se3conv3d_amd/build.py): the shipped library is never overwritten
 run() {
   SE3_CXXFLAGS="$1" python -m se3conv3d_amd.build --force > /dev/null 2>&1
   for i in 1 2; do
@@ -7,4 +8,3 @@ run() {
 }
 run "-DSE3_GEMM_REVERSE=0"
 run "-DSE3_GEMM_REVERSE=1"
-python -m se3conv3d_amd.build --force > /dev/null 2>&1

@@ -1,5 +1,6 @@
 # A/B of edge-kernel build variants on one box (run through gpurun): two bench runs per variant.
 set -u
+export SE3_LIB_SUFFIX=_ab  # variant builds go to lib/libse3conv_hip_ab.so (se3conv3d_amd/build.py): the shipped library is never overwritten
 run() {
   SE3_CXXFLAGS="$1" python -m se3conv3d_amd.build --force > /dev/null 2>&1
   for i in 1 2; do
@@ -7,4 +8,3 @@ run() {
   done
 }
 for v in "$@"; do run "$v"; done
-python -m se3conv3d_amd.build --force > /dev/null 2>&1
