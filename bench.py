@@ -206,7 +206,7 @@ def run_rank(args):
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     from se3conv3d_amd import workloads as W
-    from se3conv3d_amd.sharding import gather_scene_results, job_throughput, shard_scenes
+    from se3conv3d_amd.sharding import gather_scene_results, job_throughput, shard_scenes  # gather: dry run only
 
     spec = W.WORKLOADS[args.workload]
     n0 = spec["points"] * spec["clouds"]
@@ -378,12 +378,21 @@ def run_rank(args):
             result["fp32_mode"] = {"ms_per_step": round(ms32, 4), "value": mpts(ms32), "unit": "Mpoints/s",
                                    "note": "same stack with every contraction on v_mfma_f32_32x32x2_f32 (exact fp32 products)"}
 
-    # the "trivial result gather": one checksum of the level-0 output per scene, to rank 0
+    # the "trivial result gather": one checksum of the level-0 output per scene.  A fixed-size record per rank, so it
+    # travels as one tensor all-gather (RCCL over xGMI; gloo in the rehearsal) rather than through pickled objects.
     with torch.no_grad():
         lv = levels[0]
         out0 = lv["conv"](p_pc_in=lv["pc"], p_pc_out=lv["pc"], p_in_features=lv["x"], p_neighborhood=lv["nbh"])
-        sums = gather_scene_results({my_scenes[0]: out0.double().sum().reshape(1)}, dist, dst=0)
+        rec = torch.stack((torch.tensor(float(my_scenes[0]), dtype=torch.float64, device=device), out0.double().sum()))
+        if dist is not None:
+            rec = rec.to(reduce_device)
+            parts = [torch.empty_like(rec) for _ in range(world)]
+            dist.all_gather(parts, rec)
+        else:
+            parts = [rec]
+        sums = {int(p[0].item()): float(p[1].item()) for p in parts}
     if rank == 0:
+        assert sorted(sums) == list(range(world)), "every scene exactly once"
         result["scene_checksums"] = {str(k): round(float(v), 6) for k, v in sorted(sums.items())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
