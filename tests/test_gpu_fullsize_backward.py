@@ -184,3 +184,25 @@ def test_dfaust_f2_batch_against_oracle(amd):
                                   cpu(conv.norm_neigh_dist_), cpu(conv.norm_num_neighs_), g.cpu())
     for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), got, ref):
         assert rel_err(u, v) < tol(amd), (name, rel_err(u, v))
+
+
+def test_cloud_beyond_4gib_of_row_tensors(amd):
+    """300 000 points x 2 frames: the row-sized intermediates (600 k rows x 2048 values) pass 4 GiB, which takes the
+    kernels off their 32-bit-offset fast paths (3-byte rows, buffer addressing with 32-bit offsets).  Size-independent
+    checks: a source slice of dX and masked parameter gradients against the oracle, the adjoint identity."""
+    if amd.get_precision() != "bf16x3":
+        pytest.skip("one arithmetic mode is enough for the addressing paths (fp32 mode needs 2x the time)")
+    torch.manual_seed(4)
+    n, f = 300000, 2
+    pc = amd.pc.PointcloudRotEquiv(torch.rand(n, 3, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV),
+                                   {"pca": False, "n_frames": f, "fixed_axis": False})
+    r = radius_for_degree(n, 16)
+    nbh, conv, x, g = make_layer(amd, pc, r, 64, 64, seed=40)
+    grads = gpu_backward(conv, pc, nbh, x, g)
+    assert all(bool(torch.isfinite(t).all()) for t in grads)
+    check_dx_slice(amd, pc, nbh, conv, x, g, grads[1], n - 40, 40)
+    check_dx_slice(amd, pc, nbh, conv, x, g, grads[1], 150001, 32)
+    check_param_grads_masked(amd, pc, nbh, conv, x, g, torch.cat((torch.arange(n - 24, n), torch.randperm(n)[:40])).unique())
+    lhs = float((grads[0].double() * g.double()).sum())
+    rhs = float((x.double() * grads[1].double()).sum())
+    assert abs(lhs - rhs) <= tol(amd) * max(abs(lhs), abs(rhs), 1.0)
