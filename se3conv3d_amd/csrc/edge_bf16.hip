@@ -735,8 +735,12 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // a wave-private LDS image (CH16 * 4 KB per wavefront; in registers they cost CH16 * 16 VGPRs and spilled),
 // hence 512-thread blocks: 8 wavefronts share the CU's LDS at the same 2 waves/SIMD as before.
 // ------------------------------------------------------------------------------------------------
-template <int CH16, int NFR>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
-__global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+// PAIR (round 2, two frames only): a 128-thread workgroup = two wavefronts share ONE item -- one grad_T image (16 KB
+// instead of 16 KB per wavefront: 26 KB of LDS per workgroup, 6 workgroups = 3 wavefronts per SIMD instead of 2),
+// wavefront v builds the image of frame v (32 of the 64 row loads) and takes the chunks v, v + 2, ... of the item for
+// both frames; two workgroup barriers per item (image built / image free), partial sums folded per workgroup.
+template <int CH16, int NFR, bool PAIR = false>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
+__global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), (NFR == 2 && !PAIR) ? 2 : 3) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                          int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
                                                                          const float* __restrict__ rho_p,
@@ -747,17 +751,21 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
   // d[A;beta], is linear in the channel sum, so every channel block contributes an independent partial; each block
   // row recomputes the descriptors and GELU').  row_ch = channels per row (a multiple of 16).
   // wavefronts per block: the gT images (8 KB per frame and wavefront) bound the occupancy
-  constexpr int NW = NFR == 2 ? 8 : 4;
+  static_assert(!PAIR || NFR == 2, "the pair form shares the two frames of a point");
+  constexpr int NW = PAIR ? 2 : (NFR == 2 ? 8 : 4);
+  constexpr int NIMG = PAIR ? 1 : NW;        // grad_T images per workgroup
+  constexpr int CSTEP = PAIR ? 64 : 32;      // frame-edges between two chunks of one wavefront
   const int c_off = 64 * (int)blockIdx.y;
   const int row_bytes = row_ch * 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][2][64][4];
   // descriptor image for the d[A;beta] product: hi / lo bf16 planes, row = frame-edge, 12 columns ([desc(9), 1, 0, 0]).
   // Its MFMA fragments have the K index over the rows: read with ds_read_b64_tr_b16 (common.h), 4 per (frame, k-step).
   __shared__ __attribute__((aligned(16))) uint16_t lds_desc[NW][NFR][2][32][12];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NW][NFR][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
-  // the final block reduction reuses the gT image (NW * 10 * 32 floats <= NW * CH16 * 1024 words)
+  __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NIMG][NFR][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
+  // the final block reduction reuses the gT image (NW * 10 * 32 floats <= NIMG * NFR * CH16 * 512 words)
   float(*lds_red)[kDescExt][kBasis] = reinterpret_cast<float(*)[kDescExt][kBasis]>(&lds_gt[0][0][0][0][0][0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int img = PAIR ? 0 : wave;  // which grad_T image this wavefront reads
   const int kcol = lane & 31, h = lane >> 5;
   if (threadIdx.x < 64) mlp_weights_to_lds<NFR>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
@@ -773,14 +781,16 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
 #ifndef SE3_PG_REVERSE
 #define SE3_PG_REVERSE 1
 #endif
-  for (int64_t item_f = (int64_t)blockIdx.x * NW + wave; item_f < n_items; item_f += (int64_t)gridDim.x * NW) {
+  for (int64_t item_f = PAIR ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * NW + wave; item_f < n_items;
+       item_f += PAIR ? (int64_t)gridDim.x : (int64_t)gridDim.x * NW) {
     const int64_t item = SE3_PG_REVERSE ? n_items - 1 - item_f : item_f;
     const int groups = g.f_ctr / NFR;
     const int64_t ctr = item / groups;
     const int a0 = (int)(item - ctr * groups) * NFR;
     const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
     const int n_total = (g.ends[ctr] - start) * g.f_nb;
-    if (n_total == 0) continue;
+    if (n_total == 0) continue;  // uniform over the workgroup in the pair form: both wavefronts skip the item's barriers
+    const int c_first = PAIR ? 32 * wave : 0;  // this wavefront's first chunk
     float yc[3], rc[9];
     load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (NFR == 2 ? h : 0)), yc, rc);
 
@@ -794,35 +804,40 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
       const int fe = min(c0 + kcol, n_total - 1);
       return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
     };
-    const int nb_a = nbr_of(0);
-    int nb_b = nbr_of(32);
+    const int nb_a = nbr_of(c_first);
+    int nb_b = nbr_of(c_first + CSTEP);
 
     // gT fragments (MFMA B operand) of the item's two rows: lane (k = kcol, h) holds channels 16*st + 8h + j
-    uint32_t gw[NFR][CH16][8];
+    // (pair form: this wavefront fetches and builds the image of frame `wave` only)
+    constexpr int NBUILD = PAIR ? 1 : NFR;
+    uint32_t gw[NBUILD][CH16][8];
 #pragma unroll
-    for (int a = 0; a < NFR; ++a) {
+    for (int ab = 0; ab < NBUILD; ++ab) {
+      const int a = PAIR ? wave : ab;
       const uint32_t* gt_row = grad_t + ((item * NFR + a) * (int64_t)row_ch + c_off) * kBasis;
 #pragma unroll
       for (int st = 0; st < CH16; ++st)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          gw[a][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
-                         : (c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u);
+          gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
+                          : (c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u);
     }
-    int q_a = row_of(nb_a, 0);
+    int q_a = row_of(nb_a, c_first);
     float xn_nx[3], rn_nx[9];
     load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
 #pragma unroll
-    for (int a = 0; a < NFR; ++a)
+    for (int ab = 0; ab < NBUILD; ++ab)
 #pragma unroll
       for (int st = 0; st < CH16; ++st) {
+        const int a = PAIR ? wave : ab;
         u32x4 f_hi, f_lo;
-        frags_from_words(gw[a][st], f_hi, f_lo);
-        *reinterpret_cast<u32x4*>(&lds_gt[wave][a][st][0][lane][0]) = f_hi;
-        *reinterpret_cast<u32x4*>(&lds_gt[wave][a][st][1][lane][0]) = f_lo;
+        frags_from_words(gw[ab][st], f_hi, f_lo);
+        *reinterpret_cast<u32x4*>(&lds_gt[img][a][st][0][lane][0]) = f_hi;
+        *reinterpret_cast<u32x4*>(&lds_gt[img][a][st][1][lane][0]) = f_lo;
       }
+    if (PAIR) __syncthreads();  // both frames' images are in place
 
-    for (int c0 = 0; c0 < n_total; c0 += 32) {
+    for (int c0 = c_first; c0 < n_total; c0 += CSTEP) {
       const int cnt = min(32, n_total - c0);
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;
@@ -831,8 +846,8 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
 #pragma unroll
       for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-      const int q_b = row_of(nb_b, c0 + 32);
-      nb_b = nbr_of(c0 + 64);
+      const int q_b = row_of(nb_b, c0 + CSTEP);
+      nb_b = nbr_of(c0 + 2 * CSTEP);
 
       // gathered feature rows (MFMA A operand of gphi): lane (n = kcol, h) reads its own source row; the words are
       // turned into fragments only after the GELU' work below
@@ -922,8 +937,8 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
         f32x16 gphi = zero16();
 #pragma unroll
         for (int st = 0; st < CH16; ++st) {
-          const u32x4 bg_hi = *reinterpret_cast<const u32x4*>(&lds_gt[wave][a][st][0][lane][0]);
-          const u32x4 bg_lo = *reinterpret_cast<const u32x4*>(&lds_gt[wave][a][st][1][lane][0]);
+          const u32x4 bg_hi = *reinterpret_cast<const u32x4*>(&lds_gt[img][a][st][0][lane][0]);
+          const u32x4 bg_lo = *reinterpret_cast<const u32x4*>(&lds_gt[img][a][st][1][lane][0]);
           gphi = mfma_bf16x3(fa_hi[st], fa_lo[st], bg_hi, bg_lo, gphi);
         }
 #pragma unroll
@@ -950,6 +965,7 @@ __global__ __launch_bounds__(NFR == 2 ? 512 : 256, NFR == 2 ? 2 : 3) void edge_p
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    if (PAIR) __syncthreads();  // both wavefronts are done with the images before the next item overwrites them
   }
 
   // dacc: rows = k (acc_row(r,h)), columns = descriptor dim j = kcol (only j < 10 are meaningful)
@@ -1154,8 +1170,36 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
     const bool two = g.f_ctr % 2 == 0 && !force_single;
     const int64_t items = two ? rows / 2 : rows;
     const int blocks_y = edge_param_grad_bf16_channel_blocks(channels);
-    *n_used = n_partials * blocks_y;
-    const dim3 grid((unsigned)n_partials, (unsigned)blocks_y);
+    // pair form (two wavefronts share an item and its grad_T image, 3 wavefronts per SIMD): SE3_PG_PAIR=0 turns it off
+    static const bool pair_on = [] {
+      const char* e = getenv("SE3_PG_PAIR");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    if (pair_on && two && channels >= 64) {
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      static const int per_cu = [] {
+        const char* e = getenv("SE3_PG_PAIR_WGS");
+        return e ? atoi(e) : 6;  // 26 KB of LDS per workgroup
+      }();
+      int64_t wgs = (int64_t)n_cu * per_cu;
+      if (wgs > n_partials) wgs = n_partials;
+      if (wgs > items) wgs = items;
+      if (wgs < 1) wgs = 1;
+      *n_used = (int)wgs * blocks_y;
+      const dim3 pgrid((unsigned)wgs, (unsigned)blocks_y);
+      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
+                         feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+      return check_launch();
+    }
+    const int n_blocks = n_partials < 512 ? n_partials : 512;  // the 512-thread form: one workgroup per CU and round
+    *n_used = n_blocks * blocks_y;
+    const dim3 grid((unsigned)n_blocks, (unsigned)blocks_y);
 #define SE3_PG(CH16)                                                                                                      \
   do {                                                                                                                    \
     if (two)                                                                                                              \

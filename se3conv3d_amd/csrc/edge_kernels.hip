@@ -283,9 +283,11 @@ int launch_edge_t(const char* tag, const EdgeGeom& g, const float* feat, int cha
 
 // Blocks of the (persistent) parameter-gradient kernels = partial results to reduce: two per CU; 2048 measured 3 %
 // slower, 4096 11 % slower at the headline shape.
+// slots of partial sums the parameter-gradient kernels may use: up to 2048 workgroups (the pair form of the split-bf16
+// kernel keeps 6 x 256 resident; the other forms use at most 512 of them)
 int edge_param_grad_blocks(int64_t rows) {
   const int64_t want = (rows + 3) / 4;
-  return (int)(want < 512 ? (want > 0 ? want : 1) : 512);
+  return (int)(want < 2048 ? (want > 0 ? want : 1) : 2048);
 }
 
 int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat, int channels,
