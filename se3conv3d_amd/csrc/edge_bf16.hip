@@ -735,12 +735,18 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // a wave-private LDS image (CH16 * 4 KB per wavefront; in registers they cost CH16 * 16 VGPRs and spilled),
 // hence 512-thread blocks: 8 wavefronts share the CU's LDS at the same 2 waves/SIMD as before.
 // ------------------------------------------------------------------------------------------------
+#ifndef SE3_PG_PAIR_WAVES
+#define SE3_PG_PAIR_WAVES 3  // wavefronts per SIMD the pair form's register budget is set for
+#endif
+#ifndef SE3_PG_SEQ
+#define SE3_PG_SEQ 0  // 1: the two frames of a chunk one after the other (GELU' of one frame live at a time: fewer VGPRs)
+#endif
 // PAIR (round 2, two frames only): a 128-thread workgroup = two wavefronts share ONE item -- one grad_T image (16 KB
 // instead of 16 KB per wavefront: 26 KB of LDS per workgroup, 6 workgroups = 3 wavefronts per SIMD instead of 2),
 // wavefront v builds the image of frame v (32 of the 64 row loads) and takes the chunks v, v + 2, ... of the item for
 // both frames; two workgroup barriers per item (image built / image free), partial sums folded per workgroup.
 template <int CH16, int NFR, bool PAIR = false>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
-__global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), (NFR == 2 && !PAIR) ? 2 : 3) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+__global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_PAIR_WAVES : (NFR == 2 ? 2 : 3)) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                          int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
                                                                          const float* __restrict__ rho_p,
@@ -904,10 +910,10 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), (NFR == 2 && !
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      // GELU' of both frames first (pure VALU, covers the gather latency) ...
-      float dyv[NFR][16];
-#pragma unroll
-      for (int a = 0; a < NFR; ++a) {
+      // this lane's address for the transposed reads: row (lane >> 2) & 3 of a 4-row block, columns 4 (lane & 3)
+      // (the image has 12 columns: the last quad points at columns 8..11 again, what it returns lands in unused columns)
+      const int tr_row = (lane >> 2) & 3, tr_col = min((lane & 3) * 4, 8);
+      auto gelu_grad_of_frame = [&](int a, float (&dy)[16]) {
         const bool dims07 = NFR == 2 ? h == a : h == 0;
         u32x4 a_hi, a_lo;
 #pragma unroll
@@ -921,19 +927,12 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), (NFR == 2 && !
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float y;
-          if (SE3_PG_ABLATE & 1) dyv[a][r] = pre[r];
-          else gelu_scaled_grad(pre[r], y, dyv[a][r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
+          if (SE3_PG_ABLATE & 1) dy[r] = pre[r];
+          else gelu_scaled_grad(pre[r], y, dy[r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
         }
-      }
-      // ... then gphi = F gT on the gathered rows, gpre = gphi * GELU', and the d[A;beta] product
-      u32x4 fa_hi[CH16], fa_lo[CH16];
-#pragma unroll
-      for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
-      // this lane's address for the transposed reads: row (lane >> 2) & 3 of a 4-row block, columns 4 (lane & 3)
-      // (the image has 12 columns: the last quad points at columns 8..11 again, what it returns lands in unused columns)
-      const int tr_row = (lane >> 2) & 3, tr_col = min((lane & 3) * 4, 8);
-#pragma unroll
-      for (int a = 0; a < NFR; ++a) {
+      };
+      // gphi = F gT on the gathered rows, gpre = gphi * GELU', and the d[A;beta] product of frame a
+      auto accumulate_frame = [&](int a, const u32x4 (&fa_hi)[CH16], const u32x4 (&fa_lo)[CH16], const float (&dy)[16]) {
         f32x16 gphi = zero16();
 #pragma unroll
         for (int st = 0; st < CH16; ++st) {
@@ -945,13 +944,13 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), (NFR == 2 && !
         for (int s = 0; s < 2; ++s) {
           if (SE3_PG_ABLATE & 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dacc[j] += gphi[8 * s + j] * dyv[a][8 * s + j];
+            for (int j = 0; j < 8; ++j) dacc[j] += gphi[8 * s + j] * dy[8 * s + j];
             continue;
           }
           if (s * 16 < cnt) {
             float gp[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) gp[j] = gphi[8 * s + j] * dyv[a][8 * s + j];
+            for (int j = 0; j < 8; ++j) gp[j] = gphi[8 * s + j] * dy[8 * s + j];
             u32x4 ga_hi, ga_lo;
             frags_from_floats(gp, ga_hi, ga_lo);
             // K slot (h, j) of this k-step is frame-edge acc_row(8 s + j, h) = 16 s + 4 h + (j & 3) + 8 (j >> 2)
@@ -961,7 +960,32 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), (NFR == 2 && !
             dacc = mfma_bf16x3(ga_hi, ga_lo, db_hi, db_lo, dacc);
           }
         }
+      };
+      u32x4 fa_hi[CH16], fa_lo[CH16];
+#if SE3_PG_SEQ
+      // one frame at a time: GELU' of frame 0 (pure VALU, covers the gather latency), the gathered words become
+      // fragments, frame 0 is accumulated; then the same for frame 1 -- 16 instead of 32 GELU' values live
+#pragma unroll
+      for (int a = 0; a < NFR; ++a) {
+        float dy[16];
+        gelu_grad_of_frame(a, dy);
+        if (a == 0) {
+#pragma unroll
+          for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
+        }
+        accumulate_frame(a, fa_hi, fa_lo, dy);
       }
+#else
+      // GELU' of both frames first (pure VALU, covers the gather latency) ...
+      float dyv[NFR][16];
+#pragma unroll
+      for (int a = 0; a < NFR; ++a) gelu_grad_of_frame(a, dyv[a]);
+      // ... then the gathered words become fragments and both frames are accumulated
+#pragma unroll
+      for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
+#pragma unroll
+      for (int a = 0; a < NFR; ++a) accumulate_frame(a, fa_hi, fa_lo, dyv[a]);
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
