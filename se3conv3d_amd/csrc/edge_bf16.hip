@@ -738,6 +738,9 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 #ifndef SE3_PG_PAIR_WAVES
 #define SE3_PG_PAIR_WAVES 3  // wavefronts per SIMD the pair form's register budget is set for
 #endif
+#ifndef SE3_PG_SINGLE_WAVES
+#define SE3_PG_SINGLE_WAVES 4  // one frame per wavefront (odd F): 111-125 VGPRs when asked for 4 waves per SIMD, and with the
+#endif                         // MLP weights in one arrangement 40 KB of LDS per 4-wave workgroup = 4 per CU (48 channels: 3)
 #ifndef SE3_PG_SEQ
 #define SE3_PG_SEQ 0  // 1: the two frames of a chunk one after the other (GELU' of one frame live at a time: fewer VGPRs)
 #endif
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // wavefront v builds the image of frame v (32 of the 64 row loads) and takes the chunks v, v + 2, ... of the item for
 // both frames; two workgroup barriers per item (image built / image free), partial sums folded per workgroup.
 template <int CH16, int NFR, bool PAIR = false>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
-__global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_PAIR_WAVES : (NFR == 2 ? 2 : 3)) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
+__global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_PAIR_WAVES : (NFR == 2 ? 2 : (CH16 == 3 ? 3 : SE3_PG_SINGLE_WAVES))) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                          int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
                                                                          const float* __restrict__ rho_p,
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
   constexpr int CSTEP = PAIR ? 64 : 32;      // frame-edges between two chunks of one wavefront
   const int c_off = 64 * (int)blockIdx.y;
   const int row_bytes = row_ch * 4;
-  __shared__ __attribute__((aligned(16))) uint32_t lds_w[2][2][64][4];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[NFR][2][64][4];
   // descriptor image for the d[A;beta] product: hi / lo bf16 planes, row = frame-edge, 12 columns ([desc(9), 1, 0, 0]).
   // Its MFMA fragments have the K index over the rows: read with ds_read_b64_tr_b16 (common.h), 4 per (frame, k-step).
   __shared__ __attribute__((aligned(16))) uint16_t lds_desc[NW][NFR][2][32][12];
