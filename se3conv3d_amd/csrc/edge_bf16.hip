@@ -739,8 +739,8 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 #define SE3_PG_PAIR_WAVES 3  // wavefronts per SIMD the pair form's register budget is set for
 #endif
 #ifndef SE3_PG_SINGLE_WAVES
-#define SE3_PG_SINGLE_WAVES 4  // one frame per wavefront (odd F): 111-125 VGPRs when asked for 4 waves per SIMD, and with the
-#endif                         // MLP weights in one arrangement 40 KB of LDS per 4-wave workgroup = 4 per CU (48 channels: 3)
+#define SE3_PG_SINGLE_WAVES 3  // one frame per wavefront (odd F).  4 (40 KB of LDS per 4-wave workgroup = 4 per CU) was measured:
+#endif                         // at 128 VGPRs the 64-channel form spills 11 registers and runs 0.65 instead of 0.47 ms (ScanNet-like)
 #ifndef SE3_PG_SEQ
 #define SE3_PG_SEQ 0  // 1: the two frames of a chunk one after the other (GELU' of one frame live at a time: fewer VGPRs)
 #endif
