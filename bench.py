@@ -92,7 +92,9 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a helper thread of the process (the RCCL watchdog of an N-rank run) may touch the runtime
+        # while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             fn(levels)
 
     def __call__(self):
@@ -264,7 +266,7 @@ def run_rank(args):
 
     lib = _lib.load()
     amd.set_precision(args.precision)
-    levels = W.build_stack(spec, device, seed=my_scenes[0])
+    levels = W.build_stack(spec, device, seed=my_scenes[0], order=args.point_order)
     frames = spec["frames"]
 
     def barrier():
@@ -285,7 +287,19 @@ def run_rank(args):
         _, dt = job_throughput(float(n0 * steps), dt, dist, reduce_device)  # MAX over ranks
         return dt
 
-    run_stack = (lambda: step(levels)) if args.no_graph else GraphedStep(levels)
+    launch = "eager" if args.no_graph else "hipGraph replay of the captured step"
+    if args.no_graph:
+        run_stack = lambda: step(levels)
+    else:
+        try:
+            run_stack = GraphedStep(levels)
+        except RuntimeError as exc:
+            if world == 1:
+                raise
+            # an N-rank run must not die on a capture refused next to a live process group: this rank launches eagerly
+            torch.cuda.synchronize()
+            run_stack = lambda: step(levels)
+            launch = f"eager on rank {rank} (graph capture failed: {str(exc)[:120]})"
     dt_stack = timed(run_stack, args.steps, args.warmup)
     ms_step = dt_stack / args.steps * 1e3
     mpts = lambda ms: round(n0 * world / (ms * 1e-3) / 1e6, 3)
@@ -298,8 +312,8 @@ def run_rank(args):
                    "n_points": n0, "clouds_per_gpu": spec["clouds"], "k": spec["degree"], "frames": frames,
                    "channels": spec["widths"], "num_basis": W.NUM_BASIS,
                    "level_points": [lv["n"] for lv in levels], "level_edges": [lv["e"] for lv in levels],
-                   "mean_degree_level0": round(levels[0]["e"] / levels[0]["n"], 2),
-                   "launch": "eager" if args.no_graph else "hipGraph replay of the captured step",
+                   "mean_degree_level0": round(levels[0]["e"] / levels[0]["n"], 2), "point_order": args.point_order,
+                   "launch": launch,
                    "sharding": "one scene per rank, no data-path collective" + (" (REHEARSAL: ranks share GPUs)" if args.share_gpu else "")},
     }
 
@@ -409,6 +423,8 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="headline", choices=["headline", "scannet150k_f1", "dfaust_f2", "dfaust_f4"])
+    ap.add_argument("--point-order", default="random", choices=["random", "morton"],
+                    help="row order of the synthetic points: as drawn, or sorted along a Z-order curve per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")

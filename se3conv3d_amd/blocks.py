@@ -3,7 +3,7 @@ batch ids, the residual connection with its learned gain, the point-cloud batch 
 the reference's attribute names so that a reference ``state_dict`` loads key for key.  On GPU tensors the row-wise
 passes run as the library's fused kernels (csrc/glue.hip through ops.BatchNormTrain / SkipDropPath / BiasGelu): training
 batch norm in 3 launches each way, skip + layer scale + drop-path gate in one, bias + GELU behind a bias-free GEMM in
-one -- 11 launches forward for a block's glue instead of ~25 torch ones; the dense C x C products stay rocBLAS GEMMs.
+one (timings per block: profiles/r02_block_glue_timing.txt); the dense C x C products stay rocBLAS GEMMs.
 ``FUSED = False`` (or SE3_BLOCKS_FUSED=0) keeps the plain torch formulation (the A/B of tools/time_block.py).
 
   DropPathPC      layers/DropPathPC.py:30-46      one keep / drop decision per batch element, scaled by 1 / keep_prob

@@ -735,8 +735,14 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // a wave-private LDS image (CH16 * 4 KB per wavefront; in registers they cost CH16 * 16 VGPRs and spilled),
 // hence 512-thread blocks: 8 wavefronts share the CU's LDS at the same 2 waves/SIMD as before.
 // ------------------------------------------------------------------------------------------------
+#ifndef SE3_PG_PAIR_LEAN
+#define SE3_PG_PAIR_LEAN 0  // 1: pair form on 19 KB of LDS (8 workgroups = 4 wavefronts per SIMD): MLP weights in registers, ONE
+#endif                      // descriptor image per wavefront used by the two frames in turn, centre record re-read per chunk, next
+                            // geometry fetched between the frames -- what it takes to fit 128 VGPRs.  Measured (r02_param_grad_lean_ab):
+                            // 0.454 ms at 8 per CU against 0.446 for the 26 KB form at 6; at equal occupancy (6) the lean chunk is
+                            // 18 % slower (0.528), which the fourth wavefront only just buys back.  Parity-green, off.
 #ifndef SE3_PG_PAIR_WAVES
-#define SE3_PG_PAIR_WAVES 3  // wavefronts per SIMD the pair form's register budget is set for
+#define SE3_PG_PAIR_WAVES (SE3_PG_PAIR_LEAN ? 4 : 3)  // wavefronts per SIMD the pair form's register budget is set for
 #endif
 #ifndef SE3_PG_SINGLE_WAVES
 #define SE3_PG_SINGLE_WAVES 3  // one frame per wavefront (odd F).  4 (40 KB of LDS per 4-wave workgroup = 4 per CU) was measured:
@@ -761,23 +767,31 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
   // row recomputes the descriptors and GELU').  row_ch = channels per row (a multiple of 16).
   // wavefronts per block: the gT images (8 KB per frame and wavefront) bound the occupancy
   static_assert(!PAIR || NFR == 2, "the pair form shares the two frames of a point");
+  constexpr bool LEAN = PAIR && SE3_PG_PAIR_LEAN;
   constexpr int NW = PAIR ? 2 : (NFR == 2 ? 8 : 4);
   constexpr int NIMG = PAIR ? 1 : NW;        // grad_T images per workgroup
   constexpr int CSTEP = PAIR ? 64 : 32;      // frame-edges between two chunks of one wavefront
   const int c_off = 64 * (int)blockIdx.y;
   const int row_bytes = row_ch * 4;
-  __shared__ __attribute__((aligned(16))) uint32_t lds_w[NFR][2][64][4];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[LEAN ? 1 : NFR][LEAN ? 1 : 2][LEAN ? 1 : 64][4];  // LEAN: in registers
   // descriptor image for the d[A;beta] product: hi / lo bf16 planes, row = frame-edge, 12 columns ([desc(9), 1, 0, 0]).
   // Its MFMA fragments have the K index over the rows: read with ds_read_b64_tr_b16 (common.h), 4 per (frame, k-step).
-  __shared__ __attribute__((aligned(16))) uint16_t lds_desc[NW][NFR][2][32][12];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_desc[NW][LEAN ? 1 : NFR][2][32][12];
   __shared__ __attribute__((aligned(16))) uint32_t lds_gt[NIMG][NFR][CH16][2][64][4];  // [wave][row][step][hi/lo][lane]
   // the final block reduction reuses the gT image (NW * 10 * 32 floats <= NIMG * NFR * CH16 * 512 words)
   float(*lds_red)[kDescExt][kBasis] = reinterpret_cast<float(*)[kDescExt][kBasis]>(&lds_gt[0][0][0][0][0][0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int img = PAIR ? 0 : wave;  // which grad_T image this wavefront reads
   const int kcol = lane & 31, h = lane >> 5;
-  if (threadIdx.x < 64) mlp_weights_to_lds<NFR>(lds_w, axes_ext, threadIdx.x);
-  __syncthreads();
+  // MLP weights [A; beta] as the MFMA B operand.  LEAN: arrangement 0 (lane half 0 holds descriptor dims 0..7, half 1
+  // dims 8, 9) lives in 8 registers; frame 1 wants the halves exchanged, one v_permlane32_swap per register and chunk
+  u32x4 w_hi = {0u, 0u, 0u, 0u}, w_lo = {0u, 0u, 0u, 0u};
+  if (LEAN) {
+    load_mlp_weights(axes_ext, kcol, h, w_hi, w_lo);
+  } else {
+    if (threadIdx.x < 64) mlp_weights_to_lds<NFR>(reinterpret_cast<uint32_t(*)[2][64][4]>(&lds_w[0][0][0][0]), axes_ext, threadIdx.x);
+    __syncthreads();
+  }
   const float rho = *rho_p;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
   const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
@@ -801,7 +815,8 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     if (n_total == 0) continue;  // uniform over the workgroup in the pair form: both wavefronts skip the item's barriers
     const int c_first = PAIR ? 32 * wave : 0;  // this wavefront's first chunk
     float yc[3], rc[9];
-    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (NFR == 2 ? h : 0)), yc, rc);
+    const int ctr_row = (int)(ctr * g.f_ctr + a0 + (NFR == 2 ? h : 0));
+    if (!LEAN) load_geom_record(ctrg_rs, ctr_row, yc, rc);  // LEAN: fetched again per chunk (a cache hit; 12 registers)
 
     // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
     auto nbr_of = [&](int c0) {
@@ -874,7 +889,8 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         fw[st][0] = v0[0], fw[st][1] = v0[1], fw[st][2] = v0[2], fw[st][3] = v0[3];
         fw[st][4] = v1[0], fw[st][5] = v1[1], fw[st][6] = v1[2], fw[st][7] = v1[3];
       }
-      load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      if (LEAN) load_geom_record(ctrg_rs, ctr_row, yc, rc);
+      else load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       q_a = q_b;
 
       if (!g.transposed)
@@ -882,23 +898,24 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       else
         edge_descriptor(yc, rc, xn, rn, rho, d);
 
-      u32x4 own_hi, own_lo, oth_hi, oth_lo;
+      u32x4 own_hi, own_lo, oth_hi = {0u, 0u, 0u, 0u}, oth_lo = {0u, 0u, 0u, 0u};
       frags_from_floats(d, own_hi, own_lo);
       // descriptor image: half h writes the rows of frame a0+h -- the split pairs above are the rows of the two planes
-      if (NFR == 2 || h == 0) {
-        uint32_t p_hi, p_lo;
-        split2(d[8], 1.0f, p_hi, p_lo);
+      uint32_t own8_hi, own8_lo;
+      split2(d[8], 1.0f, own8_hi, own8_lo);
+      auto write_desc_rows = [&](int slot) {
         typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
-        uint16_t* dh = &lds_desc[wave][NFR == 2 ? h : 0][0][kcol][0];
-        uint16_t* dl = &lds_desc[wave][NFR == 2 ? h : 0][1][kcol][0];
+        uint16_t* dh = &lds_desc[wave][slot][0][kcol][0];
+        uint16_t* dl = &lds_desc[wave][slot][1][kcol][0];
         *reinterpret_cast<u32x2v*>(dh) = u32x2v{own_hi[0], own_hi[1]};
         *reinterpret_cast<u32x2v*>(dh + 4) = u32x2v{own_hi[2], own_hi[3]};
-        *reinterpret_cast<u32x2v*>(dh + 8) = u32x2v{p_hi, 0u};
+        *reinterpret_cast<u32x2v*>(dh + 8) = u32x2v{own8_hi, 0u};
         *reinterpret_cast<u32x2v*>(dl) = u32x2v{own_lo[0], own_lo[1]};
         *reinterpret_cast<u32x2v*>(dl + 4) = u32x2v{own_lo[2], own_lo[3]};
-        *reinterpret_cast<u32x2v*>(dl + 8) = u32x2v{p_lo, 0u};
-      }
-      {
+        *reinterpret_cast<u32x2v*>(dl + 8) = u32x2v{own8_lo, 0u};
+      };
+      if (!LEAN && (NFR == 2 || h == 0)) write_desc_rows(NFR == 2 ? h : 0);
+      if (!LEAN) {
         float d8 = d[8];
         if (NFR == 2) {  // dims 8, 9 of frame a come from the half that did not build frame a's descriptor
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
@@ -919,13 +936,38 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       auto gelu_grad_of_frame = [&](int a, float (&dy)[16]) {
         const bool dims07 = NFR == 2 ? h == a : h == 0;
         u32x4 a_hi, a_lo;
+        u32x4 wb_hi, wb_lo;
+        if (LEAN) {
+          // one weight arrangement (lane half 0: dims 0..7, half 1: dims 8, 9) for both frames; the descriptor of
+          // frame a was built by lane half a, so one of the two operand parts crosses the halves (v_permlane32_swap)
+          wb_hi = w_hi, wb_lo = w_lo;
+          auto other_half = [&](uint32_t v) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+            return h ? sw[0] : sw[1];
+          };
+          uint32_t d8_hi = own8_hi, d8_lo = own8_lo;
+          u32x4 r_hi = own_hi, r_lo = own_lo;
+          if (a == 0) {
+            d8_hi = other_half(own8_hi), d8_lo = other_half(own8_lo);
+          } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
-          a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
+            for (int i = 0; i < 4; ++i) r_hi[i] = other_half(own_hi[i]), r_lo[i] = other_half(own_lo[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            a_hi[i] = h == 0 ? r_hi[i] : (i == 0 ? d8_hi : 0u);
+            a_lo[i] = h == 0 ? r_lo[i] : (i == 0 ? d8_lo : 0u);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
+            a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
+          }
+          const auto* wl = reinterpret_cast<const uint32_t(*)[2][64][4]>(&lds_w[0][0][0][0]);
+          wb_hi = *reinterpret_cast<const u32x4*>(&wl[a][0][lane][0]);
+          wb_lo = *reinterpret_cast<const u32x4*>(&wl[a][1][lane][0]);
         }
-        const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[a][0][lane][0]);
-        const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[a][1][lane][0]);
         const f32x16 pre = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -958,13 +1000,38 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
             frags_from_floats(gp, ga_hi, ga_lo);
             // K slot (h, j) of this k-step is frame-edge acc_row(8 s + j, h) = 16 s + 4 h + (j & 3) + 8 (j >> 2)
             const int r0 = 16 * s + 4 * h + tr_row;
-            const u32x4 db_hi = lds_frag_tr16(&lds_desc[wave][a][0][r0][tr_col], &lds_desc[wave][a][0][r0 + 8][tr_col]);
-            const u32x4 db_lo = lds_frag_tr16(&lds_desc[wave][a][1][r0][tr_col], &lds_desc[wave][a][1][r0 + 8][tr_col]);
+            const int slot = LEAN ? 0 : a;
+            const u32x4 db_hi = lds_frag_tr16(&lds_desc[wave][slot][0][r0][tr_col], &lds_desc[wave][slot][0][r0 + 8][tr_col]);
+            const u32x4 db_lo = lds_frag_tr16(&lds_desc[wave][slot][1][r0][tr_col], &lds_desc[wave][slot][1][r0 + 8][tr_col]);
             dacc = mfma_bf16x3(ga_hi, ga_lo, db_hi, db_lo, dacc);
           }
         }
       };
       u32x4 fa_hi[CH16], fa_lo[CH16];
+      if (LEAN) {
+        // one descriptor image per wavefront: frame a's lane half writes its rows, the frame is accumulated, then the
+        // other half takes the image over (two wavefront barriers per frame instead of one per chunk)
+#pragma unroll
+        for (int a = 0; a < NFR; ++a) {
+          float dy[16];
+          gelu_grad_of_frame(a, dy);  // pure VALU in front of the first use of the gathered words
+          if (h == a) write_desc_rows(0);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (a == 0) {
+#pragma unroll
+            for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
+          }
+          accumulate_frame(a, fa_hi, fa_lo, dy);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          // the next chunk's geometry goes out between the frames: 12 registers that would not fit next to frame 0's
+          // fragments, and frame 1's work still covers the latency
+          if (a == 0) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+        }
+        continue;
+      }
 #if SE3_PG_SEQ
       // one frame at a time: GELU' of frame 0 (pure VALU, covers the gather latency), the gathered words become
       // fragments, frame 0 is accumulated; then the same for frame 1 -- 16 instead of 32 GELU' values live
@@ -1212,7 +1279,7 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       }
       static const int per_cu = [] {
         const char* e = getenv("SE3_PG_PAIR_WGS");
-        return e ? atoi(e) : 6;  // 26 KB of LDS per workgroup
+        return e ? atoi(e) : (SE3_PG_PAIR_LEAN ? 8 : 6);  // 19 KB / 26 KB of LDS per workgroup
       }();
       int64_t wgs = (int64_t)n_cu * per_cu;
       if (wgs > n_partials) wgs = n_partials;

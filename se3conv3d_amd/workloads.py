@@ -44,24 +44,43 @@ def frames_config(spec: dict) -> dict:
     return cfg
 
 
-def build_cloud(spec: dict, device, seed: int):
-    """Points ~ U[0,1)^3 per batch element, batch ids ascending, frames per ``spec`` (seeded)."""
+def morton_order(pts: torch.Tensor, bid: torch.Tensor, cell: float) -> torch.Tensor:
+    """Permutation that sorts the points of every batch element along the Z-order curve of a grid of ``cell``-sized
+    cells (what a loader does once per scene so that neighbouring points are neighbouring rows)."""
+    q = torch.clamp((pts / cell).long(), 0, (1 << 20) - 1)
+
+    def spread(v):      # 20 bits -> every third bit
+        out = torch.zeros_like(v)
+        for b in range(20):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    order = torch.argsort(key, stable=True)
+    return order[torch.argsort(bid[order].long(), stable=True)]
+
+
+def build_cloud(spec: dict, device, seed: int, order: str = "random"):
+    """Points ~ U[0,1)^3 per batch element, batch ids ascending, frames per ``spec`` (seeded).  ``order`` = "random"
+    (rows in the order they were drawn) or "morton" (rows sorted along a Z-order curve per batch element)."""
     from . import pc as _pc
 
     torch.manual_seed(seed)
     n = spec["points"] * spec["clouds"]
     pts = torch.rand(n, 3, device=device)
     bid = torch.arange(spec["clouds"], device=device, dtype=torch.int32).repeat_interleave(spec["points"])
+    if order == "morton":
+        pts = pts[morton_order(pts, bid, radius_for_degree(spec["points"], spec["degree"]))]
     return _pc.PointcloudRotEquiv(pts, bid, frames_config(spec))
 
 
-def build_stack(spec: dict, device, seed: int, n_levels: int = 4) -> List[dict]:
+def build_stack(spec: dict, device, seed: int, n_levels: int = 4, order: str = "random") -> List[dict]:
     """The stack of one rank: per level the cloud, its ball-query neighbourhood, a conv with converged EMA
     buffers (rho = 1/r, nu = M/E), input features and an output gradient."""
     from . import layers, pc as _pc
 
     r0 = radius_for_degree(spec["points"], spec["degree"])
-    pc0 = build_cloud(spec, device, seed)
+    pc0 = build_cloud(spec, device, seed, order)
     cells = [r0 * 2 ** i for i in range(n_levels - 1)]
     hier = _pc.PointHierarchyRotEquiv(pc0, n_levels - 1, "grid_avg", grid_radii=cells)
     radii = [r0 * 2 ** i for i in range(n_levels)]
