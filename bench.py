@@ -349,11 +349,18 @@ def run_rank(args):
                         "note": "achieved = SURVEY 8d bytes this launch owns (geometry + gathered rows; no row-sized "
                                 "intermediates) / its HIP-event time; intermediates appear in traffic only",
                         "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}}
+        # what the library says it moves through memory for this shape (3-byte rows / 4-byte words / nothing)
+        shp = _lib.Se3Shape(lv0["n"], lv0["n"], lv0["e"], frames, frames, lv0["c"], lv0["c"], W.NUM_BASIS,
+                            _lib.PRECISIONS[args.precision])
+        per_el = tuple(int(lib.se3conv_intermediate_bytes_per_element(C.byref(shp), w)) for w in range(3))
+        moved = W.stage_moved_bytes(lv0["n"], lv0["e"], frames, lv0["c"], per_el)
         lb = W.layer_bytes(lv0["n"], lv0["e"], frames, lv0["c"])
         sb = sum(W.layer_bytes(lv["n"], lv["e"], frames, lv["c"]) for lv in levels)
         result["roofline"] = roofline
         result["single_layer"] = {"ms_per_step": round(ms_layer, 4), "value": mpts(ms_layer), "unit": "Mpoints/s",
-                                  "algorithmic_bytes": lb}
+                                  "algorithmic_bytes": lb,
+                                  "intermediate_bytes_per_element": dict(zip(("T", "U", "grad_T"), per_el)),
+                                  "least_bytes_with_intermediates": sum(moved.values())}
         result["layer_frac"] = round(lb / (ms_layer * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
         result["stack_frac"] = round(sb / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
         result["stack_algorithmic_bytes"] = sb

@@ -39,6 +39,7 @@ _SHP = C.POINTER(Se3Shape)
 SIGNATURES = {
     "se3_abi_version": (C.c_int, []),
     "se3_error_string": (C.c_char_p, [C.c_int]),
+    "se3conv_intermediate_bytes_per_element": (C.c_int, [_SHP, C.c_int]),
     "se3_compute_keys": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "se3_batch_aabb": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
     "se3_grid_subsample_workspace_bytes": (_SZ, [_I64, _I32]),

@@ -431,6 +431,23 @@ static bool t24_rows(const EdgeGeom& g, int channels, int64_t rows, int tn_cols)
          2 * rows * (int64_t)(tn_cols > 0 ? tn_cols : 1) * 4 < (1ll << 32) - 64;
 }
 
+// Bytes per element of the row-sized intermediates this shape would move (what a traffic model has to assume):
+// which = 0: T (forward, read again by the weight gradient), 1: U (feature gradient), 2: grad_T.  0: that tensor
+// never reaches memory (fused small-level kernel); < 0: bad shape.
+extern "C" int se3conv_intermediate_bytes_per_element(const se3conv_shape* s, int which) {
+  if (!shape_ok(s) || which < 0 || which > 2) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->precision == SE3_PRECISION_FP32 || which == 2) return 4;
+  EdgeGeom g = forward_geom(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+  EdgeGeom gt{};
+  gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.n_nb = s->n_out, gt.transposed = 1;
+  if (which == 0) {
+    if (conv_fused_bf16_supported(g, s->c_in)) return 0;
+    return t24_rows(g, s->c_in, s->n_out * s->f_out, s->c_out) ? 3 : 4;
+  }
+  if (conv_fused_bf16_supported(gt, s->c_out)) return 0;
+  return t24_rows(gt, s->c_out, s->n_in * s->f_in, 0) ? 3 : 4;
+}
+
 extern "C" size_t se3conv_fwd_workspace_bytes(const se3conv_shape* s, int save_t) {
   return shape_ok(s) ? fwd_layout(s, save_t).total : 0;
 }

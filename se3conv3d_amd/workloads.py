@@ -133,15 +133,15 @@ def layer_bytes(n: int, e: int, f: int, c: int, kb: int = NUM_BASIS) -> int:
     return sum(stage_owned_bytes(n, e, f, c, kb).values())
 
 
-def stage_moved_bytes(n: int, e: int, f: int, c: int, t24: bool = True, kb: int = NUM_BASIS) -> Dict[str, int]:
+def stage_moved_bytes(n: int, e: int, f: int, c: int, bytes_per_el=(3, 3, 4), kb: int = NUM_BASIS) -> Dict[str, int]:
     """What each launch of the unfused pipeline has to move at least: its owned bytes plus the row-sized
-    intermediates it writes or reads (T / U in 3-byte rows when ``t24``, grad_T as 4-byte words)."""
+    intermediates it writes or reads.  ``bytes_per_el`` = bytes per element of (T, U, grad_T) as the library reports
+    them for the shape (``se3conv_intermediate_bytes_per_element``: 3-byte rows, 4-byte words, 0 = never written)."""
     rows = n * f
-    g_bytes = 4 * rows * c * kb
-    t_bytes = (3 if t24 else 4) * rows * c * kb
+    t_bytes, u_bytes, g_bytes = (b * rows * c * kb for b in bytes_per_el)
     own = stage_owned_bytes(n, e, f, c, kb)
     act = 4 * rows * c
     return {"edge_t_fwd": own["edge_t_fwd"] + t_bytes, "gemm_out": own["gemm_out"] + t_bytes,
-            "edge_t_transposed": own["edge_param_grad"] + t_bytes, "gemm_gradX": own["gemm_gradX"] + t_bytes + own["gemm_gradW"],
+            "edge_t_transposed": own["edge_t_transposed"] + u_bytes, "gemm_gradX": own["gemm_gradX"] + u_bytes,
             "edge_param_grad": own["edge_param_grad"] + g_bytes, "gemm_gradT": own["gemm_gradT"] + g_bytes,
             "gemm_gradW": own["gemm_gradW"] + t_bytes + act}

@@ -56,6 +56,21 @@ def test_host_side_argument_checks(built_library):
     assert lib.se3_ball_query_workspace_bytes(1000, 1000) > 0
 
 
+def test_intermediate_format_query(built_library):
+    """Host-only entry: which row format the operator picks for T / U / grad_T of a shape (bench.py's traffic model)."""
+    from se3conv3d_amd import _lib
+
+    lib = _lib.load()
+    q = lambda shp, which: lib.se3conv_intermediate_bytes_per_element(C.byref(shp), which)
+    headline = _lib.Se3Shape(65536, 65536, 2_000_000, 2, 2, 64, 64, 32, _lib.PRECISIONS["bf16x3"])
+    assert [q(headline, w) for w in range(3)] == [3, 3, 4]
+    exact = _lib.Se3Shape(65536, 65536, 2_000_000, 2, 2, 64, 64, 32, _lib.PRECISIONS["fp32"])
+    assert [q(exact, w) for w in range(3)] == [4, 4, 4]
+    narrow = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 32, 32, 32, _lib.PRECISIONS["bf16x3"])  # below the wave-pair kernel's width
+    assert [q(narrow, w) for w in range(3)] == [4, 4, 4]
+    assert q(headline, 3) < 0 and q(_lib.Se3Shape(10, 10, 10, 0, 1, 8, 8, 32, 1), 0) < 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from se3conv3d_amd import _lib
 
