@@ -71,13 +71,14 @@ __device__ __forceinline__ int lower_bound_key(const int64_t* __restrict__ keys,
 __global__ void find_ranges_kernel(const float* __restrict__ pts_dst, const int32_t* __restrict__ batch_dst,
                                    const float* __restrict__ aabb_min, const int32_t* __restrict__ num_cells,
                                    float radius, const int64_t* __restrict__ skeys, int n_src, int64_t n_dst,
-                                   int2* __restrict__ ranges) {
+                                   int2* __restrict__ ranges, const int32_t* __restrict__ order) {
   const int nc[3] = {num_cells[0], num_cells[1], num_cells[2]};
   const float inv_r = 1.0f / radius;
   const float inv[3] = {inv_r, inv_r, inv_r};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst * 9; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = i / 9;
-    const int o = (int)(i - s * 9);
+    const int64_t j = i / 9;
+    const int o = (int)(i - j * 9);
+    const int64_t s = order ? order[j] : j;  // a cloud against itself: samples in cell order (see ball_query_count_impl)
     int cell[3], b;
     cell_of(pts_dst, batch_dst, aabb_min, nc, inv, s, cell, b);
     const int x = cell[0] + o / 3 - 1, y = cell[1] + o % 3 - 1;
@@ -88,7 +89,7 @@ __global__ void find_ranges_kernel(const float* __restrict__ pts_dst, const int3
       r.x = lower_bound_key(skeys, n_src, base + z0);
       r.y = lower_bound_key(skeys, n_src, base + z1 + 1);
     }
-    ranges[i] = r;
+    ranges[s * 9 + o] = r;
   }
 }
 
@@ -127,13 +128,14 @@ __device__ __forceinline__ int lower_bound_key32(const uint32_t* __restrict__ ke
 __global__ void find_ranges32_kernel(const float* __restrict__ pts_dst, const int32_t* __restrict__ batch_dst,
                                      const float* __restrict__ aabb_min, const int32_t* __restrict__ num_cells,
                                      float radius, const uint32_t* __restrict__ skeys, int n_src, int64_t n_dst,
-                                     int2* __restrict__ ranges) {
+                                     int2* __restrict__ ranges, const int32_t* __restrict__ order) {
   const int nc[3] = {min(num_cells[0], kBq32Cells), min(num_cells[1], kBq32Cells), min(num_cells[2], kBq32Cells)};
   const float inv_r = 1.0f / radius;
   const float inv[3] = {inv_r, inv_r, inv_r};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst * 9; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = i / 9;
-    const int o = (int)(i - s * 9);
+    const int64_t j = i / 9;
+    const int o = (int)(i - j * 9);
+    const int64_t s = order ? order[j] : j;  // a cloud against itself: samples in cell order (see ball_query_count_impl)
     int cell[3], b;
     cell_of(pts_dst, batch_dst, aabb_min, nc, inv, s, cell, b);
     const int x = cell[0] + o / 3 - 1, y = cell[1] + o % 3 - 1;
@@ -145,7 +147,7 @@ __global__ void find_ranges32_kernel(const float* __restrict__ pts_dst, const in
       r.x = lower_bound_key32(skeys, n_src, base);
       r.y = lower_bound_key32(skeys, n_src, base + (uint32_t)(z1 - z0) + 1u);
     }
-    ranges[i] = r;
+    ranges[s * 9 + o] = r;
   }
 }
 
@@ -160,11 +162,13 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
                                                               const int2* __restrict__ ranges, int64_t n_dst,
                                                               int32_t* __restrict__ counts, int32_t* __restrict__ ends,
                                                               int32_t* __restrict__ neighbors, int limit,
-                                                              int32_t* __restrict__ sources, int32_t* __restrict__ info) {
+                                                              int32_t* __restrict__ sources, int32_t* __restrict__ info,
+                                                              const int32_t* __restrict__ order) {
   constexpr bool STORE = MODE != 0;
   const int lane = threadIdx.x & 63;
-  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= n_dst) return;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_dst) return;
+  const int64_t s = order ? order[w] : w;  // the wavefronts of a workgroup then share their candidate windows
   const float sx = pts_dst[s * 3], sy = pts_dst[s * 3 + 1], sz = pts_dst[s * 3 + 2];
   int lo[9], pre[10];
   pre[0] = 0;
@@ -685,6 +689,10 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
   int2* ranges = (int2*)(ws + l.ranges);
   int32_t* counts = (int32_t*)(ws + l.counts);
   size_t temp_bytes = l.temp_bytes;
+  // A cloud against itself: the samples are walked in the cell order the sort just produced (`sids`), so that
+  // neighbouring threads search for neighbouring keys and the wavefronts of a workgroup read the same candidate
+  // windows.  Results are stored at the sample's own index: nothing changes but the order of the work.
+  const int32_t* order = (pts_src == pts_dst && n_src == n_dst && batch_src == batch_dst) ? sids : nullptr;
 
   // key_bits > 0 (the bounded call, which knows the batch count): 32-bit keys with a fixed cell stride, see key32_of
   if (key_bits > 0) {
@@ -700,7 +708,7 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
                          n_src, spts);
     }
     hipLaunchKernelGGL(find_ranges32_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
-                       aabb_min, num_cells, radius, skeys32, (int)n_src, n_dst, ranges);
+                       aabb_min, num_cells, radius, skeys32, (int)n_src, n_dst, ranges, order);
   } else {
     if (n_src > 0) {
       // cell size = radius in every dimension (BallQuery.py:39-40)
@@ -713,11 +721,11 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
                          spts);
     }
     hipLaunchKernelGGL(find_ranges_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
-                       aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges);
+                       aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges, order);
   }
   hipLaunchKernelGGL(scan_candidates_kernel<0>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, stream, pts_dst,
                      1.0f / radius, spts, ranges, n_dst, counts, (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr,
-                     (int32_t*)nullptr);
+                     (int32_t*)nullptr, order);
   temp_bytes = l.temp_bytes;
   if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
     return SE3_ERR_LAUNCH;
@@ -735,7 +743,8 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
 // mode 1: two-phase store; 2: bounded (clamp, info, sources); 3: bounded all-pairs with the offsets formed in the kernel
 static int ball_query_store_impl(const float* pts_dst, const int32_t* batch_dst, float radius, int64_t n_src,
                                  int64_t n_dst, const void* workspace, size_t workspace_bytes, int32_t* ends,
-                                 int32_t* neighbors, int limit, int mode, int32_t* sources, int32_t* info, void* stream) {
+                                 int32_t* neighbors, int limit, int mode, int32_t* sources, int32_t* info, bool ordered,
+                                 void* stream) {
   const BqLayout l = bq_layout(n_src, n_dst);
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   const char* ws = (const char*)workspace;
@@ -756,10 +765,12 @@ static int ball_query_store_impl(const float* pts_dst, const int32_t* batch_dst,
   }
   if (mode == 1)
     hipLaunchKernelGGL(scan_candidates_kernel<1>, grid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
-                       (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info);
+                       (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info,
+                       ordered ? (const int32_t*)(ws + l.sids) : (const int32_t*)nullptr);
   else
     hipLaunchKernelGGL(scan_candidates_kernel<2>, grid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
-                       (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info);
+                       (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info,
+                       ordered ? (const int32_t*)(ws + l.sids) : (const int32_t*)nullptr);
   return check_launch();
 }
 
@@ -770,7 +781,7 @@ extern "C" int se3_ball_query_store(const float* pts_dst, const int32_t* batch_d
   if (n_dst == 0 || n_edges == 0) return SE3_OK;
   if (!pts_dst || !workspace || !ends || !neighbors) return SE3_ERR_INVALID_ARGUMENT;
   return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes,
-                               const_cast<int32_t*>(ends), neighbors, 0x7fffffff, 1, nullptr, nullptr, stream);
+                               const_cast<int32_t*>(ends), neighbors, 0x7fffffff, 1, nullptr, nullptr, false, stream);
 }
 
 extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
@@ -791,7 +802,8 @@ extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst
     return rc;
   // one store launch also clamps the offsets to the buffer and records total + overflow flag
   return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes, ends, neighbors,
-                               (int)capacity, inline_prefix ? 3 : 2, sources, info, stream);
+                               (int)capacity, inline_prefix ? 3 : 2, sources, info,
+                               pts_src == pts_dst && n_src == n_dst && batch_src == batch_dst, stream);
 }
 
 namespace {

@@ -161,6 +161,9 @@ def test_scannet150k_backward_against_oracle(amd, c_in, c_out):
     full_checks(amd, pc, 0.12, c_in, c_out, seed=20 + c_in)
 
 
+_DFAUST_ORACLE = {}
+
+
 def test_dfaust_f2_batch_against_oracle(amd):
     """configs[1]: 32 bodies x 2 200 points (4096 sampled -> 0.04 grid), F = 2 PCA frames from 16-NN, the network's
     first convolution C_in = 1 -> 32 (tasks/SemSeg/confs/dfaust/dfaust_I_rot_pca_2F.yaml:4,17,37-38) -- whole batch
@@ -175,13 +178,19 @@ def test_dfaust_f2_batch_against_oracle(amd):
     assert pc.local_frames_.shape == (n, f, 9)
     r = radius_for_degree(n_per, 14)
     nbh, conv, x, g = make_layer(amd, pc, r, 1, 32, seed=30)
-    nb_ref, ends_ref = O.ball_query(pts.cpu(), pts.cpu(), bid.cpu(), bid.cpu(), r)
+    cpu = lambda t: t.detach().cpu()
+    inputs = [pts.cpu(), pc.local_frames_.cpu(), x.detach().cpu(), cpu(conv.proj_axes_), cpu(conv.proj_biases_),
+              cpu(conv.conv_weights_), cpu(conv.norm_neigh_dist_), cpu(conv.norm_num_neighs_), g.cpu()]
+    # the oracle takes a minute on this batch and its inputs do not depend on the arithmetic mode of the library:
+    # computed once per session, reused when the second mode presents bit-identical inputs
+    cached = _DFAUST_ORACLE.get("inputs")
+    if cached is None or not all(torch.equal(a, b) for a, b in zip(cached, inputs)):
+        nb_ref, ends_ref = O.ball_query(pts.cpu(), pts.cpu(), bid.cpu(), bid.cpu(), r)
+        ref = O.conv_forward_backward(inputs[0], inputs[0], inputs[1], inputs[1], nb_ref, inputs[2], *inputs[3:])
+        _DFAUST_ORACLE.update(inputs=inputs, nb=nb_ref, ends=ends_ref, ref=ref)
+    nb_ref, ends_ref, ref = _DFAUST_ORACLE["nb"], _DFAUST_ORACLE["ends"], _DFAUST_ORACLE["ref"]
     assert torch.equal(nbh.start_ids_.cpu(), ends_ref) and torch.equal(canon_edges(nbh.neighbors_), canon_edges(nb_ref))
     got = gpu_backward(conv, pc, nbh, x, g)
-    cpu = lambda t: t.detach().cpu()
-    ref = O.conv_forward_backward(pts.cpu(), pts.cpu(), pc.local_frames_.cpu(), pc.local_frames_.cpu(), nb_ref, x.cpu(),
-                                  cpu(conv.proj_axes_), cpu(conv.proj_biases_), cpu(conv.conv_weights_),
-                                  cpu(conv.norm_neigh_dist_), cpu(conv.norm_num_neighs_), g.cpu())
     for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), got, ref):
         assert rel_err(u, v) < tol(amd), (name, rel_err(u, v))
 
