@@ -15,7 +15,10 @@ lib = _lib.load()
 from se3conv3d_amd import workloads as W
 levels = W.build_stack(W.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'headline'], dev, 0)
 for i, lv in enumerate(levels):
-    st = bench.profile_level(lib, lv, reps=5)
+    for _ in range(3):
+        bench.step([lv])          # warm-up: lazy builds, allocator, clocks
+    torch.cuda.synchronize()
+    st = bench.profile_level(lib, lv, reps=20)
     run = bench.GraphedStep([lv])
     for _ in range(5):
         run()
