@@ -213,7 +213,9 @@ def run_rank(args):
     spec = W.WORKLOADS[args.workload]
     n0 = spec["points"] * spec["clouds"]
     dist = None
-    if world > 1:
+    # SE3_BENCH_FORCE_DIST=1: a one-rank job still goes through the process group (RCCL init, barrier, MAX reduce, result
+    # gather, graph capture next to a live communicator) -- the rehearsal of the N-rank path a one-GPU box can run
+    if world > 1 or os.environ.get("SE3_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -52,7 +52,7 @@ def gather_scene_results(local: Dict[int, torch.Tensor], dist=None, dst: int = 0
 
 def job_throughput(units_local: float, seconds_local: float, dist=None, device=None):
     """Whole-job rate: units summed over ranks / slowest rank's time (MAX all-reduce)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return units_local / seconds_local, seconds_local
     t = torch.tensor([seconds_local], dtype=torch.float64, device=device)
     u = torch.tensor([units_local], dtype=torch.float64, device=device)

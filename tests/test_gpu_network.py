@@ -152,3 +152,28 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and sorted(rec["scene_checksums"]) == ["0", "1"]
     assert rec["scene_checksums"]["0"] != rec["scene_checksums"]["1"]      # different scenes per rank
     assert "roofline" not in rec                                            # single-GPU extras stay out of N > 1 lines
+
+
+@pytest.mark.timeout(600)
+def test_bench_rccl_path_with_one_rank():
+    """The N-rank code path of bench.py on the one GPU of this box: a one-rank RCCL process group (init with the device,
+    barrier, MAX / SUM all-reduce of the timing on the GPU, tensor all-gather of the checksums) and the step captured
+    into a HIP graph while the communicator and its watchdog thread are alive."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SE3_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-fp32"], capture_output=True, text=True, timeout=550, env=env, cwd=root)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and list(rec["scene_checksums"]) == ["0"]
+    assert rec["config"]["launch"].startswith("hipGraph"), rec["config"]["launch"]
