@@ -747,6 +747,9 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 #ifndef SE3_PG_SINGLE_WAVES
 #define SE3_PG_SINGLE_WAVES 3  // one frame per wavefront (odd F).  4 (40 KB of LDS per 4-wave workgroup = 4 per CU) was measured:
 #endif                         // at 128 VGPRs the 64-channel form spills 11 registers and runs 0.65 instead of 0.47 ms (ScanNet-like)
+#ifndef SE3_PG_GT_BUFFER
+#define SE3_PG_GT_BUFFER 1  // grad_T rows through a per-row buffer resource (0: guarded global loads = one branch per load)
+#endif
 #ifndef SE3_PG_SEQ
 #define SE3_PG_SEQ 0  // 1: the two frames of a chunk one after the other (GELU' of one frame live at a time: fewer VGPRs)
 #endif
@@ -754,7 +757,8 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // instead of 16 KB per wavefront: 26 KB of LDS per workgroup, 6 workgroups = 3 wavefronts per SIMD instead of 2),
 // wavefront v builds the image of frame v (32 of the 64 row loads) and takes the chunks v, v + 2, ... of the item for
 // both frames; two workgroup barriers per item (image built / image free), partial sums folded per workgroup.
-template <int CH16, int NFR, bool PAIR = false>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
+// POW2: the neighbour cloud's frame count is a power of two (fnb_shift >= 0) -- no division path, no branch on it
+template <int CH16, int NFR, bool PAIR = false, bool POW2 = false>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
 __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_PAIR_WAVES : (NFR == 2 ? 2 : (CH16 == 3 ? 3 : SE3_PG_SINGLE_WAVES))) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                          int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
@@ -821,12 +825,12 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
     auto nbr_of = [&](int c0) {
       const int fe = min(c0 + kcol, n_total - 1);
-      const int e = start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+      const int e = start + (POW2 || fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
       return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
     };
     auto row_of = [&](int nb, int c0) {
       const int fe = min(c0 + kcol, n_total - 1);
-      return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
+      return (POW2 ? nb << fnb_shift : nb * g.f_nb) + (POW2 || fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
     };
     const int nb_a = nbr_of(c_first);
     int nb_b = nbr_of(c_first + CSTEP);
@@ -839,11 +843,20 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     for (int ab = 0; ab < NBUILD; ++ab) {
       const int a = PAIR ? wave : ab;
       const uint32_t* gt_row = grad_t + ((item * NFR + a) * (int64_t)row_ch + c_off) * kBasis;
+      // one buffer per row (its base is wave-uniform): channels past the row read as zeros through the bounds check of
+      // the buffer load -- a guarded global load per element compiled into a branch per load
+      const int row_left = min(row_ch - c_off, 16 * CH16);
+      // (`wave` is uniform but the compiler cannot know: without readfirstlane every load becomes a waterfall loop)
+      const uint64_t gt_addr = reinterpret_cast<uint64_t>(gt_row);
+      const uint64_t gt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gt_addr >> 32)) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gt_addr);  // (the builtin returns int)
+      const __amdgpu_buffer_rsrc_t gt_rs = buffer_of(reinterpret_cast<const void*>(gt_base), (int64_t)row_left * kBasis * 4);
 #pragma unroll
       for (int st = 0; st < CH16; ++st)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
+                          : SE3_PG_GT_BUFFER ? __builtin_amdgcn_raw_buffer_load_b32(gt_rs, ((16 * st + 8 * h + j) * kBasis + kcol) * 4, 0, 0)
                           : (c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u);
     }
     int q_a = row_of(nb_a, c_first);
@@ -865,11 +878,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       const int cnt = min(32, n_total - c0);
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;
-      float xn[3], rn[9], d[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+      float d[9];
       const int q_b = row_of(nb_b, c0 + CSTEP);
       nb_b = nbr_of(c0 + 2 * CSTEP);
 
@@ -890,13 +899,15 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         fw[st][4] = v1[0], fw[st][5] = v1[1], fw[st][6] = v1[2], fw[st][7] = v1[3];
       }
       if (LEAN) load_geom_record(ctrg_rs, ctr_row, yc, rc);
-      else load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       q_a = q_b;
 
       if (!g.transposed)
-        edge_descriptor(xn, rn, yc, rc, rho, d);
+        edge_descriptor(xn_nx, rn_nx, yc, rc, rho, d);
       else
-        edge_descriptor(yc, rc, xn, rn, rho, d);
+        edge_descriptor(yc, rc, xn_nx, rn_nx, rho, d);
+      // the next chunk's record goes out once this chunk's has been consumed: issued next to the feature gathers it
+      // needed a second set of 12 registers (and spilled)
+      if (!LEAN) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
 
       u32x4 own_hi, own_lo, oth_hi = {0u, 0u, 0u, 0u}, oth_lo = {0u, 0u, 0u, 0u};
       frags_from_floats(d, own_hi, own_lo);
@@ -1287,8 +1298,12 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       if (wgs < 1) wgs = 1;
       *n_used = (int)wgs * blocks_y;
       const dim3 pgrid((unsigned)wgs, (unsigned)blocks_y);
-      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                         feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+      if (shift >= 0)
+        hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
+                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+      else
+        hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, false>), pgrid, dim3(128), 0, stream, g, feat, channels,
+                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
       return check_launch();
     }
     const int n_blocks = n_partials < 512 ? n_partials : 512;  // the 512-thread form: one workgroup per CU and round
