@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #ifndef SE3_PAIR_MLP_FP32
 #define SE3_PAIR_MLP_FP32 0  // 1: kernel MLP on v_mfma_f32_32x32x2_f32 (fewer VALU ops, measured 14 % slower: 0.41 vs 0.36 ms)
 #endif
-template <int CT, bool FULL, int NF>
+template <int CT, bool FULL, int NF, bool POW2 = false>  // POW2: fnb_shift >= 0 is known (no division path, no branch on it)
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift,
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   // per link; a wavefront lives for ~2.5 chunks only).  Frame-edge indices past the end clamp to the last one.
   auto nbr_of = [&](int c0) {
     const int fe = min(c0 + kcol, n_total - 1);
-    const int e = start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+    const int e = start + (POW2 || fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
     if (SE3_PAIR_ABLATE & 16) return (int)(((unsigned)e * 2654435761u) % (unsigned)g.n_nb);  // no id load
     return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
   };
   auto row_of = [&](int nb, int c0) {
     const int fe = min(c0 + kcol, n_total - 1);
-    return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
+    return (POW2 ? nb << fnb_shift : nb * g.f_nb) + (POW2 || fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
   };
 
   for (int cbase = 0; cbase < C; cbase += 64 * CT) {
@@ -1199,19 +1199,21 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     }
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
-#define SE3_PAIR(CT, FULL)                                                                                              \
-  do {                                                                                                                  \
-    if (two)                                                                                                            \
-      hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 2>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, t_out, item_lo, item_hi, shift, t24 ? 1 : 0);                                   \
-    else                                                                                                                \
-      hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, 1>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, t_out, item_lo, item_hi, shift, t24 ? 1 : 0);                                   \
+#define SE3_PAIR_L(CT, FULL, NF, P2)                                                                                    \
+  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
+                     axes_ext, rho, t_out, item_lo, item_hi, shift, t24 ? 1 : 0)
+#define SE3_PAIR(CT, FULL)                                   \
+  do {                                                       \
+    if (two && shift >= 0) SE3_PAIR_L(CT, FULL, 2, true);    \
+    else if (two) SE3_PAIR_L(CT, FULL, 2, false);            \
+    else if (shift >= 0) SE3_PAIR_L(CT, FULL, 1, true);      \
+    else SE3_PAIR_L(CT, FULL, 1, false);                     \
   } while (0)
     if (channels == 64) SE3_PAIR(1, true);
     else if (channels % 128 == 0) SE3_PAIR(2, true);
     else SE3_PAIR(2, false);
 #undef SE3_PAIR
+#undef SE3_PAIR_L
     return check_launch();
   }
   if (channels <= 128 && getenv("SE3_STREAM") != nullptr) {
@@ -1309,14 +1311,15 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
     const int n_blocks = n_partials < 512 ? n_partials : 512;  // the 512-thread form: one workgroup per CU and round
     *n_used = n_blocks * blocks_y;
     const dim3 grid((unsigned)n_blocks, (unsigned)blocks_y);
-#define SE3_PG(CH16)                                                                                                      \
-  do {                                                                                                                    \
-    if (two)                                                                                                              \
-      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, 2>), grid, dim3(512), 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, grad_t, partials, items, shift);                                                  \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, 1>), grid, dim3(256), 0, stream, g, feat, channels, feat_rows, \
-                         axes_ext, rho, grad_t, partials, items, shift);                                                  \
+#define SE3_PG_L(CH16, NFR, P2, THREADS)                                                                                  \
+  hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, NFR, false, P2>), grid, dim3(THREADS), 0, stream, g, feat, channels, \
+                     feat_rows, axes_ext, rho, grad_t, partials, items, shift)
+#define SE3_PG(CH16)                                       \
+  do {                                                     \
+    if (two && shift >= 0) SE3_PG_L(CH16, 2, true, 512);   \
+    else if (two) SE3_PG_L(CH16, 2, false, 512);           \
+    else if (shift >= 0) SE3_PG_L(CH16, 1, true, 256);     \
+    else SE3_PG_L(CH16, 1, false, 256);                    \
   } while (0)
     switch (channels >= 64 ? 4 : channels / 16) {
       case 1: SE3_PG(1); break;
@@ -1325,6 +1328,7 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       default: SE3_PG(4); break;
     }
 #undef SE3_PG
+#undef SE3_PG_L
     return check_launch();
   }
   hipLaunchKernelGGL(edge_param_grad_bf16_kernel, dim3(n_partials), dim3(256), 0, stream, g, feat, channels, axes_ext,
