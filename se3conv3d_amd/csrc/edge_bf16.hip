@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #ifndef SE3_PAIR_MLP_FP32
 #define SE3_PAIR_MLP_FP32 0  // 1: kernel MLP on v_mfma_f32_32x32x2_f32 (fewer VALU ops, measured 14 % slower: 0.41 vs 0.36 ms)
 #endif
-template <int CT, bool FULL, int NF, bool POW2 = false>  // POW2: fnb_shift >= 0 is known (no division path, no branch on it)
+// POW2: fnb_shift >= 0 is known (no division path, no branch on it).  TR: 0 forward, 1 transposed pass, -1 decided by
+// g.transposed at run time (both descriptor paths in the loop: their live values together spill at 128 VGPRs)
+template <int CT, bool FULL, int NF, bool POW2 = false, int TR = -1>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift,
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       q_a = q_b;
 
-      if (!g.transposed)
+      if (TR == 0 || (TR < 0 && !g.transposed))
         edge_descriptor(xn, rn, yc, rc, rho, d);
       else
         edge_descriptor(yc, rc, xn, rn, rho, d);
@@ -1199,9 +1201,15 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     }
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
-#define SE3_PAIR_L(CT, FULL, NF, P2)                                                                                    \
-  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
+#define SE3_PAIR_T(CT, FULL, NF, P2, TR)                                                                                \
+  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
                      axes_ext, rho, t_out, item_lo, item_hi, shift, t24 ? 1 : 0)
+#define SE3_PAIR_L(CT, FULL, NF, P2)                 \
+  do {                                               \
+    if (!(P2)) SE3_PAIR_T(CT, FULL, NF, P2, -1);     \
+    else if (g.transposed) SE3_PAIR_T(CT, FULL, NF, P2, 1); \
+    else SE3_PAIR_T(CT, FULL, NF, P2, 0);            \
+  } while (0)
 #define SE3_PAIR(CT, FULL)                                   \
   do {                                                       \
     if (two && shift >= 0) SE3_PAIR_L(CT, FULL, 2, true);    \
@@ -1214,6 +1222,7 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     else SE3_PAIR(2, false);
 #undef SE3_PAIR
 #undef SE3_PAIR_L
+#undef SE3_PAIR_T
     return check_launch();
   }
   if (channels <= 128 && getenv("SE3_STREAM") != nullptr) {
