@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #ifndef SE3_PAIR_ABLATE
 #define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi
 #endif
+#ifndef SE3_PAIR_PIN
+#define SE3_PAIR_PIN 1  // centre record pinned in its 12 registers inside the chunk loop (no hoisted operand pairs, no spills)
+#endif
 #ifndef SE3_PAIR_MLP_FP32
 #define SE3_PAIR_MLP_FP32 0  // 1: kernel MLP on v_mfma_f32_32x32x2_f32 (fewer VALU ops, measured 14 % slower: 0.41 vs 0.36 ms)
 #endif
@@ -229,6 +232,14 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes : kOobOffset;
       float xn[3], rn[9], d[9];
+      // the centre's record stays the 12 values it is (see edge_param_grad_bf16_v2_kernel: hoisted operand pairs of the
+      // packed FMAs otherwise spill and come back behind s_waitcnt vmcnt(0))
+#if SE3_PAIR_PIN
+#pragma unroll
+      for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(yc[i]));
+#pragma unroll
+      for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(rc[i]));
+#endif
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
 #pragma unroll
@@ -752,6 +763,15 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 #ifndef SE3_PG_GT_BUFFER
 #define SE3_PG_GT_BUFFER 1  // grad_T rows through a per-row buffer resource (0: guarded global loads = one branch per load)
 #endif
+#ifndef SE3_PG_PAIR_GEOM_AT_END
+#define SE3_PG_PAIR_GEOM_AT_END 0  // pair form: next chunk's geometry record issued at the end of the chunk body
+#endif
+#ifndef SE3_PG_PAIR_PIN
+#define SE3_PG_PAIR_PIN 0  // 1: pair form, centre record pinned in its 12 registers: the operand pairs (splats) of the descriptor's
+                           // packed FMAs are then rebuilt per chunk instead of hoisted, spilled (14 registers) and reloaded behind
+                           // s_waitcnt vmcnt(0).  Measured: 0.429 vs 0.419 ms -- the ~20 extra v_mov per chunk cost more than the
+                           // waits, which the other wavefronts of the SIMD cover (profiles/r02_param_grad_pin_ab.txt)
+#endif
 #ifndef SE3_PG_SEQ
 #define SE3_PG_SEQ 0  // 1: the two frames of a chunk one after the other (GELU' of one frame live at a time: fewer VGPRs)
 #endif
@@ -881,6 +901,15 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;
       float d[9];
+      if (PAIR && SE3_PG_PAIR_PIN) {
+        // keep the centre's record as the 12 values it is: left alone, the compiler hoists the operand pairs of the
+        // descriptor's packed FMAs (splats of these values) out of the loop, runs out of registers, spills them and
+        // reloads them every chunk behind `s_waitcnt vmcnt(0)` -- i.e. behind the feature gathers
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(yc[i]));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(rc[i]));
+      }
       const int q_b = row_of(nb_b, c0 + CSTEP);
       nb_b = nbr_of(c0 + 2 * CSTEP);
 
@@ -907,9 +936,11 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         edge_descriptor(xn_nx, rn_nx, yc, rc, rho, d);
       else
         edge_descriptor(yc, rc, xn_nx, rn_nx, rho, d);
-      // the next chunk's record goes out once this chunk's has been consumed: issued next to the feature gathers it
-      // needed a second set of 12 registers (and spilled)
-      if (!LEAN) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      // the next chunk's record goes out once this chunk's has been consumed.  Pair form: only at the end of the chunk
+      // body -- a wavefront there has one chunk per item as a rule, and a record held across the accumulation (the
+      // register peak) was spilled by the compiler and reloaded behind `s_waitcnt vmcnt(0)`, i.e. behind the feature
+      // gathers the descriptor / MLP / GELU' work is meant to overlap
+      if (!LEAN && !(PAIR && SE3_PG_PAIR_GEOM_AT_END)) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
 
       u32x4 own_hi, own_lo, oth_hi = {0u, 0u, 0u, 0u}, oth_lo = {0u, 0u, 0u, 0u};
       frags_from_floats(d, own_hi, own_lo);
@@ -1069,6 +1100,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
 #pragma unroll
       for (int a = 0; a < NFR; ++a) accumulate_frame(a, fa_hi, fa_lo, dyv[a]);
 #endif
+      if (PAIR && SE3_PG_PAIR_GEOM_AT_END && !LEAN && c0 + CSTEP < n_total) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
