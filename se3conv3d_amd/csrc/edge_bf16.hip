@@ -183,8 +183,9 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   // Persistent workgroups (SE3_PAIR_PERSIST): the block walks items blockIdx.x, blockIdx.x + gridDim.x, ... so that
   // the kernel prologue (arguments, descriptors, MLP weights into LDS) is paid once per block, not once per item.
   for (int64_t item = item_lo + blockIdx.x; item < n_items; item += gridDim.x) {  // items item_lo .. n_items-1
-  const int64_t ctr = item / groups;
-  const int a0 = (int)(item - ctr * groups) * NF;
+  // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
+  const int64_t ctr = (uint32_t)item / (uint32_t)groups;
+  const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NF;
   const int start = (SE3_PAIR_ABLATE & 32) ? (int)(ctr * 31) : (ctr > 0 ? g.ends[ctr - 1] : 0);
   const int n_total = (SE3_PAIR_ABLATE & 32) ? 31 * g.f_nb : (g.ends[ctr] - start) * g.f_nb;
   float yc[3], rc[9];
@@ -834,8 +835,9 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
        item_f += PAIR ? (int64_t)gridDim.x : (int64_t)gridDim.x * NW) {
     const int64_t item = SE3_PG_REVERSE ? n_items - 1 - item_f : item_f;
     const int groups = g.f_ctr / NFR;
-    const int64_t ctr = item / groups;
-    const int a0 = (int)(item - ctr * groups) * NFR;
+    // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
+    const int64_t ctr = (uint32_t)item / (uint32_t)groups;
+    const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NFR;
     const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
     const int n_total = (g.ends[ctr] - start) * g.f_nb;
     if (n_total == 0) continue;  // uniform over the workgroup in the pair form: both wavefronts skip the item's barriers
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
-                          : SE3_PG_GT_BUFFER ? __builtin_amdgcn_raw_buffer_load_b32(gt_rs, ((16 * st + 8 * h + j) * kBasis + kcol) * 4, 0, 0)
+                          : SE3_PG_GT_BUFFER ? __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0)
                           : (c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u);
     }
     int q_a = row_of(nb_a, c_first);

@@ -71,8 +71,9 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
   const int lane = threadIdx.x & 63;
   const int kcol = lane & 31, h = lane >> 5;
   const int groups = g.f_ctr / FC;
-  const int64_t ctr = item / groups;
-  const int a0 = (int)(item - ctr * groups) * FC;
+  // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
+  const int64_t ctr = (uint32_t)item / (uint32_t)groups;
+  const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * FC;
 
   const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
   const int n_total = (g.ends[ctr] - start) * g.f_nb;
@@ -278,8 +279,9 @@ __device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdg
     float yc[3], rc[9];
   };
   auto load_header = [&](int64_t item, Header& hd) {
-    const int64_t ctr = item / groups;
-    const int a0 = (int)(item - ctr * groups) * FC;
+    // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
+    const int64_t ctr = (uint32_t)item / (uint32_t)groups;
+    const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * FC;
     hd.e0 = g.ends[ctr > 0 ? ctr - 1 : 0];
     if (ctr == 0) hd.e0 = 0;
     hd.e1 = g.ends[ctr];
