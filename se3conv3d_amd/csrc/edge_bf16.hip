@@ -141,13 +141,14 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi
 #endif
 #ifndef SE3_PAIR_PIN
-#define SE3_PAIR_PIN 1  // centre record pinned in its 12 registers inside the chunk loop (no hoisted operand pairs, no spills)
+#define SE3_PAIR_PIN 1  // centre record passed through an empty asm at the top of every chunk: nothing derived from it is hoisted out
+                        // of the loop (fewer live registers, another schedule).  Measured -2 % (0.366 / 0.360 -> 0.359 / 0.353 ms)
 #endif
 #ifndef SE3_PAIR_MLP_FP32
 #define SE3_PAIR_MLP_FP32 0  // 1: kernel MLP on v_mfma_f32_32x32x2_f32 (fewer VALU ops, measured 14 % slower: 0.41 vs 0.36 ms)
 #endif
 // POW2: fnb_shift >= 0 is known (no division path, no branch on it).  TR: 0 forward, 1 transposed pass, -1 decided by
-// g.transposed at run time (both descriptor paths in the loop: their live values together spill at 128 VGPRs)
+// g.transposed at run time (both descriptor paths in the loop)
 template <int CT, bool FULL, int NF, bool POW2 = false, int TR = -1>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
@@ -233,8 +234,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes : kOobOffset;
       float xn[3], rn[9], d[9];
-      // the centre's record stays the 12 values it is (see edge_param_grad_bf16_v2_kernel: hoisted operand pairs of the
-      // packed FMAs otherwise spill and come back behind s_waitcnt vmcnt(0))
+      // SE3_PAIR_PIN: the centre's record stays the 12 values it is -- nothing derived from it leaves the loop
 #if SE3_PAIR_PIN
 #pragma unroll
       for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(yc[i]));
@@ -768,10 +768,8 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 #define SE3_PG_PAIR_GEOM_AT_END 0  // pair form: next chunk's geometry record issued at the end of the chunk body
 #endif
 #ifndef SE3_PG_PAIR_PIN
-#define SE3_PG_PAIR_PIN 0  // 1: pair form, centre record pinned in its 12 registers: the operand pairs (splats) of the descriptor's
-                           // packed FMAs are then rebuilt per chunk instead of hoisted, spilled (14 registers) and reloaded behind
-                           // s_waitcnt vmcnt(0).  Measured: 0.429 vs 0.419 ms -- the ~20 extra v_mov per chunk cost more than the
-                           // waits, which the other wavefronts of the SIMD cover (profiles/r02_param_grad_pin_ab.txt)
+#define SE3_PG_PAIR_PIN 0  // 1: pair form, centre record passed through an empty asm per chunk (as SE3_PAIR_PIN in the edge_t pair kernel).
+                           // Measured slower here: 0.429 vs 0.419 ms (profiles/r02_param_grad_pin_ab.txt)
 #endif
 #ifndef SE3_PG_SEQ
 #define SE3_PG_SEQ 0  // 1: the two frames of a chunk one after the other (GELU' of one frame live at a time: fewer VGPRs)
@@ -904,9 +902,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;
       float d[9];
       if (PAIR && SE3_PG_PAIR_PIN) {
-        // keep the centre's record as the 12 values it is: left alone, the compiler hoists the operand pairs of the
-        // descriptor's packed FMAs (splats of these values) out of the loop, runs out of registers, spills them and
-        // reloads them every chunk behind `s_waitcnt vmcnt(0)` -- i.e. behind the feature gathers
+        // keep the centre's record as the 12 values it is (nothing derived from it is hoisted out of the loop)
 #pragma unroll
         for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(yc[i]));
 #pragma unroll
@@ -938,10 +934,8 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         edge_descriptor(xn_nx, rn_nx, yc, rc, rho, d);
       else
         edge_descriptor(yc, rc, xn_nx, rn_nx, rho, d);
-      // the next chunk's record goes out once this chunk's has been consumed.  Pair form: only at the end of the chunk
-      // body -- a wavefront there has one chunk per item as a rule, and a record held across the accumulation (the
-      // register peak) was spilled by the compiler and reloaded behind `s_waitcnt vmcnt(0)`, i.e. behind the feature
-      // gathers the descriptor / MLP / GELU' work is meant to overlap
+      // the next chunk's record goes out once this chunk's has been consumed (SE3_PG_PAIR_GEOM_AT_END=1: only at the
+      // end of the chunk body -- measured slower, 0.434 vs 0.419 ms)
       if (!LEAN && !(PAIR && SE3_PG_PAIR_GEOM_AT_END)) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
 
       u32x4 own_hi, own_lo, oth_hi = {0u, 0u, 0u, 0u}, oth_lo = {0u, 0u, 0u, 0u};
