@@ -71,6 +71,23 @@ def test_intermediate_format_query(built_library):
     assert q(headline, 3) < 0 and q(_lib.Se3Shape(10, 10, 10, 0, 1, 8, 8, 32, 1), 0) < 0
 
 
+def test_header_lists_every_environment_switch():
+    """The header promises that ALL process-wide state is listed there: every getenv in the library's sources must be
+    named in it (suffix variants are listed as `NAME (+ _SUFFIX)`)."""
+    import glob
+
+    header = open(HEADER).read()
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "se3conv3d_amd", "csrc", "*")):
+        names |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(path).read()))
+    assert names, "no switches found: the scan is broken"
+    for name in sorted(names):
+        base = [b for b in re.findall(r"[A-Z0-9_]{5,}", header) if name == b or (name.startswith(b) and name[len(b):].startswith("_"))]
+        assert base, f"{name} is read from the environment but not listed in include/se3conv.h"
+        if name not in header:
+            assert name[len(max(base, key=len)):] in header, f"suffix of {name} not listed"
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from se3conv3d_amd import _lib
 
