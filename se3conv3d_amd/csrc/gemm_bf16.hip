@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
 // k: 128 B of hi and 64 B of lo per row and instruction.  LDS and the MFMA stage keep the 32-k tiles of the kernel
 // above: the two halves of a super tile are the two LDS buffers.  Lane l of load p reads 16-byte column
 // (l & 7) ^ (4 * (p & 1)), so every thread holds as many pieces of either half and the stores stay full-width.
+#ifndef SE3_T24_NT_LOADS
+#define SE3_T24_NT_LOADS 0  // 1: the row stream is loaded non-temporally (read once; keeps the weight tiles in L2)
+#endif
 template <int OUT_MODE, int NB>
 __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restrict__ a,
                                                           const uint16_t* __restrict__ bt_hi,
@@ -268,12 +271,12 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const uint32_t off = (uint32_t)(m0 + p * 32 + (tid >> 3)) * rb + k0 * 2u + (uint32_t)((tid & 7) ^ ((p & 1) << 2)) * 16u;
-      t.ah[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
+      t.ah[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, SE3_T24_NT_LOADS ? 2 : 0));
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const uint32_t off = (uint32_t)(m0 + p * 64 + (tid >> 2)) * rb + (uint32_t)k * 2u + k0 + (uint32_t)((tid & 3) ^ (p << 1)) * 16u;
-      t.al[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
+      t.al[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, SE3_T24_NT_LOADS ? 2 : 0));
     }
 #pragma unroll
     for (int j = 0; j < 2 * NB; ++j) {  // j = 2 * nb + p: columns 64 nb + 32 p + (tid >> 3)
