@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
 // k: 128 B of hi and 64 B of lo per row and instruction.  LDS and the MFMA stage keep the 32-k tiles of the kernel
 // above: the two halves of a super tile are the two LDS buffers.  Lane l of load p reads 16-byte column
 // (l & 7) ^ (4 * (p & 1)), so every thread holds as many pieces of either half and the stores stay full-width.
+#ifndef SE3_T24_REVERSE
+#define SE3_T24_REVERSE 0
+#endif
 #ifndef SE3_T24_NT_LOADS
 #define SE3_T24_NT_LOADS 0  // 1: the row stream is loaded non-temporally (read once; keeps the weight tiles in L2)
 #endif
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
   __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  // SE3_T24_REVERSE: row blocks last-written first (the producer wrote the rows front to back just before this launch)
+  const int64_t m0 = (int64_t)(SE3_T24_REVERSE ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BNW;
   const int st_begin = blockIdx.z * st_per_split;
   const int ns = min(k / 64 - st_begin, st_per_split);  // super tiles of this block (> 0 by construction)
