@@ -41,7 +41,21 @@ METRIC = "Mpoints/sec fwd+bwd PNEConvLayerRotEquiv (N=64k,k=32,F=2)"
 # In "bf16x3" every multiply costs 3 bf16 MFMA products, so mfma_frac <= 1/3 by construction there.
 PEAK_MFMA_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
+
+
+def library_source_sha() -> str:
+    """sha256 over the kernel sources the library is built from: what a committed PMC measurement (profiles/*_traffic.json,
+    written by tools/pmc_traffic.py with the same function) is valid for."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "se3conv3d_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -289,6 +303,35 @@ def run_rank(args):
         _, dt = job_throughput(float(n0 * steps), dt, dist, reduce_device)  # MAX over ranks
         return dt
 
+    def timed_events(fn, steps):
+        """SURVEY 8d protocol beside the wall clock: one HIP event pair per step on the launch stream (graph replays and
+        eager launches both run on torch's current stream), median and minimum over the steps."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        return {"median_ms": round(statistics.median(ms), 4), "min_ms": round(ms[0], 4), "steps": steps,
+                "method": "HIP events per step on the launch stream"}
+
+    def streaming_rate_gbps():
+        """What this chip streams: a 1 GiB device-to-device copy (1 GiB read + 1 GiB written), best of 5."""
+        a = torch.empty(1 << 28, dtype=torch.float32, device=device)
+        b = torch.empty_like(a)
+        best = 1e9
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        del a, b
+        return 2 * (1 << 30) / (best * 1e-3) / 1e9
+
     launch = "eager" if args.no_graph else "hipGraph replay of the captured step"
     if args.no_graph:
         run_stack = lambda: step(levels)
@@ -298,8 +341,14 @@ def run_rank(args):
         except RuntimeError as exc:
             if world == 1:
                 raise
-            # an N-rank run must not die on a capture refused next to a live process group: this rank launches eagerly
-            torch.cuda.synchronize()
+            # an N-rank run must not die on a capture refused next to a live process group: this rank launches eagerly.
+            # A stream left in capture mode makes the synchronisation itself raise: then the rank fails (non-zero exit,
+            # which fails the job) rather than timing something undefined
+            try:
+                torch.cuda.synchronize()
+            except RuntimeError as exc2:
+                raise SystemExit(f"rank {rank}: graph capture failed ({str(exc)[:120]}) and the device cannot be "
+                                 f"synchronised afterwards ({str(exc2)[:120]})")
             run_stack = lambda: step(levels)
             launch = f"eager on rank {rank} (graph capture failed: {str(exc)[:120]})"
     dt_stack = timed(run_stack, args.steps, args.warmup)
@@ -310,6 +359,7 @@ def run_rank(args):
         "metric": METRIC, "value": mpts(ms_step), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "timing": {"value_from": "wall clock around the K steps between barriers + synchronize, MAX over ranks (the driver's contract)"},
         "config": {"workload": f"{args.workload}: {spec['note']}; conv-only fwd+bwd (dX,dA,dbeta,dW), one scene per GPU",
                    "n_points": n0, "clouds_per_gpu": spec["clouds"], "k": spec["degree"], "frames": frames,
                    "channels": spec["widths"], "num_basis": W.NUM_BASIS,
@@ -321,8 +371,10 @@ def run_rank(args):
 
     if world == 1:
         lv0 = levels[0]
+        result["timing"]["hip_events"] = timed_events(run_stack, max(args.steps, 50))
         run_layer = (lambda: step(levels[:1])) if args.no_graph else GraphedStep(levels[:1])
         ms_layer = timed(run_layer, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
+        ev_layer = timed_events(run_layer, max(args.steps, 50))
         ms_eager = timed(lambda: step(levels), args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
 
         stages = profile_level(lib, lv0, reps=5)
@@ -335,15 +387,24 @@ def run_rank(args):
             dom = max(core, key=lambda t: core[t][0])
             sec = core[dom][0] * 1e-3
             gbs, tf = own[dom] / sec / 1e9, fl.get(dom, 0) / sec / 1e12
-            traffic = None
-            try:  # measured PMC traffic of the same kernel (separate rocprofv3 --pmc passes, committed under profiles/)
+            # measured PMC traffic of the same kernel: separate rocprofv3 --pmc passes of an EARLIER run, committed under
+            # profiles/ with the hash of the kernel sources they were taken with -- reported only while that still matches
+            traffic, traffic_source = None, "none (no PMC file for this workload / precision)"
+            try:
                 with open(TRAFFIC_JSON) as fh:
-                    tr = json.load(fh).get(dom) if (args.precision == "bf16x3" and args.workload == "headline") else None
-                traffic = tr["hbm_bytes"] if tr else None
+                    tj = json.load(fh)
+                if args.precision == "bf16x3" and args.workload == "headline":
+                    if tj.get("_library_source_sha") == library_source_sha():
+                        tr = tj.get(dom)
+                        traffic = tr["hbm_bytes"] if tr else None
+                        traffic_source = f"{os.path.relpath(TRAFFIC_JSON, ROOT)} (external: rocprofv3 --pmc passes, not this run; kernel sources {tj['_library_source_sha']})"
+                    else:
+                        traffic_source = (f"stale: {os.path.relpath(TRAFFIC_JSON, ROOT)} was measured with kernel sources "
+                                          f"{tj.get('_library_source_sha')}, this tree is {library_source_sha()}")
             except OSError:
-                pass
+                traffic_source = "none (profiles/ file missing)"
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBPS, 4), "traffic": traffic,
+                        "frac": round(gbs / PEAK_HBM_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                         "algorithmic_bytes_per_launch": own[dom],
                         "traffic_over_algorithmic": round(traffic / own[dom], 3) if traffic else None,
                         "mfma_frac": round(tf / peak_tf, 4), "avg_launch_ms": round(core[dom][0], 4),
@@ -360,9 +421,32 @@ def run_rank(args):
         sb = sum(W.layer_bytes(lv["n"], lv["e"], frames, lv["c"]) for lv in levels)
         result["roofline"] = roofline
         result["single_layer"] = {"ms_per_step": round(ms_layer, 4), "value": mpts(ms_layer), "unit": "Mpoints/s",
-                                  "algorithmic_bytes": lb,
+                                  "hip_events": ev_layer, "algorithmic_bytes": lb,
                                   "intermediate_bytes_per_element": dict(zip(("T", "U", "grad_T"), per_el)),
                                   "least_bytes_with_intermediates": sum(moved.values())}
+        # What this decomposition can reach at best: every launch moves its owned bytes plus the row-sized intermediates
+        # (T, U, grad_T) exactly once each way, at the rate this chip streams a plain copy.  The edge phase and its
+        # contraction cannot share a CU (the contraction's weight operand is 512 KB of split bf16 against 160 KB of LDS,
+        # DESIGN.md 4.6a), so T / U / grad_T cross HBM and this -- not the 8 TB/s roofline on algorithmic bytes -- is the
+        # ceiling of the design as built.
+        rate = streaming_rate_gbps()
+        least_stack = 0
+        for lv in levels:
+            shp_l = _lib.Se3Shape(lv["n"], lv["n"], lv["e"], frames, frames, lv["c"], lv["c"], W.NUM_BASIS,
+                                  _lib.PRECISIONS[args.precision])
+            pe = tuple(int(lib.se3conv_intermediate_bytes_per_element(C.byref(shp_l), w)) for w in range(3))
+            least_stack += sum(W.stage_moved_bytes(lv["n"], lv["e"], frames, lv["c"], pe).values())
+        ceil_layer_ms = sum(moved.values()) / (rate * 1e9) * 1e3
+        ceil_stack_ms = least_stack / (rate * 1e9) * 1e3
+        result["design_ceiling"] = {
+            "streaming_rate_GBps": round(rate, 1), "rate_method": "1 GiB device-to-device copy, 2 GiB moved, best of 6 (HIP events)",
+            "layer": {"least_bytes_with_intermediates": sum(moved.values()), "ms": round(ceil_layer_ms, 4),
+                      "value": mpts(ceil_layer_ms), "achieved_over_ceiling": round(ceil_layer_ms / ms_layer, 4)},
+            "stack": {"least_bytes_with_intermediates": least_stack, "ms": round(ceil_stack_ms, 4),
+                      "value": mpts(ceil_stack_ms), "achieved_over_ceiling": round(ceil_stack_ms / ms_step, 4)},
+            "note": "least bytes = algorithmic bytes + T, U, grad_T once per producer and per consumer (3 / 3 / 4 bytes per "
+                    "element here); the 50 Mpoints/s / 40 % target of BASELINE.json needs a decomposition that keeps row tiles "
+                    "on the CU, which 160 KB of LDS against a 512 KB weight operand does not allow at fp32-level accuracy"}
         result["layer_frac"] = round(lb / (ms_layer * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
         result["stack_frac"] = round(sb / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
         result["stack_algorithmic_bytes"] = sb

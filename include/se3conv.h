@@ -17,14 +17,15 @@
  *   - re-entrant: calls on different streams (or from different threads) share no events, streams
  *     or buffers.  Process-wide state, all of it listed here: (1) the profiling switch below;
  *     (2) se3conv_bwd keeps one internal side stream + fork/join event pair per (device, caller
- *     stream) it has been called on, created on first use, for running its two branches side by side
- *     on mid-sized levels -- the side stream is always joined back into `stream` before the call
- *     returns, on error paths too; (3) kernel-variant switches read ONCE from the environment at first
- *     use (A/B and ablation knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP,
- *     SE3_OVERLAP_ROWS, SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_STREAM,
- *     SE3_PAIR_STREAM (+ _WGS, _NOSTORE), SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS), SE3_BWD_MERGE, SE3CONV_FUSED
- *     (+ _ROWS).  `t_save` written by se3conv_fwd must be consumed
- *     by se3conv_bwd in the same process (same switches);
+ *     stream) it has been called on, for running its two branches side by side on mid-sized levels --
+ *     the side stream is always joined back into `stream` before the call returns, on error paths too.
+ *     These objects are only ever created by a call whose stream is NOT being captured into a HIP graph:
+ *     every eager se3conv_fwd / se3conv_bwd keeps two spare sets per device ready, a capturing stream that
+ *     is new to the library takes a spare, and if there is none (no eager call happened before the capture)
+ *     the backward pass does not fork -- same results, branches back to back; (3) kernel-variant switches read ONCE from the environment at first
+ *     use (A/B knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP, SE3_OVERLAP_ROWS,
+ *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS).
+ *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - return value: SE3_OK (0) or a negative SE3_ERR_* code; no exceptions cross the boundary.
  *
  * Layouts: points [N,3]; frames [N,F,9] = row-major 3x3 per (point,frame)
@@ -55,7 +56,9 @@ extern "C" {
 typedef struct se3conv_shape {
   int64_t n_in;    /* points of the input (source) cloud                    */
   int64_t n_out;   /* points of the output (sample) cloud                   */
-  int64_t n_edges; /* point-level edges E                                   */
+  int64_t n_edges; /* rows of the point-level edge list `neighbors`.  An UPPER BOUND on the edge count E: the kernels
+                    * walk the offsets `ends` / `t_ends` and never read a row those do not reach, so the capacity-sized
+                    * buffer of se3_ball_query_bounded is passed with n_edges = capacity (rows past ends[-1] unset)   */
   int32_t f_in;    /* frames per input point  (PointcloudRotEquiv.n_frames_) */
   int32_t f_out;   /* frames per output point                               */
   int32_t c_in;    /* input feature channels                                */
@@ -134,6 +137,21 @@ int se3_segment_pool(const float* src, const int32_t* sorted_ids, const int32_t*
 int se3_segment_unpool(const float* cell_vals, const int32_t* cell_ids, const int32_t* cell_ends, const int32_t* arg,
                        int64_t n, int32_t channels, int32_t mode, float* out, void* stream);
 
+/* Random one-point-per-cell sub-sampling  <-  GridSubSample(..., p_rnd_sample=True), pc/GridSubSample.py:43-54, 66-67,
+ * 83-91 (the task scripts build their output cloud with it every step: tasks/SemSeg/train_dfaust_rot.py:143-149).
+ * se3_grid_pick: u [n_cells] f32 in [0,1) (device; the caller draws it, e.g. torch.rand on the GPU) ->
+ *   ids [n_cells] = start(c) + floor(u[c] * count(c)): positions in the cell-sorted point list (the reference's `ids_`)
+ *   picked [n_cells] = sorted_ids[ids[c]]: the point that represents cell c.
+ *   floor(u * count) is clamped to count - 1 (in fp32 the product can round up to count, which in the reference selects
+ *   a point of the next cell).  No host synchronisation.
+ * se3_rows_gather: out[r] = src[idx[r]], rows of `row_bytes` bytes of any element type (__subsample_tensor__ :67).
+ * se3_rows_scatter: out[idx[r]] = src[r] for unique idx; the caller zero-fills out (__upsample_tensor__ :83-91, and the
+ *   gradient of the gather). */
+int se3_grid_pick(const int32_t* cell_ends, const int32_t* sorted_ids, const float* u, int64_t n_cells, int32_t* ids,
+                  int32_t* picked, void* stream);
+int se3_rows_gather(const void* src, const int32_t* idx, int64_t n_out, int64_t row_bytes, void* out, void* stream);
+int se3_rows_scatter(const void* src, const int32_t* idx, int64_t n_src, int64_t row_bytes, void* out, void* stream);
+
 /* Frame pooling (scope row f-3)  <-  PointcloudRotEquiv.feature_pooling (pc/PointcloudRotEquiv.py:224-251): the F rows
  * point*F + frame of x [n_points*F, C] -> out [n_points, C]; `arg` [n_points, C] (max / min only) = winning frame.
  * se3_frame_unpool is its gradient: grad_out [n_points, C] -> grad_x [n_points*F, C]. */
@@ -202,6 +220,14 @@ int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int
 size_t se3_csr_transpose_workspace_bytes(int64_t n_edges);
 int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, void* workspace,
                       size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream);
+/* The same for a capacity-sized buffer of se3_ball_query_bounded between two DIFFERENT clouds: `neighbors` has n_rows
+ * rows of which only the first *n_valid (device word, e.g. info[0] of that call; clamped to n_rows) are edges -- the
+ * unset tail is ignored (it sorts behind every group and no offset reaches it), t_samples [n_rows], t_ends [n_src].
+ * Workspace: se3_csr_transpose_workspace_bytes(n_rows).  No host synchronisation.  If the buffer overflowed
+ * (info[1] != 0) the forward list is truncated and so is its transpose: outputs and gradients then belong to the
+ * truncated graph, consistently -- rebuild with a larger buffer. */
+int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_rows, const int32_t* n_valid, int64_t n_src,
+                              void* workspace, size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rot tensors  <-  PNEConvLayerRotEquiv.get_rot_tenors
@@ -215,6 +241,18 @@ int se3_rot_tensors(const float* pts_in, const float* pts_out, const float* fram
                     const float* frames_out, const int32_t* neighbors, const int32_t* ends,
                     const float* rho, const se3conv_shape* shape, float* desc,
                     int32_t* fe_neighbors, int32_t* fe_ends, void* stream);
+/* The same with the relative rotation R_out^T R_in in any representation of get_relative_rot
+ * (point_cloud_lib/pc/RotationFunctions.py:549-600; the factory's p_rel_rot, PNEConvLayerRotEquiv.py:236-281):
+ * "6D" = its first two rows (desc [E',9], what the fused operator implements), "matrix" = all nine entries
+ * (desc [E',12]), "quaternion" = real part first (desc [E',7]).  The two others run through the materialised
+ * formulation (this call + se3_feat_basis_proj); no shipped configuration uses them. */
+#define SE3_REL_ROT_6D 0
+#define SE3_REL_ROT_MATRIX 1
+#define SE3_REL_ROT_QUATERNION 2
+int se3_rot_tensors_rel(const float* pts_in, const float* pts_out, const float* frames_in,
+                        const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                        const float* rho, const se3conv_shape* shape, int32_t rel_rot, float* desc,
+                        int32_t* fe_neighbors, int32_t* fe_ends, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * feat_basis_proj / feat_basis_proj_grad  <-  point_cloud_lib_ops.feat_basis_proj{,_grad}
@@ -278,8 +316,11 @@ int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_i
  * reference frames (scope row f-1: upstream of the operator, frames are an input of the hot path)
  *   se3_knn_query  <-  point_cloud_lib_ops.knn_query (custom_ops/knn_query/knn_query.cuh:25-28, kernel
  *     knn_query.cu:18-132): exact k nearest neighbours inside the point's batch element (batch ids sorted),
- *     the point itself first, ascending distance, ties to the lower index, -1 padded; k <= 32.
- *     pts [n,3] f32, batch_ids [n] i32 -> out [n,k] i32.
+ *     the point itself first, ascending distance, ties to the lower index, -1 padded; k <= 64 (the reference
+ *     kernel's limit, knn_query.cu:167).  pts [n,3] f32, batch_ids [n] i32 -> out [n,k] i32.
+ *   se3_knn_query_pair <- the torch_cluster.knn call of pc/KnnNeighborhood.py:77-84 (neighbourhoods between two
+ *     clouds): for every query point the k nearest SOURCE points of the same batch element, same order and padding;
+ *     both batch-id arrays sorted.  src_pts [n_src,3], q_pts [n_q,3] -> out [n_q,k] i32 (source indices).
  *   se3_pca_frames <-  sample_reference_frames_pca (point_cloud_lib/pc/RotationFunctions.py:307-406):
  *     covariance of the k neighbours (missing ones = the point itself), symmetric 3x3 eigen-decomposition,
  *     right-handed orientation fix and the sign-flipped copies.  axis_fixed < 0: frames [n,4,9] (eigenvalues
@@ -289,6 +330,8 @@ int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_i
  * ------------------------------------------------------------------------------------------- */
 int se3_knn_query(const float* pts, const int32_t* batch_ids, int64_t n, int32_t k, int32_t* out,
                   void* stream);
+int se3_knn_query_pair(const float* src_pts, const int32_t* src_batch, int64_t n_src, const float* q_pts,
+                       const int32_t* q_batch, int64_t n_q, int32_t k, int32_t* out, void* stream);
 /* Same result through a cell grid (the role of the reference's sorted sweep, knn_query.cu:52-128: prune the
  * candidates, stay exact): cells of size cell_size[0] (device scalar, same value in [0..2]) over the per-batch
  * boxes aabb_min [B,3] / num_cells [3] (device, as for se3_compute_keys); a query whose k-th candidate inside its
@@ -344,11 +387,15 @@ int se3_bias_gelu_bwd(const float* g, const float* z, const float* bias, int64_t
  * only prints wall-clock per batch, tasks/SemSeg/train_dfaust_rot.py:239-296).  When enabled, every
  * kernel launch of the fused operator is bracketed by hipEvents on its own launch stream; read
  * accumulates milliseconds and launch counts per stage tag ("edge_t_fwd", "gemm_out", "gemm_gradT",
- * "edge_param_grad", "gemm_gradW", "edge_t_transposed", "gemm_gradX", "edge_t_recompute", "prep"; the opt-in merged
- * backward adds "gemm_H" / "edge_bwd", the grid kNN "knn_sort" / "knn_cells" / "knn_fallback").
+ * "edge_param_grad", "gemm_gradW", "edge_t_transposed", "gemm_gradX", "edge_t_recompute", "prep"; the grid kNN adds
+ * "knn_sort" / "knn_cells" / "knn_fallback").
  * Off by default.
  * ------------------------------------------------------------------------------------------- */
 int se3_profile_enable(int on);
+/* Introspection of process-wide state (2) above, for tests of the capture contract: stats[0] = caller streams that own
+ * an internal side stream, stats[1] = spare (stream, events) sets ready on the current device, stats[2] = sets created
+ * so far in this process.  Sets are only created by calls whose stream is NOT being captured. */
+int se3_side_stream_stats(int32_t* stats);
 int se3_profile_reset(void);
 int se3_profile_read(const char* tag, double* total_ms, int64_t* launches);
 int se3_profile_tags(char* buf, size_t len);

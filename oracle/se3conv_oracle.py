@@ -264,7 +264,8 @@ def edge_descriptors(pts_in, pts_out, frames_in, frames_out, neighbors, rho) -> 
     return torch.cat((loc, rel6), -1).reshape(-1, f_out * f_in, 9)
 
 
-def get_rot_tensors(pts_in, pts_out, frames_in, frames_out, neighbors, rho, n_rows=None) -> Dict[str, torch.Tensor]:
+def get_rot_tensors(pts_in, pts_out, frames_in, frames_out, neighbors, rho, n_rows=None,
+                    rel_rot: str = "6D") -> Dict[str, torch.Tensor]:
     """Restatement of ``PNEConvLayerRotEquiv.get_rot_tenors`` (:62-128).
 
     Returns ``rel_pts_rel_orient [E',9]``, ``neighbs [E',2]`` (col0 = s*F_out+a,
@@ -275,7 +276,8 @@ def get_rot_tensors(pts_in, pts_out, frames_in, frames_out, neighbors, rho, n_ro
     fixed length the HIP path uses.
     """
     f_out, f_in = frames_out.shape[1], frames_in.shape[1]
-    desc = edge_descriptors(pts_in, pts_out, frames_in, frames_out, neighbors, rho).reshape(-1, 9)
+    desc = edge_descriptors_rel(pts_in, pts_out, frames_in, frames_out, neighbors, rho, rel_rot)
+    desc = desc.reshape(-1, desc.shape[-1])  # D = 9 ("6D"), 12 ("matrix") or 7 ("quaternion")
     e = neighbors.shape[0]
     a = torch.arange(f_out).repeat_interleave(f_in).repeat(e)
     b = torch.arange(f_in).repeat(f_out).repeat(e)
@@ -361,7 +363,7 @@ def feat_basis_proj_grad(pt_basis, pt_features, neighbors, ends, grad_t):
 
 
 def conv_forward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_axes, proj_biases,
-                 conv_weights, rho, nu, pad_rows: bool = True, act: str = "gelu") -> torch.Tensor:
+                 conv_weights, rho, nu, pad_rows: bool = True, act: str = "gelu", rel_rot: str = "6D") -> torch.Tensor:
     """One ``PNEConvLayerRotEquiv`` forward ("mlp_*" branch, :178-216), differentiable
     w.r.t. ``feat, proj_axes, proj_biases, conv_weights`` through torch autograd.
 
@@ -371,7 +373,7 @@ def conv_forward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_a
     f_out, f_in = frames_out.shape[1], frames_in.shape[1]
     with torch.no_grad():
         rt = get_rot_tensors(pts_in, pts_out, frames_in, frames_out, neighbors, rho,
-                             n_rows=pts_out.shape[0] * f_out if pad_rows else None)
+                             n_rows=pts_out.shape[0] * f_out if pad_rows else None, rel_rot=rel_rot)
     phi = kernel_mlp(rt["rel_pts_rel_orient"], proj_axes, proj_biases, act)
     seg = rt["neighbs"][:, 0]
     src = rt["neighbs"][:, 1]
@@ -384,7 +386,8 @@ def conv_forward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_a
 
 
 def conv_forward_backward(pts_in, pts_out, frames_in, frames_out, neighbors, feat, proj_axes,
-                          proj_biases, conv_weights, rho, nu, grad_out, dtype=torch.float32, act: str = "gelu"):
+                          proj_biases, conv_weights, rho, nu, grad_out, dtype=torch.float32, act: str = "gelu",
+                          rel_rot: str = "6D"):
     """Forward + autograd backward in ``dtype``; returns ``out, dX, dA, dbeta, dW``."""
     cast = lambda t: t.detach().to(dtype)
     x = cast(feat).requires_grad_(True)
@@ -392,7 +395,7 @@ def conv_forward_backward(pts_in, pts_out, frames_in, frames_out, neighbors, fea
     b = cast(proj_biases).requires_grad_(True)
     w = cast(conv_weights).requires_grad_(True)
     out = conv_forward(cast(pts_in), cast(pts_out), cast(frames_in), cast(frames_out), neighbors, x, a, b, w,
-                       cast(torch.as_tensor(rho)), cast(torch.as_tensor(nu)), act=act)
+                       cast(torch.as_tensor(rho)), cast(torch.as_tensor(nu)), act=act, rel_rot=rel_rot)
     out.backward(cast(grad_out))
     return out.detach(), x.grad, a.grad, b.grad, w.grad
 
@@ -535,3 +538,86 @@ def frame_pool(x: torch.Tensor, n_frames: int, method: str) -> torch.Tensor:
     n = x.shape[0] // n_frames
     ids = torch.arange(n, dtype=torch.int64).repeat_interleave(n_frames)
     return segment_pool(x, ids, n, method)
+
+
+# ------------------------------------------------------------ random grid sub-sample, two-cloud k-NN (rows f-2, f-1)
+def grid_subsample_rnd(cell_ids: torch.Tensor, u: torch.Tensor):
+    """``GridSubSample(..., p_rnd_sample=True)`` (GridSubSample.py:43-54) given the uniform numbers ``u [n_cells]`` the
+    reference draws with ``torch.rand``: per-cell counts (scatter_add of ones over the sorted cell ids), exclusive
+    offsets (cumsum, padded, :47-50), ``ids = floor(u * count) + offset`` (:52-54) -- positions in the cell-sorted
+    point list ``sorted_ids = argsort(cell_ids)`` (Grid.py:48; stable here, the reference's argsort leaves the order
+    inside a cell open).  Returns ``(sorted_ids, ids, picked = sorted_ids[ids])``; the product is clamped to
+    count - 1 as the HIP path does (fp32 rounding of u * count)."""
+    cid = cell_ids.to(torch.int64)
+    sorted_ids = torch.argsort(cid, stable=True)
+    counts = torch.bincount(cid)
+    offsets = torch.cumsum(counts, 0) - counts
+    off = torch.floor(u.to(torch.float32) * counts.to(torch.float32)).to(torch.int64)
+    off = torch.minimum(off.clamp_min(0), counts - 1)
+    ids = offsets + off
+    return sorted_ids, ids, sorted_ids[ids]
+
+
+def rows_upsample_rnd(x: torch.Tensor, picked: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """``__upsample_tensor__`` of the random mode (GridSubSample.py:83-91): zeros ``[n_rows, C]`` with the picked rows
+    set to ``x`` (``scatter_`` along dim 0)."""
+    out = torch.zeros((n_rows, x.shape[-1]), dtype=x.dtype)
+    return out.scatter(0, picked.to(torch.int64)[:, None].expand(-1, x.shape[-1]), x)
+
+
+def knn_query_pair(pts_src, batch_src, pts_q, batch_q, k: int) -> torch.Tensor:
+    """k nearest SOURCE points of every query inside its batch element (the ``torch_cluster.knn(x=src, y=samples, k,
+    batch_x, batch_y)`` call of KnnNeighborhood.py:77-84; torch-cluster 1.6.1 is not installed: documented semantics,
+    parity unpinned).  ``[N_q, k]`` int32 source indices, ascending (squared distance, index), ``-1`` padded."""
+    ps, pq = pts_src.to(torch.float32), pts_q.to(torch.float32)
+    out = torch.full((pq.shape[0], k), -1, dtype=torch.int32)
+    for b in torch.unique(batch_q):
+        qi = torch.nonzero(batch_q == b)[:, 0]
+        si = torch.nonzero(batch_src == b)[:, 0]
+        if si.numel() == 0:
+            continue
+        d = pq[qi][:, None, :] - ps[si][None, :, :]
+        d2 = torch.addcmul(torch.addcmul(d[..., 0] * d[..., 0], d[..., 1], d[..., 1]), d[..., 2], d[..., 2])
+        order = torch.argsort(d2, dim=1, stable=True)[:, :k]
+        out[qi, : order.shape[1]] = si[order].to(torch.int32)
+    return out
+
+
+# --------------------------------------------------- other relative-rotation descriptors (p_rel_rot, a1 / quirk 5)
+def matrix_to_quaternion(m: torch.Tensor) -> torch.Tensor:
+    """Rotation matrices ``[...,3,3]`` -> real-part-first quaternions (RotationFunctions.py:91-151, the pytorch3d
+    formulation: the four candidate quaternions, the one with the largest denominator is taken)."""
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(m.reshape(m.shape[:-2] + (9,)), dim=-1)
+    q_abs = torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1)
+    q_abs = torch.where(q_abs > 0, torch.sqrt(q_abs.clamp_min(0)), torch.zeros_like(q_abs))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    cand = cand / (2.0 * q_abs[..., None].clamp_min(0.1))
+    best = torch.nn.functional.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5
+    return cand[best, :].reshape(m.shape[:-2] + (4,))
+
+
+def edge_descriptors_rel(pts_in, pts_out, frames_in, frames_out, neighbors, rho, rel_rot: str = "6D") -> torch.Tensor:
+    """``edge_descriptors`` for the three relative-rotation representations of ``get_relative_rot``
+    (RotationFunctions.py:549-600): "6D" (9-D descriptor), "matrix" (all nine entries of R_out^T R_in: 12-D) and
+    "quaternion" (7-D).  ``[E, F_out*F_in, D]``."""
+    if rel_rot == "6D":
+        return edge_descriptors(pts_in, pts_out, frames_in, frames_out, neighbors, rho)
+    s = neighbors[:, 0].to(torch.int64)
+    p = neighbors[:, 1].to(torch.int64)
+    f_out, f_in = frames_out.shape[1], frames_in.shape[1]
+    rel = (pts_in[p] - pts_out[s]) * rho
+    r_out = frames_out[s].reshape(-1, f_out, 3, 3)
+    r_in = frames_in[p].reshape(-1, f_in, 3, 3)
+    loc = torch.matmul(rel[:, None, None, :], r_out).squeeze(2)[:, :, None, :].expand(-1, -1, f_in, -1)
+    relrot = torch.matmul(r_out.transpose(2, 3)[:, :, None], r_in[:, None])  # [E,Fo,Fi,3,3]
+    if rel_rot == "matrix":
+        tail = relrot.reshape(-1, f_out, f_in, 9)
+    elif rel_rot == "quaternion":
+        tail = matrix_to_quaternion(relrot)
+    else:
+        raise ValueError(rel_rot)
+    return torch.cat((loc, tail), -1).reshape(-1, f_out * f_in, 3 + tail.shape[-1])

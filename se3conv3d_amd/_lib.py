@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", f"libse3conv_hip{os.environ.get('SE3_LIB_SU
 
 SE3_OK = 0
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
+REL_ROT = {"6D": (0, 9), "matrix": (1, 12), "quaternion": (2, 7)}  # p_rel_rot -> (SE3_REL_ROT_*, descriptor dims)
 
 
 class Se3Shape(C.Structure):
@@ -56,7 +57,9 @@ SIGNATURES = {
     "se3_ball_query_bounded": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _I32, _P, _SZ, _I64, _P, _P, _P, _P, _P]),
     "se3_csr_transpose_workspace_bytes": (_SZ, [_I64]),
     "se3_csr_transpose": (C.c_int, [_P, _I64, _I64, _P, _SZ, _P, _P, _P]),
+    "se3_csr_transpose_bounded": (C.c_int, [_P, _I64, _P, _I64, _P, _SZ, _P, _P, _P]),
     "se3_rot_tensors": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SHP, _P, _P, _P, _P]),
+    "se3_rot_tensors_rel": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SHP, _I32, _P, _P, _P, _P]),
     "se3_feat_basis_proj": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P]),
     "se3_feat_basis_proj_grad": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P]),
     "se3conv_fwd_workspace_bytes": (_SZ, [_SHP, C.c_int]),
@@ -64,6 +67,10 @@ SIGNATURES = {
     "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
     "se3conv_bwd": (C.c_int, [_P] * 16 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
     "se3_knn_query": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "se3_knn_query_pair": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I32, _P, _P]),
+    "se3_grid_pick": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
+    "se3_rows_gather": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
+    "se3_rows_scatter": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "se3_knn_query_grid_workspace_bytes": (C.c_size_t, [_I64]),
     "se3_knn_query_grid": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_size_t, _P]),
     "se3_pca_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
@@ -74,6 +81,7 @@ SIGNATURES = {
     "se3_skip_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "se3_skip_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),
     "se3_bias_gelu_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),
+    "se3_side_stream_stats": (C.c_int, [_P]),
     "se3_profile_enable": (C.c_int, [C.c_int]),
     "se3_profile_reset": (C.c_int, []),
     "se3_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -68,12 +68,37 @@ __global__ __launch_bounds__(256) void reduce_param_partials_kernel(const float*
 
 // ---- API-parity kernels (not on the fused path) ------------------------------------------------
 
-// get_rot_tenors materialised (PNEConvLayerRotEquiv.py:62-128): one thread per (edge, a, b).
+// Rotation matrix (row-major m[9]) -> real-part-first quaternion as RotationFunctions.py:91-151 computes it: the four
+// candidates q * 2 q_r, q * 2 q_i, ..., the one with the largest |component| is divided out (denominator floored at 0.1).
+__device__ __forceinline__ void matrix_to_quaternion(const float m[9], float q[4]) {
+  const float t[4] = {1.0f + m[0] + m[4] + m[8], 1.0f + m[0] - m[4] - m[8], 1.0f - m[0] + m[4] - m[8],
+                      1.0f - m[0] - m[4] + m[8]};
+  float qa[4];
+  int best = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    qa[i] = t[i] > 0.f ? sqrtf(t[i]) : 0.f;
+    if (qa[i] > qa[best]) best = i;  // first maximum, as torch.argmax
+  }
+  const float c[4][4] = {{qa[0] * qa[0], m[7] - m[5], m[2] - m[6], m[3] - m[1]},
+                         {m[7] - m[5], qa[1] * qa[1], m[3] + m[1], m[2] + m[6]},
+                         {m[2] - m[6], m[3] + m[1], qa[2] * qa[2], m[5] + m[7]},
+                         {m[3] - m[1], m[6] + m[2], m[7] + m[5], qa[3] * qa[3]}};
+  const float den = 2.0f * fmaxf(qa[best], 0.1f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = (best == 0 ? c[0][i] : best == 1 ? c[1][i] : best == 2 ? c[2][i] : c[3][i]) / den;
+}
+
+// get_rot_tenors materialised (PNEConvLayerRotEquiv.py:62-128): one thread per (edge, a, b).  REL = representation of
+// the relative rotation R_out^T R_in (get_relative_rot, RotationFunctions.py:549-600): 0 "6D" (its first two rows, D = 9),
+// 1 "matrix" (all nine entries, D = 12), 2 "quaternion" (D = 7).
+template <int REL>
 __global__ void rot_tensors_kernel(const float* __restrict__ pts_in, const float* __restrict__ pts_out,
                                    const float* __restrict__ frames_in, const float* __restrict__ frames_out,
                                    const int32_t* __restrict__ neighbors, const int32_t* __restrict__ ends,
                                    const float* __restrict__ rho_p, int64_t n_edges, int f_in, int f_out,
                                    float* __restrict__ desc, int32_t* __restrict__ fe_neighbors) {
+  constexpr int D = REL == 0 ? 9 : (REL == 1 ? 12 : 7);
   const float rho = *rho_p;
   const int ff = f_in * f_out;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_edges * ff;
@@ -92,8 +117,27 @@ __global__ void rot_tensors_kernel(const float* __restrict__ pts_in, const float
     for (int i = 0; i < 9; ++i)
       ri[i] = frames_in[((int64_t)p * f_in + b) * 9 + i], ro[i] = frames_out[((int64_t)s * f_out + a) * 9 + i];
     edge_descriptor(x, ri, y, ro, rho, d);
+    if constexpr (REL == 0) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) desc[idx * 9 + i] = d[i];
+      for (int i = 0; i < 9; ++i) desc[idx * 9 + i] = d[i];
+    } else {
+      float rel[9];  // d[3..8] are rows 0, 1 of R_out^T R_in; row 2 the same way
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rel[i] = d[3 + i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rel[6 + c] = ro[2] * ri[c] + ro[5] * ri[3 + c] + ro[8] * ri[6 + c];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) desc[idx * D + i] = d[i];
+      if constexpr (REL == 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) desc[idx * D + 3 + i] = rel[i];
+      } else {
+        float q[4];
+        matrix_to_quaternion(rel, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) desc[idx * D + 3 + i] = q[i];
+      }
+    }
     fe_neighbors[idx * 2] = s * f_out + a;
     fe_neighbors[idx * 2 + 1] = p * f_in + b;
   }
@@ -270,8 +314,6 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   }
   l.t = (want_params && !have_t) ? take(rows_out * s->c_in * kb * 4) : 0;
   l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
-  if (fast && edge_bwd_pair_bf16_blocks((int64_t)rows_in / 2) > l.n_param_partials)
-    l.n_param_partials = edge_bwd_pair_bf16_blocks((int64_t)rows_in / 2);
   l.param_partials = want_params ? take((size_t)l.n_param_partials * edge_param_grad_bf16_channel_blocks(s->c_in) *
                                          kDescExt * kBasis * 4) : 0;
   l.tn_splits = gemm_tn_splits((int64_t)rows_out, s->c_in * (int)kb, s->c_out);
@@ -284,33 +326,91 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
 // and the feature branch (transposed edge kernel -> grad_X GEMM) are independent.  Measured on MI355X at the headline
 // shape: the kernels slow each other down more than in proportion (2.15 ms side by side vs 2.07 back to back), so
 // it is used for mid-sized levels only (kOverlapRows; SE3_OVERLAP=1 forces it, SE3_OVERLAP_ROWS=n moves the limit).
-// The stream and its two events are created once per process.
 // backward branches on two streams for this range of output rows: above it every kernel fills the chip by itself
 // (measured: 2.15 vs 2.07 ms at 131 k rows), below it the fork / join costs more than the overlap returns
 constexpr int kOverlapRows = 32768, kOverlapMinRows = 4096;
-// One side stream + fork / join event pair per (device, caller stream), created on first use ON that device and kept
-// for the life of the process: two backward calls on two caller streams (or threads) never share events or a stream,
-// and a caller stream on device 1 never gets a side stream of device 0.  Two calls racing on the SAME caller stream are
-// the caller's race anyway.  The table only grows by the number of distinct streams the caller uses.
+// One side stream + fork / join event pair per (device, caller stream), kept for the life of the process: two backward
+// calls on two caller streams (or threads) never share events or a stream, and a caller stream on device 1 never gets a
+// side stream of device 0.  Two calls racing on the SAME caller stream are the caller's race anyway.  The table only
+// grows by the number of distinct streams the caller uses.
+// Nothing is CREATED while the caller's stream is being captured into a HIP graph (creating runtime objects in the middle
+// of a capture is what a capture should not have to survive): every eager call of se3conv_fwd / se3conv_bwd keeps a few
+// spare (stream, events) sets per device ready, a capturing caller stream that is new to the table takes one of those,
+// and when there is none -- the library was never called outside a capture in this process -- the backward pass simply
+// does not fork (same results, the two branches back to back).  INTEGRATION.md: warm up eagerly before capturing.
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   bool ok = false;
 };
+constexpr size_t kSpareSideStreams = 2;
+struct SideTable {
+  std::mutex mu;
+  std::map<std::pair<int, hipStream_t>, SideStream> by_stream;
+  std::map<int, std::vector<SideStream>> spare;
+};
+SideTable& side_table() {
+  static SideTable t;
+  return t;
+}
+int g_side_streams_created = 0;  // under side_table().mu
+SideStream make_side_stream() {
+  SideStream v;
+  ++g_side_streams_created;
+  v.ok = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&v.fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&v.join, hipEventDisableTiming) == hipSuccess;
+  return v;
+}
+bool stream_is_capturing(hipStream_t s) {
+  if (s == nullptr) return false;  // the legacy default stream cannot be captured (and must not be queried during a capture)
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;  // cannot tell: behave as inside a capture (create nothing)
+  }
+  return st != hipStreamCaptureStatusNone;
+}
+// called by every eager se3conv_fwd / se3conv_bwd: the spares a later capture may need
+void keep_side_streams_ready(hipStream_t caller) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  SideTable& t = side_table();
+  {
+    std::lock_guard<std::mutex> lk(t.mu);
+    auto it = t.spare.find(dev);
+    if (it != t.spare.end() && it->second.size() >= kSpareSideStreams) return;
+  }
+  if (stream_is_capturing(caller)) return;
+  std::lock_guard<std::mutex> lk(t.mu);
+  auto& sp = t.spare[dev];
+  while (sp.size() < kSpareSideStreams) {
+    SideStream v = make_side_stream();
+    if (!v.ok) break;
+    sp.push_back(v);
+  }
+}
 SideStream* side_stream_for(hipStream_t caller) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SideStream> pool;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = pool.find({dev, caller});
-  if (it == pool.end()) {
-    SideStream v;
-    v.ok = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking) == hipSuccess &&
-           hipEventCreateWithFlags(&v.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&v.join, hipEventDisableTiming) == hipSuccess;
-    it = pool.emplace(std::make_pair(dev, caller), v).first;
+  SideTable& t = side_table();
+  {
+    std::lock_guard<std::mutex> lk(t.mu);
+    auto it = t.by_stream.find({dev, caller});
+    if (it != t.by_stream.end()) return it->second.ok ? &it->second : nullptr;
   }
+  const bool capturing = stream_is_capturing(caller);
+  std::lock_guard<std::mutex> lk(t.mu);
+  SideStream v;
+  if (capturing) {
+    auto& sp = t.spare[dev];
+    if (sp.empty()) return nullptr;  // nothing prepared outside the capture: no fork
+    v = sp.back();
+    sp.pop_back();
+  } else {
+    v = make_side_stream();
+  }
+  auto it = t.by_stream.emplace(std::make_pair(dev, caller), v).first;
   return it->second.ok ? &it->second : nullptr;
 }
 // Joins the forked side stream back into the caller's stream on EVERY exit path of se3conv_bwd once the fork has
@@ -364,11 +464,11 @@ extern "C" const char* se3_error_string(int code) {
   }
 }
 
-extern "C" int se3_rot_tensors(const float* pts_in, const float* pts_out, const float* frames_in,
-                               const float* frames_out, const int32_t* neighbors, const int32_t* ends,
-                               const float* rho, const se3conv_shape* s, float* desc, int32_t* fe_neighbors,
-                               int32_t* fe_ends, void* stream_) {
-  if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
+extern "C" int se3_rot_tensors_rel(const float* pts_in, const float* pts_out, const float* frames_in,
+                                   const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                                   const float* rho, const se3conv_shape* s, int32_t rel_rot, float* desc,
+                                   int32_t* fe_neighbors, int32_t* fe_ends, void* stream_) {
+  if (!shape_ok(s) || rel_rot < SE3_REL_ROT_6D || rel_rot > SE3_REL_ROT_QUATERNION) return SE3_ERR_INVALID_ARGUMENT;
   if (s->n_edges * s->f_in * s->f_out >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
   hipStream_t stream = (hipStream_t)stream_;
   if (s->n_out > 0) {
@@ -379,11 +479,24 @@ extern "C" int se3_rot_tensors(const float* pts_in, const float* pts_out, const 
   if (s->n_edges > 0) {
     if (!pts_in || !pts_out || !frames_in || !frames_out || !neighbors || !ends || !rho || !desc || !fe_neighbors)
       return SE3_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(rot_tensors_kernel, dim3(grid_for(s->n_edges * s->f_in * s->f_out)), dim3(256), 0, stream, pts_in,
-                       pts_out, frames_in, frames_out, neighbors, ends, rho, s->n_edges, s->f_in, s->f_out, desc,
-                       fe_neighbors);
+    const dim3 grid(grid_for(s->n_edges * s->f_in * s->f_out));
+#define SE3_ROT(REL)                                                                                                  \
+  hipLaunchKernelGGL(rot_tensors_kernel<REL>, grid, dim3(256), 0, stream, pts_in, pts_out, frames_in, frames_out, neighbors, \
+                     ends, rho, s->n_edges, s->f_in, s->f_out, desc, fe_neighbors)
+    if (rel_rot == SE3_REL_ROT_6D) SE3_ROT(0);
+    else if (rel_rot == SE3_REL_ROT_MATRIX) SE3_ROT(1);
+    else SE3_ROT(2);
+#undef SE3_ROT
   }
   return check_launch();
+}
+
+extern "C" int se3_rot_tensors(const float* pts_in, const float* pts_out, const float* frames_in,
+                               const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                               const float* rho, const se3conv_shape* s, float* desc, int32_t* fe_neighbors,
+                               int32_t* fe_ends, void* stream) {
+  return se3_rot_tensors_rel(pts_in, pts_out, frames_in, frames_out, neighbors, ends, rho, s, SE3_REL_ROT_6D, desc,
+                             fe_neighbors, fe_ends, stream);
 }
 
 static bool basis_count_ok(int kb) { return kb == 8 || kb == 16 || kb == 32 || kb == 64; }
@@ -432,19 +545,14 @@ static bool t24_rows(const EdgeGeom& g, int channels, int64_t rows, int tn_cols)
 }
 
 // Bytes per element of the row-sized intermediates this shape would move (what a traffic model has to assume):
-// which = 0: T (forward, read again by the weight gradient), 1: U (feature gradient), 2: grad_T.  0: that tensor
-// never reaches memory (fused small-level kernel); < 0: bad shape.
+// which = 0: T (forward, read again by the weight gradient), 1: U (feature gradient), 2: grad_T.  < 0: bad shape.
 extern "C" int se3conv_intermediate_bytes_per_element(const se3conv_shape* s, int which) {
   if (!shape_ok(s) || which < 0 || which > 2) return SE3_ERR_INVALID_ARGUMENT;
   if (s->precision == SE3_PRECISION_FP32 || which == 2) return 4;
   EdgeGeom g = forward_geom(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
   EdgeGeom gt{};
   gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.n_nb = s->n_out, gt.transposed = 1;
-  if (which == 0) {
-    if (conv_fused_bf16_supported(g, s->c_in)) return 0;
-    return t24_rows(g, s->c_in, s->n_out * s->f_out, s->c_out) ? 3 : 4;
-  }
-  if (conv_fused_bf16_supported(gt, s->c_out)) return 0;
+  if (which == 0) return t24_rows(g, s->c_in, s->n_out * s->f_out, s->c_out) ? 3 : 4;
   return t24_rows(gt, s->c_out, s->n_in * s->f_in, 0) ? 3 : 4;
 }
 
@@ -466,6 +574,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   const FwdLayout l = fwd_layout(s, t_save != nullptr);
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
+  keep_side_streams_ready(stream);  // what a later captured se3conv_bwd may fork onto (never created inside a capture)
   char* ws = (char*)workspace;
   float* axes_ext = (float*)(ws + l.axes_ext);
   float* t = t_save ? t_save : (float*)(ws + l.t);
@@ -484,8 +593,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   const float inv_phi = inv_fin / kGeluOut;  // the bf16 edge kernels produce kGeluOut * phi (gelu_scaled)
-  const bool fused = conv_fused_bf16_supported(g, s->c_in);
-  const bool t24 = !fused && t24_rows(g, s->c_in, rows_out, s->c_out);  // se3conv_bwd decides the same way
+  const bool t24 = t24_rows(g, s->c_in, rows_out, s->c_out);  // se3conv_bwd decides the same way
   {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
@@ -500,9 +608,6 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
   }
-  if (fused)  // edge phase + contraction in one launch; T only if the caller wants it
-    return launch_conv_fused_bf16("conv_fused_fwd", g, featpk, s->n_in * s->f_in, axes_ext, rho, bt_hi, bt_lo, s->c_out,
-                                  out, (uint32_t*)t_save, nu, inv_phi, stream);
   if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream,
                                   -1, -1, t24))
     return rc;
@@ -534,6 +639,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   const BwdLayout l = bwd_layout(s, want_feat, want_params, t_save != nullptr);
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
+  keep_side_streams_ready(stream);
   char* ws = (char*)workspace;
   float* axes_ext = (float*)(ws + l.axes_ext);
   float* big = (float*)(ws + l.big);
@@ -561,11 +667,12 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                          wt, ck, s->c_out);
       if (int rc = launch_gemm_nn("gemm_gradT", grad_out, wt, big, rows_out, ck, s->c_out, nu, inv_fin, stream)) return rc;
       if (grad_axes || grad_biases) {
+        int n_part = 0;
         if (int rc = launch_edge_param_grad("edge_param_grad", g, feat, s->c_in, axes_ext, rho, big, partials,
-                                            l.n_param_partials, stream))
+                                            l.n_param_partials, &n_part, stream))
           return rc;
         hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
-                           l.n_param_partials, grad_axes, grad_biases, 1.0f);
+                           n_part, grad_axes, grad_biases, 1.0f);
       }
       if (grad_weights) {
         const float* t = t_save;
@@ -594,7 +701,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   }
 
   // ---- split-bf16 path: same stages, operands as packed words -----------------------------------------
-  uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);    // parameter branch: grad_T (or H) weights
+  uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);    // parameter branch: grad_T weights
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   uint16_t* bx_hi = (uint16_t*)(ws + l.bt2_hi);   // feature branch: grad_X weights
   uint16_t* bx_lo = (uint16_t*)(ws + l.bt2_lo);
@@ -603,12 +710,9 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   uint32_t* bigw = (uint32_t*)big;
   const float inv_phi = inv_fin / kGeluOut;  // T and U hold kGeluOut * (the reference's values), see gelu_scaled
   const bool feat_branch = want_feat && rows_in > 0;
-  const bool merged = feat_branch && want_params && (grad_axes || grad_biases) && rows_out > 0 && l.big_u != 0 &&
-                      edge_bwd_pair_bf16_supported(s->f_in, s->c_out);
-  const bool t24_t = !conv_fused_bf16_supported(g, s->c_in) && t24_rows(g, s->c_in, rows_out, s->c_out);  // as se3conv_fwd
-  const bool t24_u = feat_branch && !merged && !conv_fused_bf16_supported(gt, s->c_out) && t24_rows(gt, s->c_out, rows_in, 0);
+  const bool t24_t = t24_rows(g, s->c_in, rows_out, s->c_out);  // as se3conv_fwd
+  const bool t24_u = feat_branch && t24_rows(gt, s->c_out, rows_in, 0);
   const bool strip_t = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);            // grad_T = g W^T
-  const bool strip_h = gemm_strip_bf16_applicable(rows_in, s->c_out * kb, s->c_in);   // H = f W''
   {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
@@ -623,13 +727,15 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (want_params) {
       pb.split(feat, featpk, rows_in * s->c_in);
       // alpha = nu/F_in is folded into these weights (one multiply per weight instead of one per grad_T element)
-      if (merged) pb.weights(conv_weights, s->c_in, kb, s->c_out, 3, bt_hi, bt_lo, nu, inv_fin, strip_h);
-      else pb.weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, nu, inv_fin, strip_t);
+      pb.weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, nu, inv_fin, strip_t);
     }
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
     gt.ctr_geom = geom_in, gt.nb_geom = geom_out;
   }
+  // The sums that end the pass -- split-K partials of the grad_X GEMM, row-range partials of the weight-gradient GEMM,
+  // per-workgroup partials of d[A; beta] -- write final outputs nobody in this call reads: one launch folds them all
+  ReduceBatch final_sums;
   auto weight_gradient = [&]() -> int {
     if (!grad_weights) return SE3_OK;
     const uint32_t* t = (const uint32_t*)t_save;
@@ -640,32 +746,19 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       t = tt;
     }
     return launch_gemm_tn_bf16("gemm_gradW", t, gpk, grad_weights, tn_partials, l.tn_splits, rows_out, ck, s->c_out, nu,
-                               inv_phi, stream, t24_t);
+                               inv_phi, stream, t24_t, &final_sums);
   };
-
-  // Opt-in (SE3_BWD_MERGE): one walk over the transposed graph yields U (feature gradient) and d[A;beta]; grad_T and
-  // the output-major parameter pass are not needed.
-  if (merged) {
-    uint32_t* ubuf = (uint32_t*)(ws + l.big_u);
-    // H[(p,b)][o,k] = alpha * sum_i f[(p,b),i] W[i,k,o]
-    if (strip_h) {
-      if (int rc = launch_gemm_strip_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, rows_in, s->c_out * kb, s->c_in, stream)) return rc;
-    } else if (int rc = launch_gemm_nn_bf16("gemm_H", featpk, bt_hi, bt_lo, bigw, true, rows_in, s->c_out * kb, s->c_in,
-                                            (float*)(ws + l.split), nullptr, 1.0f, stream)) {
-      return rc;
-    }
+  // d[A; beta]: per-workgroup partial sums; their fixed-order reduction joins the batch (the bf16 kernels accumulate with
+  // 2 GELU', gelu_scaled_grad: the 0.5 is applied there)
+  auto param_gradients = [&](hipStream_t st) -> int {
+    if (!grad_axes && !grad_biases) return SE3_OK;
     int n_part = 0;
-    if (int rc = launch_edge_bwd_pair_bf16("edge_bwd", gt, gpk, rows_out, axes_ext, rho, bigw, ubuf, partials, &n_part,
-                                           stream))
+    if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
+                                             l.n_param_partials, &n_part, st))
       return rc;
-    hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
-                       grad_axes, grad_biases, 0.5f);  // the kernels accumulate with 2 GELU' (gelu_scaled_grad)
-    if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
-                                     (float*)(ws + l.split), nu, inv_phi, stream))
-      return rc;
-    if (int rc = weight_gradient()) return rc;
-    return check_launch();
-  }
+    final_sums.params(partials, n_part, grad_axes, grad_biases, 0.5f);
+    return SE3_OK;
+  };
 
   bool branch_forked = false;
   ForkJoin fj;  // joins on every exit path from here on
@@ -695,7 +788,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     // sit in that position, here only one does (gemm_gradX 0.221 -> 0.187 ms at the headline shape).
     // SE3_BWD_BRANCH_ORDER=1 restores branch-by-branch order.
     static const bool branch_order = getenv("SE3_BWD_BRANCH_ORDER") != nullptr;
-    if (!branch_order && !branch_forked && !conv_fused_bf16_supported(gt, s->c_out) && want_params && l.big_u != 0) {
+    if (!branch_order && !branch_forked && want_params && l.big_u != 0) {
       ubuf = (uint32_t*)(ws + l.big_u);
       fsplit = (float*)(ws + l.split2);
       if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs, -1, -1, t24_u))
@@ -706,31 +799,18 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                                               (float*)(ws + l.split), nullptr, 1.0f, stream)) {
         return rc;
       }
-      if (grad_axes || grad_biases) {
-        int n_part = 0;
-        if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
-                                                 l.n_param_partials, &n_part, stream))
-          return rc;
-        hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
-                           grad_axes, grad_biases, 0.5f);
-      }
+      if (int rc = param_gradients(stream)) return rc;
       if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
-                                       fsplit, nu, inv_phi, fs, t24_u))
+                                       fsplit, nu, inv_phi, fs, t24_u, &final_sums))
         return rc;
       if (int rc = weight_gradient()) return rc;
-      return check_launch();
+      return final_sums.launch(stream);
     }
-    if (conv_fused_bf16_supported(gt, s->c_out)) {
-      if (int rc = launch_conv_fused_bf16("conv_fused_gradX", gt, gpk, rows_out, axes_ext, rho, bx_hi, bx_lo, s->c_in, grad_feat,
-                                          nullptr, nu, inv_phi, fs))
-        return rc;
-    } else {
-      if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs, -1, -1, t24_u))
-        return rc;
-      if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
-                                       fsplit, nu, inv_phi, fs, t24_u))
-        return rc;
-    }
+    if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs, -1, -1, t24_u))
+      return rc;
+    if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
+                                     fsplit, nu, inv_phi, fs, t24_u, &final_sums))
+      return rc;
   }
   if (want_params) {
     if (strip_t) {
@@ -739,18 +819,11 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                                             (float*)(ws + l.split), nullptr, 1.0f, stream)) {
       return rc;
     }
-    if (grad_axes || grad_biases) {
-      int n_part = 0;
-      if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
-                                               l.n_param_partials, &n_part, stream))
-        return rc;
-      hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials, n_part,
-                         grad_axes, grad_biases, 0.5f);  // 2 GELU' in the kernel (gelu_scaled_grad)
-    }
+    if (int rc = param_gradients(stream)) return rc;
     if (int rc = weight_gradient()) return rc;
   }
-  if (int rc = fj.join()) return rc;
-  return check_launch();
+  if (int rc = fj.join()) return rc;  // the side stream's grad_X partials are complete before they are folded
+  return final_sums.launch(stream);
 }
 
 // ---- optional per-kernel timing ------------------------------------------------------------------
@@ -797,6 +870,19 @@ void prof_end(hipStream_t stream) {
   g_prof_open = nullptr;
 }
 }  // namespace se3
+
+extern "C" int se3_side_stream_stats(int32_t* stats) {
+  if (!stats) return SE3_ERR_INVALID_ARGUMENT;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SE3_ERR_LAUNCH;
+  se3::SideTable& t = se3::side_table();
+  std::lock_guard<std::mutex> lk(t.mu);
+  stats[0] = (int32_t)t.by_stream.size();
+  auto it = t.spare.find(dev);
+  stats[1] = it == t.spare.end() ? 0 : (int32_t)it->second.size();
+  stats[2] = se3::g_side_streams_created;
+  return SE3_OK;
+}
 
 extern "C" int se3_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(se3::g_prof_mu);

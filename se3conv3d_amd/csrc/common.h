@@ -297,7 +297,7 @@ int launch_edge_t(const char* tag, const EdgeGeom& g, const float* feat, int cha
                   const float* rho, float* t_out, hipStream_t stream);
 int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat, int channels,
                            const float* axes_ext, const float* rho, const float* grad_t, float* partials,
-                           int n_partials, hipStream_t stream);
+                           int n_partials, int* n_used, hipStream_t stream);
 int edge_param_grad_blocks(int64_t rows);
 
 int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, int64_t m, int n, int k,
@@ -307,6 +307,30 @@ int launch_gemm_tn(const char* tag, const float* a, const float* b, float* c, fl
 int gemm_tn_splits(int64_t m, int ka, int n);
 int launch_reduce_partials(const float* partials, float* out, int64_t count, int splits, const float* alpha_num,
                            float alpha_scale, hipStream_t stream);
+
+// Batched reductions behind the backward pass's last kernels (prep.hip): the split-K partials of the grad_X GEMM, the
+// row-range partials of the weight-gradient GEMM and the per-workgroup partial sums of d[A; beta] are independent
+// fixed-order sums -- collected here and folded by ONE launch at the end of se3conv_bwd instead of three (a launch is
+// 5-7 us on the small hierarchy levels whatever it does).
+struct ReduceJob {
+  int type, blocks;         // 0: out[i] = alpha * sum_z partials[z * count + i];  1: d[A; beta] from n_partials slots of 320
+  const float* partials;
+  void *out, *out2;         // type 1: grad_axes, grad_biases (either may be NULL)
+  int64_t count;
+  int splits, packed;       // packed: out holds packed hi/lo words
+  const float* alpha_num;
+  float alpha_scale;
+};
+struct ReduceJobs {
+  int count;
+  ReduceJob job[4];
+};
+struct ReduceBatch {
+  ReduceJobs jobs{};
+  void sum(const float* partials, void* out, int64_t count, int splits, const float* alpha_num, float alpha_scale, bool packed);
+  void params(const float* partials, int n_partials, float* grad_axes, float* grad_biases, float scale);
+  int launch(hipStream_t stream);
+};
 
 // split-bf16 path (edge_bf16.hip, gemm_bf16.hip)
 int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream);
@@ -318,24 +342,14 @@ int edge_param_grad_bf16_channel_blocks(int channels);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
                                 float* partials, int n_partials, int* n_used, hipStream_t stream);
-bool conv_fused_bf16_supported(const EdgeGeom& g, int gathered_channels);
-bool edge_bwd_pair_bf16_supported(int f_ctr, int gathered_channels);
-int edge_bwd_pair_bf16_blocks(int64_t items);
-int launch_edge_bwd_pair_bf16(const char* tag, const EdgeGeom& gt, const uint32_t* gpk, int64_t g_rows,
-                              const float* axes_ext, const float* rho, const uint32_t* h_rows, uint32_t* u_out,
-                              float* partials, int* n_partials, hipStream_t stream);
-int launch_conv_fused_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int64_t feat_rows,
-                           const float* axes_ext, const float* rho, const uint16_t* bt_hi, const uint16_t* bt_lo,
-                           int co, float* out, uint32_t* t_save, const float* alpha_num, float alpha_scale,
-                           hipStream_t stream);
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream, const float* scale_num = nullptr, float scale = 1.0f,
                         bool frag_layout = false);
 // squared distance of the kNN kernels: one expression for the all-pairs scan and the grid search, so that both
 // order equal-looking candidates identically
 __device__ __forceinline__ float knn_dist2(float dx, float dy, float dz) { return fmaf(dz, dz, fmaf(dy, dy, dx * dx)); }
-int launch_knn_bruteforce(const float* pts, const int32_t* batch_ids, int64_t n, int k, int32_t* out,
-                          hipStream_t stream);
+int launch_knn_bruteforce(const float* pts, const int32_t* batch_ids, int64_t n, const float* qpts, const int32_t* qbatch,
+                          int64_t m, int k, int32_t* out, hipStream_t stream);
 int launch_knn_listed(const float* pts, const int32_t* batch_ids, int64_t n, int k, int32_t* out, const int32_t* list,
                       const int32_t* list_count, hipStream_t stream);
 
@@ -417,9 +431,10 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
                            int64_t m, int n, int k, hipStream_t stream);
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
-                        float alpha_scale, hipStream_t stream, bool a24 = false);
+                        float alpha_scale, hipStream_t stream, bool a24 = false, ReduceBatch* defer = nullptr);
 size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k);
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
-                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24 = false);
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24 = false,
+                        ReduceBatch* defer = nullptr);  // defer (both GEMMs): the reduction joins the caller's ReduceBatch
 
 }  // namespace se3

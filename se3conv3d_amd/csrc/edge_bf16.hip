@@ -15,7 +15,6 @@
 // Kernels in this file:
 //   edge_t_pair_bf16_kernel<CT, FULL, NF>   default for C >= 64: a wave pair per item (two frames, or one row for odd F)
 //   edge_t_bf16_kernel<VW, FC, FULL>        single wavefront per item (edge_bf16_body.h), used for C < 64
-//   edge_t_stream_bf16_kernel               persistent variant of the latter (SE3_STREAM, not faster)
 //   edge_param_grad_bf16_v2_kernel<CH16, NFR>  parameter gradients, 64-channel blocks over blockIdx.y
 //   edge_param_grad_bf16_kernel             generic fallback (channel counts that are not multiples of 16)
 #include <cstdlib>
@@ -135,7 +134,8 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
 #define SE3_PAIR_WAVES 4
 #endif
 #ifndef SE3_PG_ABLATE
-#define SE3_PG_ABLATE 0  // diagnostic builds of edge_param_grad_bf16_v2 (wrong results): 1 no GELU', 2 no feature gather, 4 no grad_T loads, 8 no d[A;beta] product
+#define SE3_PG_ABLATE 0  // diagnostic builds of edge_param_grad_bf16_v2 (wrong results): 1 no GELU', 2 no feature gather, 4 no grad_T loads, 8 no d[A;beta] product,
+                         // 16 no geometry gathers / descriptor / descriptor split (upper bound of what a descriptor stash written by the forward could save)
 #endif
 #ifndef SE3_PAIR_ABLATE
 #define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi
@@ -373,262 +373,6 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// The wave-pair kernel as a CHUNK STREAM (two frames per point, C = 64): a resident set of workgroups, each walking a
-// contiguous range of centre points whose edge count is balanced on the device (binary search in the inclusive
-// offsets `ends`, which are prefix sums), treats the chunks of all its points as one software-pipelined sequence.
-// What a one-point workgroup pays in front of its first chunk -- three dependent memory round trips (row extent ->
-// neighbour ids -> geometry records; a wavefront lives for ~2.5 chunks, 37 % of it parked in s_waitcnt, VALU issue
-// slots 46 % used: profiles/r01_n_pmc_summary.txt) -- is paid once per workgroup here: neighbour ids run two chunks
-// ahead ACROSS points, geometry records one chunk ahead, and everything that is uniform over the workgroup (row
-// extents, the centre's own record) comes through the scalar cache into SGPRs (constant-address-space loads), which
-// also takes 12 VGPRs out of the 128 the kernel may use at 4 wavefronts per SIMD.
-// ------------------------------------------------------------------------------------------------
-using cint_p = const __attribute__((address_space(4))) int32_t*;
-using cflt_p = const __attribute__((address_space(4))) float*;
-constexpr int kStreamItemWeight = 8;  // a point costs about as much as 8 edges besides its edges (row epilogue)
-
-struct ChunkCur {  // wave-uniform position in the chunk stream (SGPRs)
-  int ctr, start, end, end2, c0;
-};
-
-#ifndef SE3_STREAM_WAVES
-#define SE3_STREAM_WAVES SE3_PAIR_WAVES  // wavefronts per SIMD the register budget is set for (5 needs SE3_STREAM_PHIBUF=1)
-#endif
-#ifndef SE3_STREAM_PHIBUF
-#define SE3_STREAM_PHIBUF 2  // 2: phi fragments double buffered in LDS (18 KB per workgroup, one barrier per chunk, at most
-#endif                       // 8 workgroups per CU); 1: single buffer, two barriers per chunk, 10 KB per workgroup
-__global__ __launch_bounds__(128, SE3_STREAM_WAVES) void edge_t_pair_stream_bf16_kernel(
-    EdgeGeom g, const uint32_t* __restrict__ feat, int64_t feat_rows, const float* __restrict__ axes_ext,
-    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int ctr_lo, int ctr_hi, int fnb_shift, int t24) {
-  constexpr int C = 64;
-  __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_phi[SE3_STREAM_PHIBUF][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int kcol = lane & 31, h = lane >> 5;
-  if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
-  __syncthreads();
-  const float rho = *rho_p;
-  constexpr int row_bytes = C * 4;
-  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
-  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
-  const cint_p ends_c = (cint_p)g.ends;
-  const int f_nb = g.f_nb;
-
-  // ---- this workgroup's range of centre points: equal shares of  edges + kStreamItemWeight * points
-  const int G = (int)gridDim.x, b = (int)blockIdx.x;
-  auto prefix = [&](int c) -> int64_t { return (int64_t)(c > 0 ? ends_c[c - 1] : 0) + (int64_t)kStreamItemWeight * c; };
-  const int64_t p_lo = prefix(ctr_lo), p_total = prefix(ctr_hi) - p_lo;
-  auto bound = [&](int j) {
-    if (j <= 0) return ctr_lo;
-    if (j >= G) return ctr_hi;
-    const int64_t t = p_lo + p_total * j / G;
-    int lo = ctr_lo, hi = ctr_hi;  // smallest c with prefix(c) >= t
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (prefix(mid) < t) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-  };
-  const int my_lo = bound(b), my_hi = bound(b + 1);
-  if (my_lo >= my_hi) return;
-
-  auto cur_init = [&](int c) {
-    ChunkCur k;
-    k.ctr = c, k.start = c > 0 ? ends_c[c - 1] : 0, k.end = ends_c[c], k.end2 = ends_c[min(c + 1, my_hi - 1)], k.c0 = 0;
-    return k;
-  };
-  auto n_of = [&](const ChunkCur& k) { return (k.end - k.start) * f_nb; };
-  auto advance = [&](ChunkCur& k) {
-    k.c0 += 32;
-    if (k.c0 >= n_of(k)) {  // next point (also for a point without neighbours: one empty chunk)
-      k.ctr += 1, k.start = k.end, k.end = k.end2, k.c0 = 0;
-      k.end2 = ends_c[min(k.ctr + 1, my_hi - 1)];
-      if (k.ctr >= my_hi) k.end = k.start;  // past the range: empty chunks, nothing is loaded for them
-    }
-  };
-  // frame-edge of this lane in chunk k -> neighbour id (global load) / source row
-  auto fe_of = [&](const ChunkCur& k) { return max(min(k.c0 + kcol, n_of(k) - 1), 0); };
-  auto nbr_of = [&](const ChunkCur& k) {
-    if (n_of(k) <= 0) return 0;
-    const int fe = fe_of(k);
-    const int e = k.start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / f_nb);
-    return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-  };
-  auto row_of = [&](int nb, const ChunkCur& k) {
-    const int fe = fe_of(k);
-    return nb * f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % f_nb);
-  };
-  // the centre's own record (this wavefront's frame) through the scalar cache
-  auto centre_record = [&](int ctr, float yc[3], float rc[9]) {
-    const cflt_p p = (cflt_p)(g.ctr_geom + ((int64_t)ctr * 2 + wv) * 16);
-    yc[0] = p[0], yc[1] = p[1], yc[2] = p[2], rc[8] = p[3];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rc[i] = p[4 + i];
-  };
-
-  ChunkCur A = cur_init(my_lo), B = A;
-  advance(B);
-  ChunkCur Cc = B;
-  advance(Cc);
-  float yc[3], rc[9], yc_n[3], rc_n[9];
-  centre_record(A.ctr, yc, rc);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) yc_n[i] = yc[i];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) rc_n[i] = rc[i];
-  int q_a = row_of(nbr_of(A), A);
-  int ids_b = nbr_of(B);
-  float xn_nx[3], rn_nx[9];
-  load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
-  const int hb = 16 * h;
-  int buf = 0;
-  f32x16 acc[2] = {zero16(), zero16()};
-
-  while (A.ctr < my_hi) {
-    const int n_a = n_of(A);
-    const int cnt = max(min(32, n_a - A.c0), 0);
-    const int qoff = A.c0 + kcol < n_a ? q_a * row_bytes : kOobOffset;
-    float xn[3], rn[9], d[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-    const int q_b = row_of(ids_b, B);
-    ids_b = nbr_of(Cc);  // ids two chunks ahead, across points
-
-    uint32_t fw[2][8];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
-        fw[s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + (32 * wv + kcol) * 4, 0, 0);
-      }
-    load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);  // geometry one chunk ahead
-    if (B.c0 == 0 && B.ctr < my_hi) centre_record(B.ctr, yc_n, rc_n);
-
-    if (!g.transposed)
-      edge_descriptor(xn, rn, yc, rc, rho, d);
-    else
-      edge_descriptor(yc, rc, xn, rn, rho, d);
-    {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
-      u32x4 a_hi, a_lo;
-      frags_from_floats(v, a_hi, a_lo);
-      const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
-      const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
-      const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (s * 16 < cnt) {
-          float pv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
-          u32x4 b_hi, b_lo;
-          frags_from_floats(pv, b_hi, b_lo);
-          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
-          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
-        }
-      }
-    }
-    __syncthreads();  // both frames' fragments of this chunk are published (the other buffer is used next chunk)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s * 16 < cnt) {
-        u32x4 fa_hi, fa_lo;
-        frags_from_words(fw[s], fa_hi, fa_lo);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const u32x4 b_hi = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
-          const u32x4 b_lo = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
-          acc[a] = mfma_bf16x3(fa_hi, fa_lo, b_hi, b_lo, acc[a]);
-        }
-      }
-    }
-    // The prefetches of this iteration (neighbour ids, next chunk's geometry) are made to land HERE, before the row
-    // stores below are issued: vmcnt retires loads and stores in issue order, and the register copies the compiler
-    // places at the loop's back edge would otherwise wait for the stores of a finished point as well (vmcnt(0)).
-    asm volatile("" : "+v"(ids_b), "+v"(xn_nx[0]), "+v"(xn_nx[1]), "+v"(xn_nx[2]), "+v"(rn_nx[0]), "+v"(rn_nx[1]),
-                 "+v"(rn_nx[2]), "+v"(rn_nx[3]), "+v"(rn_nx[4]), "+v"(rn_nx[5]), "+v"(rn_nx[6]), "+v"(rn_nx[7]),
-                 "+v"(rn_nx[8]));
-    if (A.c0 + 32 >= n_a) {
-      // last chunk of the point: acc[a] register r, lane (kcol, h) = T[row 2*ctr + a][32*wv + acc_row(r,h)][kcol]
-      const int ch0 = 32 * wv;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int64_t row_id = (int64_t)A.ctr * 2 + a;
-        if (t24 & 2) {  // diagnostic (SE3_PAIR_STREAM_NOSTORE, wrong results): rows are converted but not stored
-          uint32_t x = 0;
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            uint32_t hp, lp;
-            t24_pack2(acc[a][r], acc[a][r + 1], hp, lp);
-            x ^= hp ^ lp;
-          }
-          if (x == 0x12345678u) t_out[0] = x;
-        } else if (t24) {
-          char* row = reinterpret_cast<char*>(t_out) + row_id * t24_row_bytes(C);
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const int ch = ch0 + acc_row(r, h);  // even
-            uint32_t hp, lp;
-            t24_pack2(acc[a][r], acc[a][r + 1], hp, lp);
-            const int idx = (ch >> 1) * kBasis + kcol;
-            __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
-            __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2) + idx);
-          }
-        } else {
-          uint32_t* t_row = t_out + (row_id * C + ch0) * kBasis;
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            uint32_t w0, w1;
-            split_pack2(acc[a][r], acc[a][r + 1], w0, w1);
-            __builtin_nontemporal_store(w0, &t_row[acc_row(r, h) * kBasis + kcol]);
-            __builtin_nontemporal_store(w1, &t_row[acc_row(r + 1, h) * kBasis + kcol]);
-          }
-        }
-        acc[a] = zero16();
-      }
-    }
-    if (B.c0 == 0) {  // the next chunk starts a new point: its centre record has arrived by now
-#pragma unroll
-      for (int i = 0; i < 3; ++i) yc[i] = yc_n[i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rc[i] = rc_n[i];
-    }
-    A = B, B = Cc;
-    advance(Cc);
-    q_a = q_b;
-    if (SE3_STREAM_PHIBUF == 2) buf ^= 1;
-    else __syncthreads();  // single buffer: every fragment of this chunk has been read before the next chunk's are written
-  }
-}
-
-// persistent variant (single channel pass): see edge_stream_bf16
-template <int VW, int FC, bool FULL>
-__global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_stream_bf16_kernel(
-    EdgeGeom g, const uint32_t* __restrict__ feat, int channels, int64_t feat_rows, const float* __restrict__ axes_ext,
-    const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t n_items, int fnb_shift) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
-  if (threadIdx.x < 64) mlp_weights_to_lds<FC>(lds_w, axes_ext, threadIdx.x);
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * channels * 4);
-  const int64_t row_words = (int64_t)channels * kBasis;
-  const int64_t first = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  edge_stream_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, first, (int64_t)gridDim.x * 4, n_items, fnb_shift,
-                                 [&](int64_t item, int a, int off, uint32_t w) {
-#if SE3_NT_STORES
-                                   __builtin_nontemporal_store(w, &t_out[(item * FC + a) * row_words + off]);
-#else
-                                   t_out[(item * FC + a) * row_words + off] = w;
-#endif
-                                 });
-}
-
-// ------------------------------------------------------------------------------------------------
 // Gradient of the kernel-MLP parameters (cf. edge_param_grad_kernel in edge_kernels.hip):
 //   gphi[n,k] = sum_i feat[q(n), i] * gT[m][i,k]   rows n, cols k, k-dim = channels, 16 per MFMA:
 //               A: lane (n,h) reads words feat[q(n)][i0 + 8h .. +7]  (32 contiguous bytes)
@@ -842,7 +586,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     const int c_first = PAIR ? 32 * wave : 0;  // this wavefront's first chunk
     float yc[3], rc[9];
     const int ctr_row = (int)(ctr * g.f_ctr + a0 + (NFR == 2 ? h : 0));
-    if (!LEAN) load_geom_record(ctrg_rs, ctr_row, yc, rc);  // LEAN: fetched again per chunk (a cache hit; 12 registers)
+    if (!LEAN && !(SE3_PG_ABLATE & 16)) load_geom_record(ctrg_rs, ctr_row, yc, rc);  // LEAN: fetched again per chunk (a cache hit; 12 registers)
 
     // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
     auto nbr_of = [&](int c0) {
@@ -883,7 +627,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     }
     int q_a = row_of(nb_a, c_first);
     float xn_nx[3], rn_nx[9];
-    load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
+    if (!(SE3_PG_ABLATE & 16)) load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
 #pragma unroll
     for (int ab = 0; ab < NBUILD; ++ab)
 #pragma unroll
@@ -930,15 +674,22 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       if (LEAN) load_geom_record(ctrg_rs, ctr_row, yc, rc);
       q_a = q_b;
 
-      if (!g.transposed)
+      if (SE3_PG_ABLATE & 16) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[i] = 0.25f;
+      } else if (!g.transposed)
         edge_descriptor(xn_nx, rn_nx, yc, rc, rho, d);
       else
         edge_descriptor(yc, rc, xn_nx, rn_nx, rho, d);
       // the next chunk's record goes out once this chunk's has been consumed (SE3_PG_PAIR_GEOM_AT_END=1: only at the
       // end of the chunk body -- measured slower, 0.434 vs 0.419 ms)
-      if (!LEAN && !(PAIR && SE3_PG_PAIR_GEOM_AT_END)) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      if (!(SE3_PG_ABLATE & 16) && !LEAN && !(PAIR && SE3_PG_PAIR_GEOM_AT_END)) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
 
       u32x4 own_hi, own_lo, oth_hi = {0u, 0u, 0u, 0u}, oth_lo = {0u, 0u, 0u, 0u};
+      if (SE3_PG_ABLATE & 16) {  // what the stash would deliver: the split descriptor as two 16-byte words per plane
+        own_hi = u32x4{(uint32_t)q_a, (uint32_t)q_a * 3u, (uint32_t)q_a * 5u, (uint32_t)q_a * 7u} & 0x3f803f80u;
+        own_lo = own_hi >> 3;
+      } else
       frags_from_floats(d, own_hi, own_lo);
       // descriptor image: half h writes the rows of frame a0+h -- the split pairs above are the rows of the two planes
       uint32_t own8_hi, own8_lo;
@@ -1200,33 +951,6 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
     const int64_t n_range = item_hi - item_lo;
     if (n_range <= 0) return SE3_OK;
-    // chunk-stream form (opt-in, SE3_PAIR_STREAM=1: measured equal to one workgroup per point):
-    // two frames per point, 64 channels
-    static const bool stream_on = [] {
-      const char* e = getenv("SE3_PAIR_STREAM");
-      return e != nullptr && atoi(e) != 0;
-    }();
-    if (stream_on && two && g.f_ctr == 2 && channels == 64 && g.n_ctr < (1ll << 30)) {
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      }
-      static const int per_cu = [] {
-        const char* e = getenv("SE3_PAIR_STREAM_WGS");
-        return e ? atoi(e) : 2 * SE3_STREAM_WAVES;  // resident 128-thread workgroups per CU at SE3_STREAM_WAVES waves / SIMD
-      }();
-      const int64_t resident = (int64_t)n_cu * per_cu;
-      // short ranges lose the point of the stream: below 4 points per workgroup use fewer workgroups
-      int64_t wgs = n_range / 4 < resident ? (n_range + 3) / 4 : resident;
-      if (wgs < 1) wgs = 1;
-      static const int nostore = getenv("SE3_PAIR_STREAM_NOSTORE") != nullptr ? 2 : 0;
-      hipLaunchKernelGGL(edge_t_pair_stream_bf16_kernel, dim3((unsigned)wgs), dim3(128), 0, stream, g, feat, feat_rows,
-                         axes_ext, rho, t_out, (int)item_lo, (int)item_hi, shift, (t24 ? 1 : 0) | nostore);
-      return check_launch();
-    }
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
 #define SE3_PAIR_T(CT, FULL, NF, P2, TR)                                                                                \
@@ -1253,30 +977,6 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
 #undef SE3_PAIR_T
     return check_launch();
   }
-  if (channels <= 128 && getenv("SE3_STREAM") != nullptr) {
-    // single channel pass: persistent wavefronts with cross-item prefetch, ~all wave slots of the chip filled
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
-      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int64_t want = (items + 3) / 4;
-    const int per_cu = fc == 1 ? 3 : 2;  // resident 256-thread blocks per CU at the kernels' register budgets
-    const dim3 pgrid((unsigned)(want < (int64_t)n_cu * per_cu ? want : (int64_t)n_cu * per_cu));
-#define SE3_STREAM(VW, FC, FULL)                                                                                     \
-  hipLaunchKernelGGL((edge_t_stream_bf16_kernel<VW, FC, FULL>), pgrid, block, 0, stream, g, feat, channels, feat_rows, \
-                     axes_ext, rho, t_out, items, shift)
-    if (channels == 128) SE3_STREAM(4, 1, true);
-    else if (channels == 64) { if (fc == 2) SE3_STREAM(2, 2, true); else SE3_STREAM(2, 1, true); }
-    else if (channels == 32) { if (fc == 2) SE3_STREAM(1, 2, true); else SE3_STREAM(1, 1, true); }
-    else if (channels < 32) { if (fc == 2) SE3_STREAM(1, 2, false); else SE3_STREAM(1, 1, false); }
-    else goto per_item;
-#undef SE3_STREAM
-    return check_launch();
-  }
-per_item:
   const dim3 grid((unsigned)((items + 3) / 4));
 #define SE3_LAUNCH(VW, FC, FULL)                                                                                      \
   hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL>), grid, block, 0, stream, g, feat, channels, feat_rows,          \
@@ -1368,7 +1068,8 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
 #undef SE3_PG_L
     return check_launch();
   }
-  hipLaunchKernelGGL(edge_param_grad_bf16_kernel, dim3(n_partials), dim3(256), 0, stream, g, feat, channels, axes_ext,
+  *n_used = n_partials < 512 ? n_partials : 512;  // generic fallback: two workgroups per CU, as the fp32 kernel
+  hipLaunchKernelGGL(edge_param_grad_bf16_kernel, dim3(*n_used), dim3(256), 0, stream, g, feat, channels, axes_ext,
                      rho, grad_t, partials, rows);
   return check_launch();
 }

@@ -1,10 +1,9 @@
-// Per-item body of the split-bf16 edge kernels, shared by the stand-alone kernel (edge_bf16.hip: rows of
-// T go to HBM) and the fused kernels (fused_bf16.hip: rows of T go to an LDS tile that a dense MFMA
-// stage contracts with the weights before anything leaves the CU).  See edge_bf16.hip for the scheme.
+// Per-item body of the single-wavefront split-bf16 edge kernel (edge_bf16.hip, rows narrower than 64 channels).
+// See edge_bf16.hip for the scheme.
 #pragma once
 
 #ifndef SE3_ABLATE
-#define SE3_ABLATE 0  // diagnostic builds only (tools/ablate.sh): 1 no GELU, 2 no feature gather, 3 no geometry gather, 4 no stores
+#define SE3_ABLATE 0  // diagnostic builds only (tools/ab.sh with a variant build): 1 no GELU, 2 no feature gather, 3 no geometry gather, 4 no stores
 #endif
 #ifndef SE3_ABLATE_MASK
 #define SE3_ABLATE_MASK (SE3_ABLATE ? (1 << (SE3_ABLATE - 1)) : 0)
@@ -249,197 +248,5 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
   }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Persistent form of edge_item_bf16 for shapes with a single channel pass (channels <= 32*VW): a
-// wavefront walks items first, first+stride, ... and software-pipelines ACROSS items.  A fresh item
-// starts with a three-level dependent load chain (ends -> neighbour ids -> their geometry, ~2-3 us);
-// with one item per wavefront and 2 wavefronts per SIMD that chain was a quarter of an item's life.
-// Here the next item's header is requested while the current item computes, its first chunk's
-// neighbour ids during the current item's last chunk and their geometry before the epilogue.
-// sink(item, a, offset_in_row, word).
-// ------------------------------------------------------------------------------------------------
-template <int VW, int FC, bool FULL, class Sink>
-__device__ __forceinline__ void edge_stream_bf16(const EdgeGeom& g, const __amdgpu_buffer_rsrc_t feat_rs, int channels,
-                                                 const uint32_t (*lds_w)[2][64][4], float rho, int64_t first,
-                                                 int64_t stride, int64_t n_items, int fnb_shift, Sink&& sink) {
-  const int lane = threadIdx.x & 63;
-  const int kcol = lane & 31, h = lane >> 5;
-  const int groups = g.f_ctr / FC;
-  const int row_bytes = channels * 4;
-  const int hb = 16 * h;
-  const int cb = VW * kcol;
-  const bool ch_ok = FULL || cb < channels;
-  const int cb4 = (ch_ok ? cb : 0) * 4;
-  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
-  const __amdgpu_buffer_rsrc_t ctrg_rs = buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64);
-
-  struct Header {
-    int e0, e1;  // ends[ctr-1] (0 for the first point), ends[ctr]
-    float yc[3], rc[9];
-  };
-  auto load_header = [&](int64_t item, Header& hd) {
-    // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
-    const int64_t ctr = (uint32_t)item / (uint32_t)groups;
-    const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * FC;
-    hd.e0 = g.ends[ctr > 0 ? ctr - 1 : 0];
-    if (ctr == 0) hd.e0 = 0;
-    hd.e1 = g.ends[ctr];
-    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (FC == 2 ? h : 0)), hd.yc, hd.rc);
-  };
-  auto edge_of = [&](int start, int n_total, int c0, int& nb, int& q) {
-    const int fe = min(c0 + kcol, n_total - 1);
-    int e, fn;
-    if (fnb_shift >= 0) {
-      e = start + (fe >> fnb_shift);
-      fn = fe & ((1 << fnb_shift) - 1);
-    } else {
-      e = start + fe / g.f_nb;
-      fn = fe % g.f_nb;
-    }
-    nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-    q = nb * g.f_nb + fn;
-  };
-  auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-    load_geom_record(nbg_rs, q, xn, rn);
-  };
-
-  int64_t item = first;
-  if (item >= n_items) return;
-  Header cur, nxt;
-  load_header(item, cur);
-  int nb_nx = 0, q_nx = 0;
-  float xn_nx[3], rn_nx[9];
-  bool pf_valid = false;  // (nb_nx .. rn_nx) hold chunk 0 of the item about to start (wave-uniform)
-
-  while (true) {
-    const int start = cur.e0;
-    const int n_total = (cur.e1 - start) * g.f_nb;
-    const int64_t item_nx = item + stride;
-    const bool has_next = item_nx < n_items;
-    if (has_next) load_header(item_nx, nxt);  // level 1 of the next item's chain
-
-    f32x16 acc[FC][VW];
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-      for (int t = 0; t < VW; ++t) acc[a][t] = zero16();
-
-    if (n_total > 0 && !pf_valid) {
-      edge_of(start, n_total, 0, nb_nx, q_nx);
-      geom_of(nb_nx, q_nx, xn_nx, rn_nx);
-    }
-    pf_valid = false;
-    for (int c0 = 0; c0 < n_total; c0 += 32) {
-      const int cnt = min(32, n_total - c0);
-      const int q = q_nx;
-      // rows past the end of the edge list are read out of bounds (raw buffer loads return 0), so phi needs no mask
-      const int qoff = c0 + kcol < n_total ? q * row_bytes : kOobOffset;
-      float xn[3], rn[9], d[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-      const bool more = c0 + 32 < n_total;  // wave-uniform
-      // what to prefetch: the next chunk of this item, or chunk 0 of the next item
-      const int nstart = more ? start : nxt.e0;
-      const int ntotal = more ? n_total : (has_next ? (nxt.e1 - nxt.e0) * g.f_nb : 0);
-      const bool pf = ntotal > 0;
-      if (pf) edge_of(nstart, ntotal, more ? c0 + 32 : 0, nb_nx, q_nx);  // level 2
-      if (!g.transposed)
-        edge_descriptor(xn, rn, cur.yc, cur.rc, rho, d);
-      else
-        edge_descriptor(cur.yc, cur.rc, xn, rn, rho, d);
-
-      u32x4 own_hi, own_lo, oth_hi, oth_lo;
-      frags_from_floats(d, own_hi, own_lo);
-      {
-        float d8 = d[8];
-        if constexpr (FC == 2) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
-          d8 = __uint_as_float(h ? sw[0] : sw[1]);
-        }
-        uint32_t p_hi, p_lo;
-        split2(d8, 1.0f, p_hi, p_lo);
-        oth_hi = u32x4{p_hi, 0u, 0u, 0u};
-        oth_lo = u32x4{p_lo, 0u, 0u, 0u};
-      }
-
-      u32x4 fa_hi[2][VW], fa_lo[2][VW];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (s * 16 < cnt) {
-          uint32_t w[VW][8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
-            const int voff = src_off + cb4;
-            if constexpr (VW == 4) {
-              const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
-              w[0][j] = v[0], w[1][j] = v[1], w[2][j] = v[2], w[3][j] = v[3];
-            } else if constexpr (VW == 2) {
-              const auto v = __builtin_amdgcn_raw_buffer_load_b64(feat_rs, voff, 0, 0);
-              w[0][j] = v[0], w[1][j] = v[1];
-            } else {
-              w[0][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, voff, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < VW; ++t) {
-            frags_from_words(w[t], fa_hi[s][t], fa_lo[s][t]);
-            if (!ch_ok) fa_hi[s][t] = fa_lo[s][t] = u32x4{0u, 0u, 0u, 0u};
-          }
-        }
-      }
-      if (pf) geom_of(nb_nx, q_nx, xn_nx, rn_nx);  // level 3
-      if (!more) pf_valid = pf;
-
-#pragma unroll
-      for (int a = 0; a < FC; ++a) {
-        const bool dims07 = FC == 1 ? h == 0 : h == a;
-        u32x4 a_hi, a_lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
-          a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
-        }
-        const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[a][0][lane][0]);
-        const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[a][1][lane][0]);
-        f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s * 16 < cnt) {
-            float pv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              pv[j] = gelu_scaled(phi[8 * s + j]);
-            }
-            u32x4 b_hi, b_lo;
-            frags_from_floats(pv, b_hi, b_lo);
-#pragma unroll
-            for (int t = 0; t < VW; ++t) acc[a][t] = mfma_bf16x3(fa_hi[s][t], fa_lo[s][t], b_hi, b_lo, acc[a][t]);
-          }
-        }
-      }
-    }
-
-#pragma unroll
-    for (int a = 0; a < FC; ++a)
-#pragma unroll
-      for (int t = 0; t < VW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int ch0 = VW * acc_row(r, h) + t, ch1 = VW * acc_row(r + 1, h) + t;
-          uint32_t w0, w1;
-          split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
-          if (FULL || ch0 < channels) sink(item, a, ch0 * kBasis + kcol, w0);
-          if (FULL || ch1 < channels) sink(item, a, ch1 * kBasis + kcol, w1);
-        }
-
-    if (!has_next) break;
-    item = item_nx;
-    cur = nxt;
-  }
-}
 
 }  // namespace se3

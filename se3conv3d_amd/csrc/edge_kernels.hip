@@ -281,8 +281,6 @@ int launch_edge_t(const char* tag, const EdgeGeom& g, const float* feat, int cha
   return check_launch();
 }
 
-// Blocks of the (persistent) parameter-gradient kernels = partial results to reduce: two per CU; 2048 measured 3 %
-// slower, 4096 11 % slower at the headline shape.
 // slots of partial sums the parameter-gradient kernels may use: up to 2048 workgroups (the pair form of the split-bf16
 // kernel keeps 6 x 256 resident; the other forms use at most 512 of them)
 int edge_param_grad_blocks(int64_t rows) {
@@ -292,10 +290,13 @@ int edge_param_grad_blocks(int64_t rows) {
 
 int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat, int channels,
                            const float* axes_ext, const float* rho, const float* grad_t, float* partials,
-                           int n_partials, hipStream_t stream) {
+                           int n_partials, int* n_used, hipStream_t stream) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   ProfScope prof(tag, stream);
-  hipLaunchKernelGGL(edge_param_grad_kernel, dim3(n_partials), dim3(256), 0, stream, g, feat, channels, axes_ext,
+  // two workgroups per CU (2048 measured 3 % slower, 4096 11 %): the slot capacity is sized for the pair form of the
+  // split-bf16 kernel, this kernel uses at most 512 of the slots
+  *n_used = n_partials < 512 ? n_partials : 512;
+  hipLaunchKernelGGL(edge_param_grad_kernel, dim3(*n_used), dim3(256), 0, stream, g, feat, channels, axes_ext,
                      rho, grad_t, partials, rows);
   return check_launch();
 }

@@ -15,37 +15,40 @@ namespace se3 {
 namespace {
 
 constexpr int kKnnQueries = 64;  // queries per block (one per lane)
-constexpr int kKnnSlices = 8;    // wavefronts per block, each scanning 1/8 of the candidate range
+constexpr int kKnnSlices = 8;    // wavefronts per block, each scanning 1/8 of the candidate range (4 for K = 64: LDS)
 
-// A block owns 64 consecutive queries; its 8 wavefronts scan disjoint slices of the candidate range (all-pairs
-// inside the batch segment), each keeping the K best per query in registers; the 8 partial lists meet in LDS
+// A block owns 64 consecutive queries; its S wavefronts scan disjoint slices of the candidate range (all-pairs
+// inside the batch segment), each keeping the K best per query in registers; the S partial lists meet in LDS
 // and wavefront 0 merges them.  8x the wavefronts of the one-wave-per-64-queries version (which left 3 of 4
-// SIMD slots idle and serialised on LDS latency).
-template <int K>
-__global__ __launch_bounds__(kKnnQueries* kKnnSlices) void knn_kernel(const float* __restrict__ pts,
-                                                                       const int32_t* __restrict__ batch_ids,
-                                                                       int64_t n, int k_out,
-                                                                       int32_t* __restrict__ out) {
-  __shared__ float4 tile[kKnnSlices][64];  // per wavefront: x, y, z, batch id (as bits)
-  __shared__ float m_d[kKnnSlices][K][kKnnQueries];
-  __shared__ int m_i[kKnnSlices][K][kKnnQueries];
+// SIMD slots idle and serialised on LDS latency).  Queries (qpts, qbatch, m) and candidates (pts, batch_ids, n)
+// may be different clouds (KnnNeighborhood between two clouds, pc/KnnNeighborhood.py:77-84); both batch-id arrays
+// are sorted.  The self query passes the same arrays twice.
+template <int K, int S>
+__global__ __launch_bounds__(kKnnQueries* S) void knn_kernel(const float* __restrict__ pts,
+                                                             const int32_t* __restrict__ batch_ids, int64_t n,
+                                                             const float* __restrict__ qpts,
+                                                             const int32_t* __restrict__ qbatch, int64_t m, int k_out,
+                                                             int32_t* __restrict__ out) {
+  __shared__ float4 tile[S][64];  // per wavefront: x, y, z, batch id (as bits)
+  __shared__ float m_d[S][K][kKnnQueries];
+  __shared__ int m_i[S][K][kKnnQueries];
   __shared__ int64_t s_lo, s_hi;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * kKnnQueries + lane;
-  const bool active = i < n;
-  const int64_t ic = active ? i : n - 1;
-  const float qx = pts[ic * 3], qy = pts[ic * 3 + 1], qz = pts[ic * 3 + 2];
-  const int qb = batch_ids[ic];
+  const bool active = i < m;
+  const int64_t ic = active ? i : m - 1;
+  const float qx = qpts[ic * 3], qy = qpts[ic * 3 + 1], qz = qpts[ic * 3 + 2];
+  const int qb = qbatch[ic];
   if (threadIdx.x == 0) {
-    // candidate range of the block: batch ids are sorted, so [first point of the first query's batch,
-    // last point of the last query's batch]
+    // candidate range of the block: batch ids are sorted, so [first candidate of the first query's batch element,
+    // last candidate of the last query's batch element]
     const int64_t first = (int64_t)blockIdx.x * kKnnQueries;
-    const int64_t last = min(n, first + kKnnQueries) - 1;
-    const int b0 = batch_ids[first], b1 = batch_ids[last];
-    int64_t lo = 0, hi = first;
+    const int64_t last = min(m, first + kKnnQueries) - 1;
+    const int b0 = qbatch[first], b1 = qbatch[last];
+    int64_t lo = 0, hi = n;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] < b0) lo = mid + 1; else hi = mid; }
     s_lo = lo;
-    lo = last, hi = n;
+    hi = n;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] <= b1) lo = mid + 1; else hi = mid; }
     s_hi = lo;
   }
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(kKnnQueries* kKnnSlices) void knn_kernel(const floa
   };
   // slice of this wavefront (multiples of 64 candidates)
   const int64_t total = s_hi - s_lo;
-  const int64_t per = ((total + kKnnSlices - 1) / kKnnSlices + 63) / 64 * 64;
+  const int64_t per = ((total + S - 1) / S + 63) / 64 * 64;
   const int64_t w_lo = s_lo + wave * per, w_hi = min(s_hi, w_lo + per);
   for (int64_t t0 = w_lo; t0 < w_hi; t0 += 64) {
     const int64_t j = t0 + lane;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kKnnQueries* kKnnSlices) void knn_kernel(const floa
   __syncthreads();
   if (wave == 0) {
     // merge the other slices' lists in slice order (their indices are larger: ties keep the lower index)
-    for (int w = 1; w < kKnnSlices; ++w)
+    for (int w = 1; w < S; ++w)
 #pragma unroll
       for (int e = 0; e < K; ++e) {
         const float d = m_d[w][e][lane];
@@ -298,11 +301,16 @@ __global__ __launch_bounds__(64 * kListedWaves) void knn_listed_kernel(const flo
 }
 }  // namespace
 
-int launch_knn_bruteforce(const float* pts, const int32_t* batch_ids, int64_t n, int k, int32_t* out, hipStream_t s) {
-  const dim3 grid((unsigned)((n + kKnnQueries - 1) / kKnnQueries)), block(kKnnQueries * kKnnSlices);
-  if (k <= 8) hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, s, pts, batch_ids, n, k, out);
-  else if (k <= 16) hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, s, pts, batch_ids, n, k, out);
-  else hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, pts, batch_ids, n, k, out);
+int launch_knn_bruteforce(const float* pts, const int32_t* batch_ids, int64_t n, const float* qpts, const int32_t* qbatch,
+                          int64_t m, int k, int32_t* out, hipStream_t s) {
+  const dim3 grid((unsigned)((m + kKnnQueries - 1) / kKnnQueries));
+#define SE3_KNN(K, S) \
+  hipLaunchKernelGGL((knn_kernel<K, S>), grid, dim3(kKnnQueries * S), 0, s, pts, batch_ids, n, qpts, qbatch, m, k, out)
+  if (k <= 8) SE3_KNN(8, kKnnSlices);
+  else if (k <= 16) SE3_KNN(16, kKnnSlices);
+  else if (k <= 32) SE3_KNN(32, kKnnSlices);
+  else SE3_KNN(64, 4);  // the partial lists of 8 slices would not fit LDS
+#undef SE3_KNN
   return check_launch();
 }
 
@@ -320,10 +328,21 @@ int launch_knn_listed(const float* pts, const int32_t* batch_ids, int64_t n, int
 extern "C" int se3_knn_query(const float* pts, const int32_t* batch_ids, int64_t n, int32_t k, int32_t* out,
                              void* stream) {
   if (n < 0 || k < 1) return SE3_ERR_INVALID_ARGUMENT;
-  if (k > 32 || n >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  if (k > 64 || n >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;  // k <= 64 as the reference's kernel (knn_query.cu:167)
   if (n == 0) return SE3_OK;
   if (!pts || !batch_ids || !out) return SE3_ERR_INVALID_ARGUMENT;
-  return launch_knn_bruteforce(pts, batch_ids, n, (int)k, out, (hipStream_t)stream);
+  return launch_knn_bruteforce(pts, batch_ids, n, pts, batch_ids, n, (int)k, out, (hipStream_t)stream);
+}
+
+extern "C" int se3_knn_query_pair(const float* src_pts, const int32_t* src_batch, int64_t n_src, const float* q_pts,
+                                  const int32_t* q_batch, int64_t n_q, int32_t k, int32_t* out, void* stream) {
+  if (n_src < 0 || n_q < 0 || k < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (k > 64 || n_src >= (1ll << 31) || n_q >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  if (n_q == 0) return SE3_OK;
+  if (!q_pts || !q_batch || !out) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_src == 0) return hipMemsetAsync(out, 0xff, (size_t)n_q * k * 4, (hipStream_t)stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  if (!src_pts || !src_batch) return SE3_ERR_INVALID_ARGUMENT;
+  return launch_knn_bruteforce(src_pts, src_batch, n_src, q_pts, q_batch, n_q, (int)k, out, (hipStream_t)stream);
 }
 
 extern "C" int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, int32_t axis_fixed,

@@ -169,7 +169,7 @@ int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, in
 // 1024 rows 0.27 ms, 32 ranges of 4096 rows 0.22 ms, 16 ranges 0.24 ms); never less than 256 rows per range.
 int gemm_tn_splits(int64_t m, int ka, int n) {
   const int64_t tiles = (int64_t)((ka + 127) / 128) * ((n + BN - 1) / BN);
-  int64_t s = (512 + tiles - 1) / tiles;
+  int64_t s = 512 / tiles;  // at most 512 workgroups (two per CU): one resident round
   const int64_t max_s = (m + 255) / 256;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;

@@ -520,6 +520,7 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partials, void* _
   const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
+#pragma unroll 8
     for (int z = 0; z < splits; ++z) s += partials[(int64_t)z * count + i];
     if constexpr (OUT_PACKED) static_cast<uint32_t*>(out)[i] = split_pack(alpha * s);
     else static_cast<float*>(out)[i] = alpha * s;
@@ -777,13 +778,31 @@ int gemm_nn_bf16_col_blocks(int n, int k) { return n > BN && k >= 512 ? 2 : 1; }
 
 int gemm_nn_bf16_splits(int64_t m, int n, int k) {
   const int bnw = BN * gemm_nn_bf16_col_blocks(n, k);
-  const int64_t blocks = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
+  const int64_t tiles = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
   const int nkt = (k + BK - 1) / BK;
   constexpr int target = 512;  // workgroups aimed at (two per CU); 1024 and 256 measured slower on the 9 k-point level
-  if (blocks >= target / 2 || nkt < 8) return 1;
-  int64_t s = (target + blocks - 1) / blocks;
-  if (s > nkt / 4) s = nkt / 4;  // >= 4 k-tiles per split
-  return (int)(s < 1 ? 1 : s);
+  if (tiles >= target / 2 || nkt < 8) return 1;
+  // at most `target` workgroups (one more split than fits starts a second, nearly empty round: 144 tiles x 4 splits =
+  // 576 on 512 slots took as long as two full rounds), at least 4 k-tiles per split
+  int64_t s_max = target / tiles;
+  if (s_max > nkt / 4) s_max = nkt / 4;
+  if (s_max < 1) s_max = 1;
+  // Cost model in microseconds (rocprofv3 times of the small levels, profiles/r03_small_level_kernels.txt): a block's
+  // k loop is serial at ~0.35 us per 32-k tile; the A stream (~3.5 bytes per element) runs at 4.5 TB/s times the share
+  // of the chip the blocks cover; a split costs the reduction launch (5 us) and its partials written and read back
+  // (~0.5 us per MB and split).  64 splits of a 512 x 256 output spent more on 33 MB of partials than on the GEMM.
+  const double a_bytes = (double)m * k * 3.5, out_bytes = (double)m * n * 4.0;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int64_t s = 1; s <= s_max; ++s) {
+    const int per = (int)((nkt + s - 1) / s);
+    const int s_eff = (nkt + per - 1) / per;
+    const double fill = (double)(tiles * s_eff) / 256.0;
+    const double t_loop = per * 0.35, t_stream = a_bytes / (4.5e6 * (fill < 1.0 ? fill : 1.0));
+    const double cost = (t_loop > t_stream ? t_loop : t_stream) + (s_eff > 1 ? 5.0 + s_eff * out_bytes * 0.5e-6 : 0.0);
+    if (cost < best_cost) best_cost = cost, best = s_eff;
+  }
+  return best;
 }
 
 // Row-strip kernel: packed output, k <= 64, n a multiple of 32, weights prepared with frag_layout and alpha folded in.
@@ -799,7 +818,7 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
   if (!gemm_strip_bf16_applicable(m, n, k)) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
   const int64_t row_blocks = (m + 127) / 128;
-  int n_split = row_blocks >= 1024 ? 1 : (int)((1024 + row_blocks - 1) / row_blocks);
+  int n_split = row_blocks >= 1024 ? 1 : (int)(1024 / row_blocks);  // <= 1024 workgroups = one resident round (4 per CU)
   const int n_tiles = n / 32;
   if (n_split > n_tiles / 4) n_split = n_tiles / 4 > 0 ? n_tiles / 4 : 1;  // >= 4 column tiles per block
   const dim3 sgrid((unsigned)row_blocks, (unsigned)n_split);
@@ -815,7 +834,7 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
 
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
-                        float alpha_scale, hipStream_t stream, bool a24) {
+                        float alpha_scale, hipStream_t stream, bool a24, ReduceBatch* defer) {
   if (m == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   const int kp = (k + 31) / 32 * 32;
@@ -850,7 +869,9 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
     SE3_NN(2, split_ws);
     const int64_t count = m * n;
     const int rb = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
-    if (out_packed)
+    if (defer)  // the caller folds the partials together with its other reductions (ReduceBatch)
+      defer->sum(split_ws, c, count, splits, alpha_num, alpha_scale, out_packed);
+    else if (out_packed)
       hipLaunchKernelGGL(reduce_splits_kernel<true>, dim3(rb), dim3(256), 0, stream, split_ws, c, count, splits,
                          alpha_num, alpha_scale);
     else
@@ -873,7 +894,8 @@ size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k) {
 }
 
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
-                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24) {
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24,
+                        ReduceBatch* defer) {
   if (ka == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   int64_t chunk = (m + splits - 1) / splits;
@@ -889,6 +911,10 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
   else
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  if (defer) {
+    defer->sum(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, false);
+    return check_launch();
+  }
   return launch_reduce_partials(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, stream);
 }
 

@@ -375,11 +375,15 @@ __global__ __launch_bounds__(256) void batch_aabb_kernel(const float* __restrict
   flush();
 }
 
-__global__ void split_edges_kernel(const int32_t* __restrict__ neighbors, int64_t e, int32_t* __restrict__ src,
-                                   int32_t* __restrict__ smp) {
+// n_valid (device, may be NULL): rows from *n_valid on are unset (the tail of a capacity-bounded edge buffer) -- they
+// get the source id n_src, which sorts behind every real group and which no offset of group_ends_kernel reaches
+__global__ void split_edges_kernel(const int32_t* __restrict__ neighbors, int64_t e, const int32_t* __restrict__ n_valid,
+                                   int32_t n_src, int32_t* __restrict__ src, int32_t* __restrict__ smp) {
+  const int64_t valid = n_valid ? (int64_t)max(min((int64_t)*n_valid, e), (int64_t)0) : e;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
-    smp[i] = neighbors[i * 2];
-    src[i] = neighbors[i * 2 + 1];
+    const bool ok = i < valid;
+    smp[i] = ok ? neighbors[i * 2] : 0;
+    src[i] = ok ? neighbors[i * 2 + 1] : n_src;
   }
 }
 
@@ -828,10 +832,12 @@ TrLayout tr_layout(int64_t e) {
 
 extern "C" size_t se3_csr_transpose_workspace_bytes(int64_t n_edges) { return tr_layout(n_edges).total; }
 
-extern "C" int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, void* workspace,
-                                 size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream_) {
+extern "C" int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_rows, const int32_t* n_valid, int64_t n_src,
+                                         void* workspace, size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends,
+                                         void* stream_) {
+  const int64_t n_edges = n_rows;
   if (n_edges < 0 || n_src < 0) return SE3_ERR_INVALID_ARGUMENT;
-  if (n_edges >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
+  if (n_edges >= (1ll << 31) || n_src >= (1ll << 31) - 1) return SE3_ERR_UNSUPPORTED;
   if (n_src == 0) return SE3_OK;
   if (!t_ends || (n_edges > 0 && (!neighbors || !workspace || !t_samples))) return SE3_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
@@ -843,7 +849,8 @@ extern "C" int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int6
     int32_t* src = (int32_t*)(ws + l.src);
     int32_t* smp = (int32_t*)(ws + l.smp);
     ssrc = (int32_t*)(ws + l.ssrc);
-    hipLaunchKernelGGL(split_edges_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, src, smp);
+    hipLaunchKernelGGL(split_edges_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, n_valid,
+                       (int32_t)n_src, src, smp);
     size_t temp_bytes = l.temp_bytes;
     // stable LSD radix sort: inside one source the samples keep their ascending input order
     if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, src, ssrc, smp, t_samples, (int)n_edges, 0, 32,
@@ -852,6 +859,11 @@ extern "C" int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int6
   }
   hipLaunchKernelGGL(group_ends_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, ssrc, n_edges, n_src, t_ends);
   return check_launch();
+}
+
+extern "C" int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, void* workspace,
+                                 size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream) {
+  return se3_csr_transpose_bounded(neighbors, n_edges, nullptr, n_src, workspace, workspace_bytes, t_samples, t_ends, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1113,4 +1125,75 @@ extern "C" int se3_frame_unpool(const float* grad_out, const int32_t* arg, int64
   else SE3_FUNPOOL(kPoolSum);
 #undef SE3_FUNPOOL
   return check_launch();
+}
+
+// ---- random one-point-per-cell sub-sampling (GridSubSample(..., p_rnd_sample=True), pc/GridSubSample.py:43-54) -------
+namespace se3 {
+namespace {
+// ids[c] = start(c) + floor(u[c] * count(c))  (a position in the cell-sorted point list, GridSubSample.py:52-54);
+// picked[c] = sorted_ids[ids[c]] (the point that represents the cell, :67).  The product is clamped to count - 1:
+// u * count can round up to count in fp32, which in the reference selects the first point of the NEXT cell.
+__global__ void grid_pick_kernel(const int32_t* __restrict__ cell_ends, const int32_t* __restrict__ sorted_ids,
+                                 const float* __restrict__ u, int64_t n_cells, int32_t* __restrict__ ids,
+                                 int32_t* __restrict__ picked) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  const int start = c > 0 ? cell_ends[c - 1] : 0;
+  const int count = cell_ends[c] - start;
+  int off = (int)floorf(u[c] * (float)count);
+  off = min(max(off, 0), count - 1);
+  ids[c] = start + off;
+  picked[c] = sorted_ids[start + off];
+}
+
+// out[r] = src[idx[r]] for rows of `row_words` 4-byte words (gather) / out[idx[r]] = src[r] (scatter; idx unique)
+template <bool SCATTER, typename W>
+__global__ void rows_move_kernel(const W* __restrict__ src, const int32_t* __restrict__ idx, int64_t n_rows,
+                                 int64_t row_words, W* __restrict__ out) {
+  const int64_t total = n_rows * row_words;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / row_words, w = t - r * row_words;
+    const int64_t other = (int64_t)idx[r] * row_words + w;
+    if (SCATTER) out[other] = src[t];
+    else out[t] = src[other];
+  }
+}
+}  // namespace
+}  // namespace se3
+
+extern "C" int se3_grid_pick(const int32_t* cell_ends, const int32_t* sorted_ids, const float* u, int64_t n_cells,
+                             int32_t* ids, int32_t* picked, void* stream) {
+  if (n_cells < 0) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_cells == 0) return SE3_OK;
+  if (!cell_ends || !sorted_ids || !u || !ids || !picked) return SE3_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(grid_pick_kernel, dim3(blocks_for(n_cells)), dim3(256), 0, (hipStream_t)stream, cell_ends, sorted_ids,
+                     u, n_cells, ids, picked);
+  return check_launch();
+}
+
+static int rows_move(bool scatter, const void* src, const int32_t* idx, int64_t n_rows, int64_t row_bytes, void* out,
+                     void* stream_) {
+  if (n_rows < 0 || row_bytes < 1) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return SE3_OK;
+  if (!src || !idx || !out) return SE3_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool words = row_bytes % 4 == 0 && ((uintptr_t)src | (uintptr_t)out) % 4 == 0;
+  const int64_t rw = words ? row_bytes / 4 : row_bytes;
+  const dim3 grid(blocks_for(n_rows * rw)), block(256);
+  if (words) {
+    if (scatter) hipLaunchKernelGGL((rows_move_kernel<true, uint32_t>), grid, block, 0, stream, (const uint32_t*)src, idx, n_rows, rw, (uint32_t*)out);
+    else hipLaunchKernelGGL((rows_move_kernel<false, uint32_t>), grid, block, 0, stream, (const uint32_t*)src, idx, n_rows, rw, (uint32_t*)out);
+  } else {
+    if (scatter) hipLaunchKernelGGL((rows_move_kernel<true, uint8_t>), grid, block, 0, stream, (const uint8_t*)src, idx, n_rows, rw, (uint8_t*)out);
+    else hipLaunchKernelGGL((rows_move_kernel<false, uint8_t>), grid, block, 0, stream, (const uint8_t*)src, idx, n_rows, rw, (uint8_t*)out);
+  }
+  return check_launch();
+}
+
+extern "C" int se3_rows_gather(const void* src, const int32_t* idx, int64_t n_out, int64_t row_bytes, void* out, void* stream) {
+  return rows_move(false, src, idx, n_out, row_bytes, out, stream);
+}
+
+extern "C" int se3_rows_scatter(const void* src, const int32_t* idx, int64_t n_src, int64_t row_bytes, void* out, void* stream) {
+  return rows_move(true, src, idx, n_src, row_bytes, out, stream);
 }

@@ -133,6 +133,72 @@ void PrepBatch::weights(const float* w, int c_in, int kb, int c_out, int mode, u
   j.scale = scale;
 }
 
+// ---- batched reductions (ReduceBatch, common.h) ------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceJobs jobs) {
+  __shared__ float red[256];
+  int block = blockIdx.x, ji = 0;
+  while (ji + 1 < jobs.count && block >= jobs.job[ji].blocks) block -= jobs.job[ji++].blocks;
+  const ReduceJob& j = jobs.job[ji];
+  if (j.type == 0) {
+    const float alpha = (j.alpha_num ? *j.alpha_num : 1.0f) * j.alpha_scale;
+    for (int64_t i = (int64_t)block * blockDim.x + threadIdx.x; i < j.count; i += (int64_t)j.blocks * blockDim.x) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int z = 0; z < j.splits; ++z) s += j.partials[(int64_t)z * j.count + i];
+      if (j.packed) static_cast<uint32_t*>(j.out)[i] = split_pack(alpha * s);
+      else static_cast<float*>(j.out)[i] = alpha * s;
+    }
+    return;
+  }
+  // d[A; beta]: one block per output element, 256 threads stride over the per-workgroup partials, then a tree
+  const int i = block;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < j.splits; p += 256) s += j.partials[(int64_t)p * kDescExt * kBasis + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* ga = static_cast<float*>(j.out);
+    float* gb = static_cast<float*>(j.out2);
+    if (i < SE3_DESC_DIMS * kBasis) {
+      if (ga) ga[i] = red[0] * j.alpha_scale;
+    } else if (gb) {
+      gb[i - SE3_DESC_DIMS * kBasis] = red[0] * j.alpha_scale;
+    }
+  }
+}
+}  // namespace
+
+void ReduceBatch::sum(const float* partials, void* out, int64_t count, int splits, const float* alpha_num, float alpha_scale,
+                      bool packed) {
+  if (count == 0) return;
+  ReduceJob& j = jobs.job[jobs.count++];
+  j = ReduceJob{};
+  j.type = 0, j.blocks = blocks_for(count, 2048), j.partials = partials, j.out = out, j.count = count, j.splits = splits;
+  j.packed = packed ? 1 : 0, j.alpha_num = alpha_num, j.alpha_scale = alpha_scale;
+}
+
+void ReduceBatch::params(const float* partials, int n_partials, float* grad_axes, float* grad_biases, float scale) {
+  ReduceJob& j = jobs.job[jobs.count++];
+  j = ReduceJob{};
+  j.type = 1, j.blocks = kDescExt * kBasis, j.partials = partials, j.out = grad_axes, j.out2 = grad_biases;
+  j.splits = n_partials, j.alpha_scale = scale;
+}
+
+int ReduceBatch::launch(hipStream_t stream) {
+  if (jobs.count == 0) return check_launch();  // still the caller's last word on the launches before it
+  int total = 0;
+  for (int i = 0; i < jobs.count; ++i) total += jobs.job[i].blocks;
+  ProfScope prof("reductions", stream);
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)total), dim3(256), 0, stream, jobs);
+  jobs.count = 0;
+  return check_launch();
+}
+
 int PrepBatch::launch(hipStream_t stream) {
   if (status != SE3_OK) return status;
   if (jobs.count == 0) return SE3_OK;

@@ -116,7 +116,8 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     geom = ops.ConvGeometry.build(p_pc_in.pts_, p_pc_out.pts_, p_pc_in.local_frames_, p_pc_out.local_frames_,
                                   nb32, p_neighborhood.start_ids_,
                                   symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and p_pc_in is p_pc_out)
-    geom.bounded = getattr(p_neighborhood, "edge_info_", None) is not None
+    geom.edge_info = getattr(p_neighborhood, "edge_info_", None)
+    geom.bounded = geom.edge_info is not None
     if geom.symmetric:
         geom.sources = getattr(p_neighborhood, "sources_i32_", None)
     try:
@@ -126,11 +127,11 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     return geom
 
 
-_ACTIVATIONS = {"mlp_relu": torch.relu, "mlp_sin": torch.sin, "mlp_linear": (lambda t: t),
+_ACTIVATIONS = {"mlp_gelu": torch.nn.functional.gelu, "mlp_relu": torch.relu, "mlp_sin": torch.sin, "mlp_linear": (lambda t: t),
                 "mlp_softmax": (lambda t: torch.softmax(t, dim=-1))}  # PNEConvLayer.py:91-100 besides mlp_gelu
 
 
-def _conv_materialised(feat, axes, biases, weights, geom, rho, nu, act):
+def _conv_materialised(feat, axes, biases, weights, geom, rho, nu, act, rel_rot="6D"):
     """The reference's own formulation (PNEConvLayerRotEquiv.py:199-216) on the library's API-parity ops, for the
     kernel-MLP activations the fused operator does not implement (no *_rot configuration uses them): descriptors
     materialised by ``se3_rot_tensors``, ``act(desc @ A + beta)`` and the contraction in torch, the aggregation
@@ -138,13 +139,14 @@ def _conv_materialised(feat, axes, biases, weights, geom, rho, nu, act):
     if getattr(geom, "bounded", False):
         raise NotImplementedError("a capacity-bounded neighbourhood (rows past the edge count are unset) cannot feed "
                                   "the materialised path: build the neighbourhood without p_capacity")
-    desc, neighbs, ends = ops.rot_tensors(geom, rho)
+    desc, neighbs, ends = ops.rot_tensors(geom, rho, rel_rot)
     phi = act(torch.matmul(desc, axes) + biases)
     t = ops.FeatBasisProj.apply(phi, feat, neighbs, ends)
     out = torch.einsum("nik,iko->no", t, weights)
     return out / geom.frames_in.shape[1] * nu
 
 
+_REL_ROT_DIMS = {"6D": 9, "matrix": 12, "quaternion": 7}  # p_rel_rot -> p_dims (RotationFunctions.py:593-600)
 _KB = 32  # basis functions per call of the MFMA operator (include/se3conv.h: num_basis == 32)
 
 
@@ -191,10 +193,11 @@ class PNEConvLayerRotEquiv(IConvLayer):
     @staticmethod
     def get_rot_tenors(p_pc_in, p_pc_out, p_neighborhood, radius):
         """Materialised rot tensors with the reference's dict keys (computed on the GPU, not
-        cached by content hash).  ``radius`` is the layer's ``norm_neigh_dist_`` like in the reference."""
+        cached by content hash).  ``radius`` is the layer's ``norm_neigh_dist_`` like in the reference; the relative
+        rotation comes in the class-level ``rel_rot_type`` representation, as there."""
         with torch.no_grad():
             geom = _geometry_of(p_pc_in, p_pc_out, p_neighborhood)
-            desc, neighbs, ends = ops.rot_tensors(geom, radius)
+            desc, neighbs, ends = ops.rot_tensors(geom, radius, PNEConvLayerRotEquiv.rel_rot_type)
             rel_pt = (geom.pts_in[geom.neighbors[:, 1].long()] - geom.pts_out[geom.neighbors[:, 0].long()]) * \
                 torch.as_tensor(radius, dtype=torch.float32, device=geom.pts_in.device)
             return {"tensor": rel_pt, "rel_pts_rel_orient": desc, "neighbs": neighbs.to(torch.int64),
@@ -218,14 +221,19 @@ class PNEConvLayerRotEquiv(IConvLayer):
 
     def __compute_convolution__(self, p_pc_in, p_pc_out, p_in_features, p_neighborhood):
         if "mlp" in self.pne_type_:
-            if PNEConvLayerRotEquiv.rel_rot_type != "6D" or self.dims_ != 9:
-                raise NotImplementedError("only the 9-D descriptor (3 offsets + '6D' relative rotation) is implemented")
+            rel_rot = PNEConvLayerRotEquiv.rel_rot_type  # class attribute set by the last-created factory (:278), as the reference
+            if rel_rot not in _REL_ROT_DIMS:
+                raise ValueError(f"rel_rot_type {rel_rot!r}: expected one of {sorted(_REL_ROT_DIMS)}")
+            if self.dims_ != _REL_ROT_DIMS[rel_rot]:
+                raise ValueError(f"p_dims = {self.dims_} but the '{rel_rot}' descriptor has {_REL_ROT_DIMS[rel_rot]} entries")
+            if self.pne_type_ not in _ACTIVATIONS:
+                raise Exception(f"unknown pne type {self.pne_type_}")
             geom = _geometry_of(p_pc_in, p_pc_out, p_neighborhood)
-            if self.pne_type_ != "mlp_gelu":
-                if self.pne_type_ not in _ACTIVATIONS:
-                    raise Exception(f"unknown pne type {self.pne_type_}")
+            if self.pne_type_ != "mlp_gelu" or rel_rot != "6D":
+                # activations / relative-rotation representations no *_rot configuration uses: the reference's own
+                # materialised formulation on the library's API-parity ops
                 return _conv_materialised(p_in_features, self.proj_axes_, self.proj_biases_, self.conv_weights_, geom,
-                                          self.norm_neigh_dist_, self.norm_num_neighs_, _ACTIVATIONS[self.pne_type_])
+                                          self.norm_neigh_dist_, self.norm_num_neighs_, _ACTIVATIONS[self.pne_type_], rel_rot)
             return _conv_any_num_basis(p_in_features, self.proj_axes_, self.proj_biases_, self.conv_weights_, geom,
                                        self.norm_neigh_dist_, self.norm_num_neighs_)
         elif "kp" in self.pne_type_:
@@ -295,7 +303,8 @@ class PNEConvLayer(IConvLayer):
                                           nb32, p_neighborhood.start_ids_,
                                           symmetric=bool(getattr(p_neighborhood, "symmetric_", False)) and
                                           p_pc_in is p_pc_out)
-            geom.bounded = getattr(p_neighborhood, "edge_info_", None) is not None
+            geom.edge_info = getattr(p_neighborhood, "edge_info_", None)
+            geom.bounded = geom.edge_info is not None
             if geom.symmetric:
                 geom.sources = getattr(p_neighborhood, "sources_i32_", None)
             try:

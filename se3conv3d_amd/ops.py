@@ -185,13 +185,15 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
 
 
 def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, capacity: int,
-                       n_batches: Optional[int] = None, want_sources: bool = False):
+                       n_batches: Optional[int] = None, want_sources: bool = False,
+                       neighbors_out: Optional[torch.Tensor] = None):
     """The same query without the host round trip for the edge count (``se3_ball_query_bounded``): the caller sizes the
     edge buffer (``capacity`` rows, e.g. 1.25 x the previous step's count).  Returns ``(neighbors [capacity,2] int32,
     ends [M] int32, info [2] int32 on the device)`` with ``info[0]`` = true edge count and ``info[1]`` = 1 when it did
     not fit (the list is then truncated and ``ends`` clamped: rerun with a larger buffer).  Capturable in a HIP graph
     when ``n_batches`` is given.  ``want_sources``: a fourth result, the source ids as a dense ``[capacity]`` array
-    (the source-major edge list of a cloud against itself)."""
+    (the source-major edge list of a cloud against itself).  ``neighbors_out``: a caller-owned contiguous
+    ``[capacity, 2]`` int32 buffer to write into (e.g. a slice of a larger arena) instead of a fresh allocation."""
     lib = _lib.load()
     pts_src = _as(pts_src, torch.float32)
     pts_dst = _as(pts_dst, torch.float32)
@@ -203,7 +205,12 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
     bs, bd = _as(batch_src, torch.int32), _as(batch_dst, torch.int32)
     n_src, n_dst = pts_src.shape[0], pts_dst.shape[0]
     f32, i32 = torch.float32, torch.int32
-    neighbors = torch.empty((int(capacity), 2), dtype=i32, device=dev)
+    if neighbors_out is not None:
+        if neighbors_out.shape != (int(capacity), 2) or neighbors_out.dtype != i32 or not neighbors_out.is_contiguous():
+            raise ValueError(f"neighbors_out must be a contiguous int32 [{int(capacity)}, 2] tensor")
+        neighbors = neighbors_out
+    else:
+        neighbors = torch.empty((int(capacity), 2), dtype=i32, device=dev)
     sources = torch.empty(int(capacity), dtype=i32, device=dev) if want_sources else None
     ends = torch.empty(n_dst, dtype=i32, device=dev)
     if n_dst == 0:
@@ -240,17 +247,20 @@ class BallQuery(torch.autograd.Function):
         return None, None, None, None, None, None, None
 
 
-def csr_transpose(neighbors_i32: torch.Tensor, n_src: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Source-major copy of an edge list: ``t_samples [E]``, ``t_ends [n_src]`` (inclusive)."""
+def csr_transpose(neighbors_i32: torch.Tensor, n_src: int, n_valid: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Source-major copy of an edge list: ``t_samples [E]``, ``t_ends [n_src]`` (inclusive).  ``n_valid`` (device int32
+    tensor, e.g. ``info`` of ``ball_query_bounded``): only the first ``n_valid[0]`` rows are edges -- the unset tail of a
+    capacity-sized buffer is ignored, without a host round trip."""
     lib = _lib.load()
     dev = neighbors_i32.device
     e = neighbors_i32.shape[0]
     t_samples = torch.empty(e, dtype=torch.int32, device=dev)
     t_ends = torch.zeros(n_src, dtype=torch.int32, device=dev)
     ws = _workspace(lib.se3_csr_transpose_workspace_bytes(e), dev)
-    _lib.check(lib.se3_csr_transpose(_ptr(neighbors_i32, torch.int32, "neighbors"), e, n_src,
-                                     C.c_void_p(ws.data_ptr()), ws.numel(), _ptr(t_samples, torch.int32, "t_samples"),
-                                     _ptr(t_ends, torch.int32, "t_ends"), _stream(dev)), "se3_csr_transpose")
+    _lib.check(lib.se3_csr_transpose_bounded(_ptr(neighbors_i32, torch.int32, "neighbors"), e,
+                                             _ptr(n_valid, torch.int32, "n_valid", dev), n_src, C.c_void_p(ws.data_ptr()),
+                                             ws.numel(), _ptr(t_samples, torch.int32, "t_samples"),
+                                             _ptr(t_ends, torch.int32, "t_ends"), _stream(dev)), "se3_csr_transpose_bounded")
     return t_samples, t_ends
 
 
@@ -320,6 +330,83 @@ def _segment_unpool(cells: GridCells, v2, arg, mode: int):
                                       _ptr(cells.cell_ends, torch.int32, "cell_ends"), _ptr(arg, torch.int32, "arg"),
                                       n, c, mode, _ptr(out, torch.float32, "out"), _stream(v2.device)), "se3_segment_unpool")
     return out
+
+
+def grid_pick(cells: GridCells, u: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One random point per cell (GridSubSample.py:43-54): ``ids [n_cells]`` = positions in the cell-sorted point list
+    (the reference's ``ids_``) and ``picked [n_cells]`` = those points' indices (``sorted_ids_[ids_]``).  ``u``:
+    uniform numbers in [0,1), one per cell (default: drawn on the device -- the reference draws them on the host and
+    copies them over); nothing here synchronises with the host."""
+    lib = _lib.load()
+    dev = cells.sorted_ids.device
+    if u is None:
+        u = torch.rand(cells.n_cells, device=dev)
+    u = _as(u, torch.float32).to(dev)
+    if u.shape != (cells.n_cells,):
+        raise ValueError(f"grid_pick: {tuple(u.shape)} random numbers for {cells.n_cells} cells")
+    i32 = torch.int32
+    ids = torch.empty(cells.n_cells, dtype=i32, device=dev)
+    picked = torch.empty(cells.n_cells, dtype=i32, device=dev)
+    _lib.check(lib.se3_grid_pick(_ptr(cells.cell_ends, i32, "cell_ends", dev), _ptr(cells.sorted_ids, i32, "sorted_ids"),
+                                 _ptr(u, torch.float32, "u"), cells.n_cells, _ptr(ids, i32, "ids"),
+                                 _ptr(picked, i32, "picked"), _stream(dev)), "se3_grid_pick")
+    return ids, picked
+
+
+def _rows_move(lib_fn, name, src, idx, out):
+    row_bytes = src[0].numel() * src.element_size() if src.shape[0] else max(1, out[0].numel() * out.element_size())
+    _lib.check(lib_fn(C.c_void_p(src.data_ptr()), _ptr(idx, torch.int32, "idx", src.device), idx.shape[0], row_bytes,
+                      C.c_void_p(out.data_ptr()), _stream(src.device)), name)
+
+
+def rows_gather(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """``src[idx]`` along dim 0 for any dtype (``se3_rows_gather``)."""
+    if not src.is_cuda:
+        raise ValueError("rows_gather: expected a GPU tensor (the HIP path has no CPU fallback)")
+    src = src.detach().contiguous()
+    out = torch.empty((idx.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if idx.shape[0] and out.numel():
+        _rows_move(_lib.load().se3_rows_gather, "se3_rows_gather", src, idx, out)
+    return out
+
+
+def rows_scatter(src: torch.Tensor, idx: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """Zeros ``[n_rows, ...]`` with ``out[idx[r]] = src[r]`` (unique ``idx``; ``se3_rows_scatter``)."""
+    if not src.is_cuda:
+        raise ValueError("rows_scatter: expected a GPU tensor (the HIP path has no CPU fallback)")
+    src = src.detach().contiguous()
+    out = torch.zeros((int(n_rows),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if idx.shape[0] and src.numel():
+        _rows_move(_lib.load().se3_rows_scatter, "se3_rows_scatter", src, idx, out)
+    return out
+
+
+class RowsGather(torch.autograd.Function):
+    """``x[idx]`` for unique row indices (``__subsample_tensor__`` of the random grid sub-sample, GridSubSample.py:67);
+    the gradient is the scatter into zeros."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.idx, ctx.n = idx, x.shape[0]
+        return rows_gather(x, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        return rows_scatter(g, ctx.idx, ctx.n), None
+
+
+class RowsScatter(torch.autograd.Function):
+    """Rows ``idx`` of a zero tensor ``[n_rows, ...]`` set to ``x`` (``__upsample_tensor__``, GridSubSample.py:83-91);
+    the gradient is the gather."""
+
+    @staticmethod
+    def forward(ctx, x, idx, n_rows):
+        ctx.idx = idx
+        return rows_scatter(x, idx, n_rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        return rows_gather(g, ctx.idx), None, None
 
 
 class GridPool(torch.autograd.Function):
@@ -418,7 +505,12 @@ def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: s
     n, dev = pts.shape[0], pts.device
     out = torch.empty((n, int(k)), dtype=torch.int32, device=dev)
     f32, i32 = torch.float32, torch.int32
-    if method == "scan" or (method == "auto" and n < KNN_GRID_MIN_POINTS) or n == 0:
+    if not 1 <= int(k) <= 64:
+        raise ValueError(f"knn_query: k = {k}; the kernels keep at most 64 neighbours per point (the reference's own "
+                         "kernel has the same limit, knn_query.cu:167)")
+    if method == "grid" and k > 32:
+        raise ValueError("knn_query: the cell-grid search keeps at most 32 neighbours; use method='scan' or 'auto'")
+    if method == "scan" or (method == "auto" and (n < KNN_GRID_MIN_POINTS or k > 32)) or n == 0:
         _lib.check(lib.se3_knn_query(_ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), n, int(k),
                                      _ptr(out, i32, "out"), _stream(dev)), "se3_knn_query")
         return out
@@ -433,6 +525,26 @@ def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: s
         _ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), _ptr(mn, f32, "aabb_min"), _ptr(num_cells, i32, "num_cells"),
         _ptr(cell3, f32, "cell_size"), n, int(k), _ptr(out, i32, "out"), C.c_void_p(ws.data_ptr()), ws.numel(),
         _stream(dev)), "se3_knn_query_grid")
+    return out
+
+
+def knn_query_pair(pts_src, batch_src, pts_q, batch_q, k: int) -> torch.Tensor:
+    """For every query point the ``k`` nearest SOURCE points of the same batch element: ``[N_q, k]`` int32 source
+    indices, ascending (distance, index), -1 padded (``se3_knn_query_pair``; the ``torch_cluster.knn`` call of
+    pc/KnnNeighborhood.py:77-84).  Both batch-id arrays sorted; k <= 64."""
+    lib = _lib.load()
+    f32, i32 = torch.float32, torch.int32
+    ps, pq = _as(pts_src, f32), _as(pts_q, f32)
+    bs, bq = _as(batch_src, i32), _as(batch_q, i32)
+    if ps.dim() != 2 or ps.shape[1] != 3 or pq.dim() != 2 or pq.shape[1] != 3:
+        raise ValueError("knn_query_pair: only [N,3] point sets are supported")
+    if not 1 <= int(k) <= 64:
+        raise ValueError(f"knn_query_pair: k = {k}; at most 64 neighbours per point")
+    dev = pq.device
+    out = torch.empty((pq.shape[0], int(k)), dtype=i32, device=dev)
+    _lib.check(lib.se3_knn_query_pair(_ptr(ps, f32, "pts_src", dev), _ptr(bs, i32, "batch_src", dev), ps.shape[0],
+                                      _ptr(pq, f32, "pts_q"), _ptr(bq, i32, "batch_q", dev), pq.shape[0], int(k),
+                                      _ptr(out, i32, "out"), _stream(dev)), "se3_knn_query_pair")
     return out
 
 
@@ -482,6 +594,7 @@ class ConvGeometry:
     symmetric: bool = False
     bounded: bool = False  # `neighbors` is a capacity-sized buffer whose rows past ends[-1] are unset
     sources: Optional[torch.Tensor] = None  # column 1 of `neighbors` as a dense array when the ball query wrote one
+    edge_info: Optional[torch.Tensor] = None  # [2] int32 on the device (bounded only): true edge count, overflow flag
 
     @staticmethod
     def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends, symmetric: bool = False) -> "ConvGeometry":
@@ -505,10 +618,16 @@ class ConvGeometry:
                 src = self.sources if self.sources is not None else self.neighbors[:, 1].contiguous()
                 self._transpose = (src, self.ends)
             else:
-                self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0])
+                if self.bounded and self.edge_info is None:
+                    raise ValueError("a capacity-bounded edge buffer between two clouds needs its device-side edge count "
+                                     "(edge_info) to be transposed: rows past it are unset")
+                # bounded: the unset tail of the buffer must not reach the sort (se3_csr_transpose_bounded)
+                self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0],
+                                                self.edge_info if self.bounded else None)
         return self._transpose
 
     def shape(self, c_in: int, c_out: int, num_basis: int, precision: Optional[str] = None) -> Se3Shape:
+        # n_edges = rows of the edge buffer: an upper bound on the edge count for a bounded neighbourhood (se3conv.h)
         return Se3Shape(self.pts_in.shape[0], self.pts_out.shape[0], self.neighbors.shape[0],
                         self.frames_in.shape[1], self.frames_out.shape[1], c_in, c_out, num_basis,
                         _lib.PRECISIONS[precision or _precision])
@@ -618,21 +737,25 @@ class SE3ConvFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ API-parity ops (a1, a3, a4, a5)
-def rot_tensors(geom: ConvGeometry, rho):
-    """``get_rot_tenors`` materialised on the GPU: ``desc [E',9]``, ``neighbs [E',2] int32`` sorted by
-    output row, ``ends [N_out*F_out] int32``."""
+def rot_tensors(geom: ConvGeometry, rho, rel_rot: str = "6D"):
+    """``get_rot_tenors`` materialised on the GPU: ``desc [E',D]``, ``neighbs [E',2] int32`` sorted by
+    output row, ``ends [N_out*F_out] int32``.  ``rel_rot`` = the factory's ``p_rel_rot``: "6D" (D = 9), "matrix"
+    (D = 12) or "quaternion" (D = 7)."""
     lib = _lib.load()
+    if rel_rot not in _lib.REL_ROT:
+        raise ValueError(f"rel_rot {rel_rot!r}; expected one of {sorted(_lib.REL_ROT)}")
+    mode, dims = _lib.REL_ROT[rel_rot]
     dev = geom.pts_out.device
     shp = geom.shape(1, 1, 32)
     ff = shp.f_in * shp.f_out
     e2 = geom.neighbors.shape[0] * ff
-    desc = torch.empty((e2, 9), dtype=torch.float32, device=dev)
+    desc = torch.empty((e2, dims), dtype=torch.float32, device=dev)
     fe_nb = torch.empty((e2, 2), dtype=torch.int32, device=dev)
     fe_ends = torch.zeros(geom.pts_out.shape[0] * shp.f_out, dtype=torch.int32, device=dev)
     rho_t = _scalar(rho, "rho", dev)
-    _lib.check(lib.se3_rot_tensors(*_geom_ptrs(geom), _ptr(rho_t, torch.float32, "rho"), C.byref(shp),
-                                   _ptr(desc, torch.float32, "desc"), _ptr(fe_nb, torch.int32, "fe_neighbors"),
-                                   _ptr(fe_ends, torch.int32, "fe_ends"), _stream(dev)), "se3_rot_tensors")
+    _lib.check(lib.se3_rot_tensors_rel(*_geom_ptrs(geom), _ptr(rho_t, torch.float32, "rho"), C.byref(shp), mode,
+                                       _ptr(desc, torch.float32, "desc"), _ptr(fe_nb, torch.int32, "fe_neighbors"),
+                                       _ptr(fe_ends, torch.int32, "fe_ends"), _stream(dev)), "se3_rot_tensors_rel")
     return desc, fe_nb, fe_ends
 
 

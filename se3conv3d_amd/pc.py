@@ -9,8 +9,9 @@ Only what the convolution and the benchmark stack need:
     (``KnnNeighborhood`` + ``sample_reference_frames_pca``, scope row f-1, HIP kernels in csrc/frames.hip).
   * ``Neighborhood`` / ``BQNeighborhood``    (pc/Neighborhood.py, pc/BQNeighborhood.py:13-64) on the HIP ball query.
   * ``GridSubSample`` / ``PointHierarchy`` / ``PointHierarchyRotEquiv`` (pc/GridSubSample.py:40-93,
-    pc/Grid.py:37-57, pc/PointHierarchy.py:10-93, pc/PointHierarchyRotEquiv.py:7-44): grid-average
-    sub-sampling on the HIP key kernel + torch unique / index_reduce (plumbing), neighbourhood memo.
+    pc/Grid.py:37-57, pc/PointHierarchy.py:10-93, pc/PointHierarchyRotEquiv.py:7-44): grid-average and
+    random one-point-per-cell sub-sampling (``se3_grid_subsample`` / ``se3_grid_pick``), neighbourhood memo
+    (ball query and k-NN).
 """
 from __future__ import annotations
 
@@ -281,23 +282,35 @@ class BQNeighborhood(Neighborhood):
 
 
 class KnnNeighborhood(Neighborhood):
-    """Self-kNN neighbourhood (pc/KnnNeighborhood.py:14-75, the ``pc_src == samples`` / k <= 64 branch): fixed k
-    neighbours per point, ``neighbors_ [N*k, 2]`` (centre, neighbour; -1 where the batch element is too small),
-    ``start_ids_`` = ``(arange + 1) * k`` when empty slots are kept."""
+    """k-NN neighbourhood (pc/KnnNeighborhood.py:14-135): the k nearest SOURCE points of every sample inside its
+    batch element, k <= 64.  A cloud against itself is the reference's own kernel path (:38-75): ``neighbors_ [N*k, 2]``
+    int32 (centre, neighbour; the point itself first, -1 where the batch element is too small), ``start_ids_`` =
+    ``(arange + 1) * k`` when empty slots are kept.  Two different clouds are the reference's ``torch_cluster.knn``
+    path (:77-135): ``neighbors_`` int64 ``(sample, source)`` in ascending distance per sample, without the missing
+    entries unless ``p_keep_empty`` (then -1 in column 1, column 0 = the sample)."""
+
+    MAX_K = 64  # neighbours a query keeps in registers; the reference's kernel has the same limit (knn_query.cu:167)
 
     def __init__(self, p_pc_src, p_samples, p_k, p_keep_empty=False, p_standard_knn=False):
         # p_standard_knn (the evaluation scripts pass it, test_scannet_rot.py:110): the reference then takes
         # torch_cluster.knn instead of its own sweep kernel -- another EXACT k-NN; the search here is exact already,
         # so the flag only changes which of several equidistant candidates may come first there
-        if p_pc_src is not p_samples or p_k > 32:
-            raise NotImplementedError("only the self-kNN path with k <= 32 (PCA frame construction) is implemented")
-        self.k_ = p_k
+        if not 1 <= int(p_k) <= self.MAX_K:
+            raise NotImplementedError(f"KnnNeighborhood: k = {p_k}; the HIP k-NN keeps at most {self.MAX_K} neighbours "
+                                      "per point (the limit of the reference's own kernel; its torch_cluster fallback "
+                                      "for larger k is not implemented)")
+        self.k_ = int(p_k)
         self.keep_empty_ = p_keep_empty
         self.standard_knn_ = p_standard_knn
         super().__init__(p_pc_src, p_samples)
 
     def __compute_neighborhood__(self):
-        ids = ops.KNNQuery.apply(self.pc_src_.pts_, self.pc_src_.batch_ids_, self.k_)
+        self_query = self.pc_src_ is self.samples_
+        if self_query:
+            ids = ops.KNNQuery.apply(self.pc_src_.pts_, self.pc_src_.batch_ids_, self.k_)
+        else:
+            ids = ops.knn_query_pair(self.pc_src_.pts_, self.pc_src_.batch_ids_, self.samples_.pts_,
+                                     self.samples_.batch_ids_, self.k_)
         n = ids.shape[0]
         centers = torch.arange(n, dtype=torch.int32, device=ids.device)[:, None].expand(-1, self.k_)
         self.neighbors_ = torch.stack((centers.reshape(-1), ids.reshape(-1)), -1)
@@ -307,6 +320,8 @@ class KnnNeighborhood(Neighborhood):
             mask = self.neighbors_[:, 1] >= 0
             self.neighbors_ = self.neighbors_[mask]
             self.start_ids_ = torch.cumsum(mask.reshape(n, self.k_).sum(1), 0).to(torch.int32)
+        if not self_query:
+            self.neighbors_ = self.neighbors_.to(torch.int64)  # what torch_cluster.knn returns
 
 
 def sample_reference_frames_pca(points, p_neighborhood, axis_fixed=False, dtype=None, device=None):
@@ -317,17 +332,31 @@ def sample_reference_frames_pca(points, p_neighborhood, axis_fixed=False, dtype=
 
 # --------------------------------------------------------------------------------------- hierarchy
 class GridSubSample(object):
-    """Grid-average sub-sampling (pc/GridSubSample.py, pc/Grid.py, pc/BoundingBox.py): one library call builds the cell
-    ids, the per-cell point lists and the next level's points / batch ids (``ops.grid_subsample``)."""
+    """Grid sub-sampling (pc/GridSubSample.py, pc/Grid.py, pc/BoundingBox.py): one library call builds the cell ids, the
+    per-cell point lists and the cell averages (``ops.grid_subsample``).
 
-    def __init__(self, p_pc_src, p_cell_size):
+    ``p_rnd_sample=False``: a level point is the average of its cell (``grid_avg``).  ``p_rnd_sample=True``: ONE random
+    point represents each cell (GridSubSample.py:43-54) -- ``ids_`` are its positions in the cell-sorted point list
+    ``sorted_ids_`` exactly as in the reference, ``__subsample_tensor__`` gathers those rows whatever the method
+    (:66-67), ``__upsample_tensor__`` scatters rows back into zeros (:83-91).  The index choice runs on the device
+    (``se3_grid_pick``, no host synchronisation); ``p_rnd_values`` (extension) supplies the uniform numbers in [0,1)
+    instead of ``torch.rand`` on the device, one per cell in ascending cell-key order."""
+
+    def __init__(self, p_pc_src, p_cell_size, p_rnd_sample=False, p_rnd_values=None):
         self.pc_src_ = p_pc_src
         self.cell_size_ = p_cell_size
+        self.rnd_sample_ = bool(p_rnd_sample)
         self.cells_ = ops.grid_subsample(p_pc_src.pts_, p_pc_src.batch_ids_, p_cell_size, p_pc_src.num_batches())
         self.cell_ids_ = self.cells_.cell_ids
+        self.sorted_ids_ = self.cells_.sorted_ids
         self.num_out_ = self.cells_.n_cells
+        self.ids_ = None
+        if self.rnd_sample_:
+            self.ids_, self.picked_ = ops.grid_pick(self.cells_, p_rnd_values)
 
     def __subsample_tensor__(self, p_tensor, p_method="avg"):
+        if self.rnd_sample_:
+            return ops.RowsGather.apply(p_tensor, self.picked_)
         if p_method not in ("avg", "max"):
             raise ValueError(p_method)
         if p_tensor is self.pc_src_.pts_ and p_method == "avg" and not p_tensor.requires_grad:
@@ -339,15 +368,29 @@ class GridSubSample(object):
         return ops.GridPool.apply(p_tensor, self.cells_, p_method)
 
     def __upsample_tensor__(self, p_tensor):
+        if self.rnd_sample_:
+            if p_tensor.dim() != 2:
+                raise ValueError("__upsample_tensor__ of a random grid sub-sample takes [cells, C] tensors (as the reference)")
+            return ops.RowsScatter.apply(p_tensor, self.picked_, self.cell_ids_.shape[0])
         if not p_tensor.is_floating_point():
             return p_tensor[self.cell_ids_.to(torch.int64)]
         return ops.GridUpsample.apply(p_tensor, self.cells_)
 
 
+def _make_sub_sample(p_point_cloud, p_samp_method, p_id, **kwargs):
+    """The sub-sampling object of one hierarchy step (pc/PointHierarchy.py:46-52)."""
+    if p_samp_method == "grid_avg":
+        return GridSubSample(p_point_cloud, kwargs["grid_radii"][p_id], False)
+    if p_samp_method == "grid_rnd":
+        return GridSubSample(p_point_cloud, kwargs["grid_radii"][p_id], True)
+    if p_samp_method == "fps":
+        raise NotImplementedError("farthest-point sub-sampling (FPSSubSample -> torch_cluster.fps) is outside the "
+                                  "accelerated path; no *_rot configuration uses it (INTEGRATION.md)")
+    raise ValueError(f"unknown sub-sample method {p_samp_method!r} (grid_avg, grid_rnd)")
+
+
 class PointHierarchy(object):
     def __init__(self, p_point_cloud, p_num_sub_samples, p_subsample_method="grid_avg", **kwargs):
-        if p_subsample_method != "grid_avg":
-            raise NotImplementedError("only grid_avg sub-sampling is implemented (the *_rot task scripts use it)")
         self.sub_sampled_objs_ = []
         self.pcs_ = [p_point_cloud]
         cur = p_point_cloud
@@ -359,18 +402,25 @@ class PointHierarchy(object):
         self.neigh_cache_ = {}
 
     def __create_sub_sample__(self, p_point_cloud, p_samp_method, p_id, **kwargs):
-        samp = GridSubSample(p_point_cloud, kwargs["grid_radii"][p_id])
+        samp = _make_sub_sample(p_point_cloud, p_samp_method, p_id, **kwargs)
         new_pts = samp.__subsample_tensor__(p_point_cloud.pts_, "avg")
         new_bid = samp.__subsample_tensor__(p_point_cloud.batch_ids_, "max")
         return Pointcloud(new_pts, new_bid), samp
 
     def create_neighborhood(self, p_pc_src_id, p_pc_dest_id, p_neigh_method, **kwargs):
-        if p_neigh_method != "ball_query":
-            raise NotImplementedError("only ball_query neighbourhoods are on the accelerated path")
-        key = f"{p_pc_src_id}_{p_pc_dest_id}_{p_neigh_method}{kwargs['bq_radius']}"
+        """Memoised per (source level, destination level, method + its parameter), pc/PointHierarchy.py:60-79 (the k-NN
+        keyword is spelled ``neihg_k`` there; ``neigh_k`` is accepted too)."""
+        if p_neigh_method == "ball_query":
+            param = kwargs["bq_radius"]
+        elif p_neigh_method == "knn":
+            param = kwargs["neihg_k"] if "neihg_k" in kwargs else kwargs["neigh_k"]
+        else:
+            raise ValueError(f"unknown neighbourhood method {p_neigh_method!r} (ball_query, knn)")
+        key = f"{p_pc_src_id}_{p_pc_dest_id}_{p_neigh_method}{param}"
         if key not in self.neigh_cache_:
-            self.neigh_cache_[key] = BQNeighborhood(self.pcs_[p_pc_src_id], self.pcs_[p_pc_dest_id],
-                                                    kwargs["bq_radius"])
+            src, dst = self.pcs_[p_pc_src_id], self.pcs_[p_pc_dest_id]
+            self.neigh_cache_[key] = BQNeighborhood(src, dst, param) if p_neigh_method == "ball_query" else \
+                KnnNeighborhood(src, dst, param)
         return self.neigh_cache_[key]
 
     def clear_neigh_cache(self):
@@ -389,7 +439,7 @@ class PointHierarchyRotEquiv(PointHierarchy):
     """Every level gets its own freshly sampled frames (pc/PointHierarchyRotEquiv.py:31-44)."""
 
     def __create_sub_sample__(self, p_point_cloud, p_samp_method, p_id, **kwargs):
-        samp = GridSubSample(p_point_cloud, kwargs["grid_radii"][p_id])
+        samp = _make_sub_sample(p_point_cloud, p_samp_method, p_id, **kwargs)
         new_pts = samp.__subsample_tensor__(p_point_cloud.pts_, "avg")
         new_bid = samp.__subsample_tensor__(p_point_cloud.batch_ids_, "max")
         return PointcloudRotEquiv(new_pts, new_bid, p_point_cloud.local_frames_config_), samp

@@ -51,3 +51,35 @@ def test_reference_style_checkpoint_round_trip(tmp_path):
     for prefix in ("first_conv_", "plain_conv_", "block_.spatial_conv_"):
         for leaf in ("proj_axes_", "proj_biases_", "conv_weights_", "norm_neigh_dist_", "norm_num_neighs_"):
             assert f"{prefix}.{leaf}" in want, f"{prefix}.{leaf}"
+
+
+def test_state_dict_layout_equals_the_reference_modules():
+    """Names AND shapes of every parameter / buffer against a key list generated from the reference's own modules
+    (tools/gen_golden.py `keys`: PNEConvLayerRotEquiv, PNEConvLayer, BatchNormPC, SkipConnection, ResNetFormer with and
+    without its `skip_conv_`), then a strict load of a state dict carrying exactly those keys."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as fh:
+        ref = json.load(fh)
+    eq = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu")
+    std = amd.PNEConvLayerFactory(3, 32, "mlp_gelu")
+    ours = {
+        "PNEConvLayerRotEquiv(9,16,24,32)": eq.create_conv_layer(16, 24),
+        "PNEConvLayer(3,16,24,32)": std.create_conv_layer(16, 24),
+        "BatchNormPC(24)": blocks.BatchNormPC(24),
+        "SkipConnection(24)": blocks.SkipConnection(0.1, 24),
+        "ResNetFormer(16,24)": blocks.ResNetFormer(16, 24, eq, blocks.BatchNormPC, 0.1),
+        "ResNetFormer(24,24)": blocks.ResNetFormer(24, 24, eq, blocks.BatchNormPC, 0.0),
+    }
+    assert sorted(ours) == sorted(ref)
+    for name, module in ours.items():
+        got = {k: list(v.shape) for k, v in module.state_dict().items()}
+        assert got == ref[name], name
+        # a checkpoint with the reference's keys (values arbitrary) loads strictly
+        fake = {k: torch.full(shape, 0.25) if k.split(".")[-1] != "num_batches_tracked" else torch.tensor(3)
+                for k, shape in ref[name].items()}
+        missing, unexpected = module.load_state_dict(fake, strict=True)
+        assert not missing and not unexpected, name

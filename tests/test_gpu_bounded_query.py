@@ -48,11 +48,12 @@ def test_bounded_equals_two_phase_and_oracle(amd, n_src, n_dst, batches, r):
     nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=e, n_batches=batches)
     assert info.tolist() == [e, 0] and torch.equal(nb, nb2)
     cap = e // 2
-    sentinel = torch.full((cap + 7, 2), -7, dtype=torch.int32, device=DEV)
-    nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=cap, n_batches=batches)
+    # the edge buffer sits inside a larger pre-filled arena: a truncated build must not write a row past its capacity
+    arena = torch.full((cap + 64, 2), -7, dtype=torch.int32, device=DEV)
+    nb, ends, info = amd.ops.ball_query_bounded(*args, capacity=cap, n_batches=batches, neighbors_out=arena[:cap])
     assert info.tolist() == [e, 1]
     assert torch.equal(ends.cpu(), torch.clamp(ends_r, max=cap)) and torch.equal(nb, nb2[:cap])
-    del sentinel
+    assert nb.data_ptr() == arena.data_ptr() and bool((arena[cap:] == -7).all())
     # the optional dense list of source ids = column 1 of the edge list (the source-major list of a symmetric graph)
     nb, ends, info, src = amd.ops.ball_query_bounded(*args, capacity=e + 5, n_batches=batches, want_sources=True)
     assert torch.equal(src[:e], nb2[:, 1]) and torch.equal(nb[:e], nb2)
@@ -111,3 +112,47 @@ def test_neighbourhood_and_conv_step_in_one_graph(amd):
     assert small.overflowed() and small.num_edges() == e // 3
     out_small = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x.detach(), p_neighborhood=small)
     assert bool(torch.isfinite(out_small).all())
+
+
+@pytest.mark.parametrize("poison", [False, True])
+def test_bounded_neighbourhood_between_two_clouds_runs_forward_and_backward(amd, poison):
+    """A capacity-bounded neighbourhood between DIFFERENT clouds: backward needs the source-major copy of the edge list,
+    and the unset tail of the buffer must not reach the sort that builds it (se3_csr_transpose_bounded).  Outputs and
+    every gradient equal the two-phase neighbourhood's bit for bit -- also when the tail holds in-range garbage ids."""
+    torch.manual_seed(1)
+    n_in, n_out, f, c_in, c_out = 5000, 1800, 2, 32, 64
+    cfg = {"pca": False, "n_frames": f, "fixed_axis": False}
+    pc_in = amd.pc.PointcloudRotEquiv(torch.rand(n_in, 3, device=DEV), torch.zeros(n_in, dtype=torch.int32, device=DEV), cfg)
+    pc_out = amd.pc.PointcloudRotEquiv(torch.rand(n_out, 3, device=DEV), torch.zeros(n_out, dtype=torch.int32, device=DEV), cfg)
+    pc_in.num_batches(), pc_out.num_batches()
+    r = radius_for_degree(n_in, 20)
+    ref_nbh = amd.pc.BQNeighborhood(pc_in, pc_out, r)
+    e = ref_nbh.num_edges()
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c_in, c_out).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r), conv.norm_num_neighs_.fill_(n_out / e)
+    x = torch.randn(n_in * f, c_in, device=DEV, requires_grad=True)
+    g = torch.randn(n_out * f, c_out, device=DEV)
+
+    def run(nbh):
+        x.grad = None
+        conv.zero_grad(set_to_none=True)
+        out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=x, p_neighborhood=nbh)
+        out.backward(g)
+        return [t.detach().clone() for t in (out, x.grad, conv.proj_axes_.grad, conv.proj_biases_.grad, conv.conv_weights_.grad)]
+
+    want = run(ref_nbh)
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, r, p_capacity=int(e * 1.3) + 11)
+    assert not nbh.symmetric_ and not nbh.overflowed() and nbh.num_edges() == e
+    if poison:  # what an uninitialised allocation may hold: ids that look like real points
+        tail = nbh.neighbors_i32_[e:]
+        tail[:, 0] = torch.randint(0, n_out, (tail.shape[0],), device=DEV, dtype=torch.int32)
+        tail[:, 1] = torch.randint(0, n_in, (tail.shape[0],), device=DEV, dtype=torch.int32)
+    got = run(nbh)
+    for a, b, name in zip(got, want, ("out", "dX", "dA", "dbeta", "dW")):
+        assert torch.equal(a, b), name
+    # against the oracle as well (the two-phase path is not the only witness)
+    ref = O.conv_forward_backward(pc_in.pts_.cpu(), pc_out.pts_.cpu(), pc_in.local_frames_.cpu(), pc_out.local_frames_.cpu(),
+                                  ref_nbh.neighbors_.cpu(), x.detach().cpu(), conv.proj_axes_.detach().cpu(),
+                                  conv.proj_biases_.detach().cpu(), conv.conv_weights_.detach().cpu(), 1.0 / r, n_out / e, g.cpu())
+    for a, b, name in zip(got, ref, ("out", "dX", "dA", "dbeta", "dW")):
+        assert rel_err(a, b) < 5e-5, name

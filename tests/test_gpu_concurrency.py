@@ -105,6 +105,75 @@ def test_forked_backward_inside_graph_capture(amd):
         assert torch.equal(u, v)
 
 
+def _side_stats():
+    import ctypes as C
+    from se3conv3d_amd import _lib
+
+    buf = (C.c_int32 * 3)()
+    _lib.check(_lib.load().se3_side_stream_stats(C.cast(buf, C.c_void_p)), "se3_side_stream_stats")
+    return list(buf)   # [streams that own a side stream, spares on this device, sets created in this process]
+
+
+def test_capture_creates_no_runtime_objects(amd):
+    """The capture contract (include/se3conv.h): the side stream a captured backward forks onto was made by
+    an earlier EAGER call -- nothing is created while the caller's stream is being captured."""
+    c = _case(amd, 6)                       # 10 000 output rows: backward forks
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):              # warm-up on a side stream, as torch asks for before a capture
+        ref = _fwd_bwd(c)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    owners0, spares0, created0 = _side_stats()
+    assert spares0 >= 1
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):           # torch captures on a stream of its own: new to the library
+        outs = _fwd_bwd(c)
+    owners1, spares1, created1 = _side_stats()
+    assert created1 == created0, "a stream / event was created during the capture"
+    # torch captures on a stream from its pool: new to the library (it took a spare) or known from an earlier capture
+    assert (owners1, spares1) in ((owners0 + 1, spares0 - 1), (owners0, spares0))
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    for u, v in zip(outs, ref):
+        assert torch.equal(u, v)
+    _fwd_bwd(c)                             # the next eager call tops the spares up again
+    assert _side_stats()[1] >= spares0
+
+
+def test_first_call_of_a_process_inside_a_capture_does_not_fork():
+    """No eager call before the capture: no spare exists, the captured backward runs its branches back to back (same
+    results).  Own process: the library state of this one is warm."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import se3conv3d_amd as amd
+import test_gpu_concurrency as T
+amd.set_precision("bf16x3")
+# geometry, neighbourhood and parameters are built eagerly (they are inputs); the operator itself first runs captured
+c = T._case(amd, 7)
+assert T._side_stats() == [0, 0, 0]
+s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    outs = T._fwd_bwd(c)
+assert T._side_stats() == [0, 0, 0], T._side_stats()
+graph.replay(); torch.cuda.synchronize()
+ref = T._fwd_bwd(c); torch.cuda.synchronize()
+assert all(torch.equal(u, v) for u, v in zip(outs, ref))
+assert T._side_stats()[2] > 0
+print("ok")
+''' % (root, root)
+    proc = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "ok" in proc.stdout, (proc.stdout + proc.stderr)[-2000:]
+
+
 def test_tensors_on_another_device_are_refused(amd):
     from se3conv3d_amd import ops
 

@@ -132,10 +132,12 @@ def test_reference_resnetformer_block_runs_unchanged(built_library):
 
 
 @pytest.mark.timeout(600)
-def test_bench_two_ranks_on_one_gpu_rehearsal():
+@pytest.mark.parametrize("workload", ["headline", "scannet150k_f1"])
+def test_bench_two_ranks_on_one_gpu_rehearsal(workload):
     """`bench.py --gpus 2` started plainly forks two ranks (torch.distributed.run children); with --share-gpu both use
     this box's one GPU and gloo carries the barrier / MAX reduce / result gather: the whole N-rank path runs real
-    kernels -- two scenes (seeds = scene ids), one JSON line from rank 0 with n_gpus = 2 and both checksums."""
+    kernels -- two scenes (seeds = scene ids), one JSON line from rank 0 with n_gpus = 2 and both checksums.
+    `scannet150k_f1` is the workload BASELINE.json's config 5 names (150 k-point scenes sharded by scene, F = 1)."""
     import json
     import os
     import subprocess
@@ -144,7 +146,8 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3",
-                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=550, env=env, cwd=root)
+                        "--warmup", "1", "--no-cpu-baseline", "--workload", workload],
+                       capture_output=True, text=True, timeout=550, env=env, cwd=root)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -152,6 +155,7 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and sorted(rec["scene_checksums"]) == ["0", "1"]
     assert rec["scene_checksums"]["0"] != rec["scene_checksums"]["1"]      # different scenes per rank
     assert "roofline" not in rec                                            # single-GPU extras stay out of N > 1 lines
+    assert rec["config"]["workload"].startswith(workload) and rec["config"]["n_points"] == (65536 if workload == "headline" else 150000)
 
 
 @pytest.mark.timeout(600)

@@ -1,15 +1,16 @@
 """Kernel variants that are selected by environment variables (read once per process) are exercised by
 re-running a slice of the parity suite in a child process with the variable set:
 
-  SE3_BWD_MERGE=1   merged transposed-convolution + parameter-gradient kernel, role-specialised wavefronts (edge_bwd_bf16.hip)
   SE3_NO_PAIR=1     single-wavefront edge kernel instead of the wave-pair kernel for C = 64
-  SE3CONV_FUSED=1   fused edge + contraction kernel (fused_bf16.hip)
   SE3_PG_SINGLE=1   one row per wavefront in the parameter-gradient kernel (what odd frame counts use)
   SE3_PAIR_PERSIST=n  wave-pair edge kernel with n persistent workgroups walking strided items
   SE3_NO_T24=1      T and U as packed hi/lo words instead of the 3-byte row format (what C < 64 always uses)
   SE3_OVERLAP=1     backward branches on two streams at every size (default: 4 k - 32 k output rows only)
   SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
-  SE3_PAIR_STREAM=1 wave-pair edge kernel as a chunk stream over edge-balanced point ranges (edge_t_pair_stream_bf16_kernel)
+
+(The merged backward kernel, the fused edge + contraction kernel and the chunk-stream kernels of rounds 1-2 lost their A/B
+measurements -- profiles/r02_levels_fused.txt, r02_stream_kernel_ab.txt, r03_merged_backward_and_stash_ab.txt -- and were
+removed in round 3; so were round 3's in-kernel reductions, profiles/r03_in_kernel_reduction_ab.txt.)
 
 One child at a time; each child is an ordinary `pytest -m gpu` run over the golden / random-shape / headline
 tests of tests/test_gpu_parity.py.
@@ -25,8 +26,8 @@ SLICE = "golden or random_shapes or headline_subset or features_only or empty_ro
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("var", ["SE3_BWD_MERGE", "SE3_NO_PAIR", "SE3CONV_FUSED", "SE3_PG_SINGLE", "SE3_PAIR_PERSIST=64",
-                                 "SE3_NO_T24", "SE3_OVERLAP", "SE3_BWD_BRANCH_ORDER", "SE3_PAIR_STREAM"])
+@pytest.mark.parametrize("var", ["SE3_NO_PAIR", "SE3_PG_SINGLE", "SE3_PAIR_PERSIST=64", "SE3_NO_T24", "SE3_OVERLAP",
+                                 "SE3_BWD_BRANCH_ORDER"])
 def test_variant_passes_parity_slice(var):
     env = dict(os.environ)
     name, _, value = var.partition("=")

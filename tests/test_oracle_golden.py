@@ -228,3 +228,56 @@ def test_resnetformer_block_glue_matches_reference_fixture():
     for k, v in blk.state_dict().items():
         if "running" in k:
             np.testing.assert_allclose(v.numpy(), d["after/" + k], rtol=1e-5, atol=1e-6)
+
+
+# ---- round 3: random grid sub-sample, other relative-rotation descriptors, checkpoint key layout -------------------
+def test_grid_rnd_oracle_matches_reference_fixture():
+    """GridSubSample(..., p_rnd_sample=True) (GridSubSample.py:43-54): `ids_` from the stored uniform numbers is integer
+    work (bit-exact); which point sits at a position of the cell-sorted list is left open by the reference (its argsort
+    is not stable), so the gather / scatter maps are checked with the reference's own `sorted_ids_`."""
+    d = load_npz(os.path.join(GOLDEN, "grid_rnd.npz"))
+    cell_ids, n_cells, _, _ = O.grid_subsample(d["pts"], d["batch"], float(d["cell"]))
+    assert torch.equal(cell_ids.to(torch.int32), d["cell_ids"]) and n_cells == d["u"].shape[0]
+    sorted_ids, ids, picked = O.grid_subsample_rnd(cell_ids, d["u"])
+    assert torch.equal(ids.to(torch.int32), d["ids"])
+    # the oracle's pick and the reference's pick are points of the same cell
+    assert torch.equal(cell_ids[picked], torch.arange(n_cells))
+    assert torch.equal(d["cell_ids"].long()[d["picked"].long()], torch.arange(n_cells))
+    ref_picked = d["sorted_ids"].long()[ids]
+    assert torch.equal(ref_picked.to(torch.int32), d["picked"])
+    assert torch.equal(d["pts"][ref_picked], d["sub_pts"]) and torch.equal(d["labels"][ref_picked], d["sub_labels"])
+    assert torch.equal(d["batch"][ref_picked], d["sub_batch"])
+    assert torch.equal(O.rows_upsample_rnd(d["z"], ref_picked, d["pts"].shape[0]), d["up_y"])
+    assert torch.equal(O.rows_upsample_rnd(d["sub_g"], ref_picked, d["pts"].shape[0]), d["sub_dx"])  # gradient of the gather
+    assert torch.equal(d["up_g"][ref_picked], d["up_dz"])                                             # gradient of the scatter
+
+
+@pytest.mark.parametrize("rel_rot", ["matrix", "quaternion"])
+def test_rel_rot_descriptors_and_layer_match_reference(rel_rot):
+    """p_rel_rot = 'matrix' (D = 12) / 'quaternion' (D = 7), RotationFunctions.py:593-600: descriptors, forward, gradients."""
+    d = load_npz(os.path.join(GOLDEN, f"rel_rot_{rel_rot}.npz"))
+    nb = d["neighbors"].long()
+    rt = O.get_rot_tensors(d["pts"], d["pts"], d["frames"], d["frames"], nb, d["rho"], rel_rot=rel_rot)
+    assert torch.equal(rt["neighbs_start_ids"], d["rt_ends"])
+    ref_nb, new_nb = d["rt_neighbs"].long(), rt["neighbs"]
+    big = int(ref_nb[:, 1].max()) + 1
+    o_ref, o_new = torch.argsort(ref_nb[:, 0] * big + ref_nb[:, 1]), torch.argsort(new_nb[:, 0] * big + new_nb[:, 1])
+    assert torch.equal(ref_nb[o_ref], new_nb[o_new])
+    assert rel_err(rt["rel_pts_rel_orient"][o_new], d["rt_desc"][o_ref]) < TOL
+    out, dx, da, db, dw = O.conv_forward_backward(d["pts"], d["pts"], d["frames"], d["frames"], nb, d["x"], d["proj_axes"],
+                                                  d["proj_biases"], d["conv_weights"], d["rho"], d["nu"], d["grad_out"],
+                                                  rel_rot=rel_rot)
+    for got, key in ((out, "out"), (dx, "dx"), (da, "dA"), (db, "dbeta"), (dw, "dW")):
+        assert rel_err(got, d[key]) < TOL, key
+
+
+def test_knn_pair_oracle_reduces_to_self_query():
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(300, 3, generator=g)
+    bid = torch.sort(torch.randint(0, 3, (300,), generator=g, dtype=torch.int32)).values
+    assert torch.equal(O.knn_query_pair(pts, bid, pts, bid, 9), O.knn_query(pts, bid, 9))
+    q = torch.rand(40, 3, generator=g)
+    qb = torch.sort(torch.randint(0, 4, (40,), generator=g, dtype=torch.int32)).values  # batch 3 has no sources
+    ids = O.knn_query_pair(pts, bid, q, qb, 5)
+    assert (ids[qb == 3] == -1).all() and (ids[qb < 3] >= 0).all()
+    assert (bid[ids[qb < 3].long()] == qb[qb < 3][:, None]).all()

@@ -289,6 +289,107 @@ def hierarchy_case(pclib, seed):
     return out
 
 
+def grid_rnd_case(pclib, seed):
+    """GridSubSample(..., p_rnd_sample=True) of the reference (pc/GridSubSample.py:43-54, 66-67, 83-91) as the task
+    scripts use it for the output cloud (tasks/SemSeg/train_dfaust_rot.py:143-149), plus a PointHierarchy built with
+    "grid_rnd".  Stored: the uniform numbers the reference drew (its first RNG call after the seed: re-drawn here and
+    checked against `ids_`), `ids_`, `sorted_ids_`, `cell_ids_`, the selected points, the sub-sampled points / batch ids /
+    labels, an up-sampled feature tensor and the gradients of both maps."""
+    n, c = 600, 10
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(n, 3, generator=g) * torch.tensor([1.0, 0.8, 0.5])
+    bid = torch.sort(torch.randint(0, 3, (n,), dtype=torch.int32, generator=g)).values
+    labels = torch.randint(0, 7, (n,), dtype=torch.int64, generator=g)
+    cell = 0.13
+    pc = pclib.pc.Pointcloud(pts, bid)
+    torch.manual_seed(seed + 100)
+    samp = pclib.pc.GridSubSample(pc, cell, p_rnd_sample=True)
+    n_cells = int(samp.grid_.cell_ids_.max()) + 1
+    torch.manual_seed(seed + 100)
+    u = torch.rand(n_cells)  # the numbers GridSubSample.py:52 drew
+    counts = torch.bincount(samp.grid_.cell_ids_.long())
+    assert torch.equal(torch.floor(u * counts).to(torch.int32) + (torch.cumsum(counts, 0) - counts).to(torch.int32), samp.ids_)
+    picked = samp.grid_.sorted_ids_[samp.ids_.long()]
+    out = {"pts": pts.numpy(), "batch": bid.numpy(), "labels": labels.numpy(), "cell": np.float32(cell), "u": u.numpy(),
+           "ids": samp.ids_.numpy().astype(np.int32), "sorted_ids": samp.grid_.sorted_ids_.numpy().astype(np.int32),
+           "cell_ids": samp.grid_.cell_ids_.numpy().astype(np.int32), "picked": picked.numpy().astype(np.int32),
+           "sub_pts": samp.__subsample_tensor__(pc.pts_, "avg").numpy(),
+           "sub_batch": samp.__subsample_tensor__(pc.batch_ids_, "max").numpy().astype(np.int32),
+           "sub_labels": samp.__subsample_tensor__(labels, "max").numpy()}
+    x = torch.randn(n, c, generator=g, requires_grad=True)
+    y = samp.__subsample_tensor__(x, "avg")
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out["x"], out["sub_x"], out["sub_g"], out["sub_dx"] = x.detach().numpy(), y.detach().numpy(), gy.numpy(), x.grad.numpy()
+    z = torch.randn(n_cells, c, generator=g, requires_grad=True)
+    up = samp.__upsample_tensor__(z)
+    gu = torch.randn(up.shape, generator=g)
+    up.backward(gu)
+    out["z"], out["up_y"], out["up_g"], out["up_dz"] = z.detach().numpy(), up.detach().numpy(), gu.numpy(), z.grad.numpy()
+    # a two-step hierarchy with "grid_rnd": the random numbers of each step, the level points / batch ids
+    cells = [0.11, 0.23]
+    torch.manual_seed(seed + 200)
+    hier = pclib.pc.PointHierarchy(pclib.pc.Pointcloud(pts, bid), 2, "grid_rnd", grid_radii=cells)
+    torch.manual_seed(seed + 200)
+    out["h_cells"] = np.array(cells, dtype=np.float32)
+    for lv in (1, 2):
+        nc = hier.pcs_[lv].pts_.shape[0]
+        out[f"h_u{lv}"] = torch.rand(nc).numpy()
+        out[f"h_pts{lv}"] = hier.pcs_[lv].pts_.numpy()
+        out[f"h_batch{lv}"] = hier.pcs_[lv].batch_ids_.numpy().astype(np.int32)
+        out[f"h_picked{lv}"] = hier.sub_sampled_objs_[lv - 1].grid_.sorted_ids_[hier.sub_sampled_objs_[lv - 1].ids_.long()].numpy().astype(np.int32)
+    return out
+
+
+def rel_rot_case(pclib, seed, rel_rot, dims):
+    """PNEConvLayerRotEquiv with p_rel_rot = 'matrix' (12-D descriptor) / 'quaternion' (7-D): forward, backward and the
+    materialised rot tensors through the reference's Python (PNEConvLayerRotEquiv.py:236-281, RotationFunctions.py:593-600)."""
+    torch.manual_seed(seed)
+    n, f, c_in, c_out = 160, 2, 8, 16
+    pts = torch.rand(n, 3)
+    bid = torch.zeros(n, dtype=torch.int32)
+    pc = pclib.pc.PointcloudRotEquiv(pts, bid, {"pca": False, "n_frames": f, "fixed_axis": False})
+    r = _radius(n, 10)
+    neigh = pclib.pc.BQNeighborhood(pc, pc, r)
+    conv = pclib.layers.PNEConvLayerRotEquivFactory(dims, 32, "mlp_gelu", rel_rot).create_conv_layer(c_in, c_out)
+    with torch.no_grad():
+        conv.proj_biases_.uniform_(-0.5, 0.5)
+    conv.norm_neigh_dist_ = torch.tensor(1.0 / r, dtype=torch.float32)
+    conv.norm_num_neighs_ = torch.tensor(neigh.start_ids_.shape[0] / neigh.neighbors_.shape[0], dtype=torch.float32)
+    pclib.layers.PNEConvLayerRotEquiv.empty_rot_tenors_cache()
+    x = torch.randn(n * f, c_in, requires_grad=True)
+    out = conv(p_pc_in=pc, p_pc_out=pc, p_in_features=x, p_neighborhood=neigh)
+    g = torch.randn_like(out)
+    out.backward(g)
+    rt = pclib.layers.PNEConvLayerRotEquiv.get_rot_tenors(pc, pc, neigh, conv.norm_neigh_dist_)
+    pclib.layers.PNEConvLayerRotEquiv.rel_rot_type = "6D"  # class attribute set by the last-created factory: restore
+    pclib.layers.PNEConvLayerRotEquiv.empty_rot_tenors_cache()
+    return {"pts": pts.numpy(), "batch": bid.numpy(), "frames": pc.local_frames_.numpy(), "radius": np.float64(r),
+            "neighbors": neigh.neighbors_.numpy().astype(np.int32), "ends": neigh.start_ids_.numpy().astype(np.int32),
+            "proj_axes": conv.proj_axes_.detach().numpy(), "proj_biases": conv.proj_biases_.detach().numpy(),
+            "conv_weights": conv.conv_weights_.detach().numpy(), "rho": conv.norm_neigh_dist_.numpy(),
+            "nu": conv.norm_num_neighs_.numpy(), "x": x.detach().numpy(), "out": out.detach().numpy(), "grad_out": g.numpy(),
+            "dx": x.grad.numpy(), "dA": conv.proj_axes_.grad.numpy(), "dbeta": conv.proj_biases_.grad.numpy(),
+            "dW": conv.conv_weights_.grad.numpy(), "rt_desc": rt["rel_pts_rel_orient"].numpy(),
+            "rt_neighbs": rt["neighbs"].numpy().astype(np.int32), "rt_ends": rt["neighbs_start_ids"].numpy().astype(np.int32)}
+
+
+def state_dict_keys(pclib):
+    """Parameter / buffer names and shapes of the reference's modules around the hot path (checkpoint layout): the two
+    convolutions, BatchNormPC, SkipConnection and a whole ResNetFormer block.  Names and shapes only -- no values."""
+    rot = pclib.layers.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu")
+    pne = pclib.layers.PNEConvLayerFactory(3, 32, "mlp_gelu")
+    mods = {
+        "PNEConvLayerRotEquiv(9,16,24,32)": rot.create_conv_layer(16, 24),
+        "PNEConvLayer(3,16,24,32)": pne.create_conv_layer(16, 24),
+        "BatchNormPC(24)": pclib.layers.BatchNormPC(24),
+        "SkipConnection(24)": pclib.layers.SkipConnection(0.1, 24),
+        "ResNetFormer(16,24)": pclib.layers.ResNetFormer(16, 24, rot, pclib.layers.BatchNormPC, 0.1),
+        "ResNetFormer(24,24)": pclib.layers.ResNetFormer(24, 24, rot, pclib.layers.BatchNormPC, 0.0),
+    }
+    return {name: {k: list(v.shape) for k, v in m.state_dict().items()} for name, m in mods.items()}
+
+
 def block_case(pclib, seed):
     """A whole ResNetFormer block of the reference (BatchNormPC in training mode, SkipConnection with gamma moved off
     its 1e-6 initial value, no drop path) around PNEConvLayerRotEquiv: state_dict, input, output and every gradient."""
@@ -390,6 +491,27 @@ def main():
         np.savez_compressed(path, **hierarchy_case(pclib, 11))
         print(f"{path}: size={os.path.getsize(path) / 1e6:.2f} MB")
     if only == "hierarchy":
+        return
+    if only in ("", "grid_rnd"):
+        path = os.path.join(OUT, "grid_rnd.npz")
+        np.savez_compressed(path, **grid_rnd_case(pclib, 17))
+        print(f"{path}: size={os.path.getsize(path) / 1e6:.2f} MB")
+    if only == "grid_rnd":
+        return
+    if only in ("", "rel_rot"):
+        for rel_rot, dims in (("matrix", 12), ("quaternion", 7)):
+            path = os.path.join(OUT, f"rel_rot_{rel_rot}.npz")
+            np.savez_compressed(path, **rel_rot_case(pclib, 19, rel_rot, dims))
+            print(f"{path}: size={os.path.getsize(path) / 1e6:.2f} MB")
+    if only == "rel_rot":
+        return
+    if only in ("", "keys"):
+        import json
+        path = os.path.join(OUT, "state_dict_keys.json")
+        with open(path, "w") as fh:
+            json.dump(state_dict_keys(pclib), fh, indent=1, sort_keys=True)
+        print(f"{path}: written")
+    if only == "keys":
         return
     if only in ("", "block"):
         path = os.path.join(OUT, "resnetformer_block.npz")

@@ -15,7 +15,6 @@ from collections import defaultdict
 STAGES = {
     "edge_t_pair_bf16_kernel": ["edge_t_fwd", "edge_t_transposed"],
     "edge_param_grad_bf16_v2_kernel": ["edge_param_grad"],
-    "edge_bwd_pair_bf16_kernel": ["edge_bwd"],
     "gemm_nn_bf16_kernel": ["gemm_out", "gemm_gradX"],
     "gemm_nn_t24_kernel": ["gemm_out", "gemm_gradX"],
     "gemm_strip_bf16_kernel": ["gemm_gradT"],
@@ -32,7 +31,11 @@ def main(d, out):
                 for key in STAGES:
                     if key in r["Kernel_Name"]:
                         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    res = {"_note": __doc__.split("usage:")[0].strip() + "  Headline shape N=65536, k=32, F=2, C=64, K=32, bf16x3."}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench  # library_source_sha: bench.py reports this file's numbers only while the kernel sources still match
+
+    res = {"_note": __doc__.split("usage:")[0].strip() + "  Headline shape N=65536, k=32, F=2, C=64, K=32, bf16x3.",
+           "_library_source_sha": bench.library_source_sha()}
     for key, cs in acc.items():
         if "FETCH_SIZE" not in cs or "WRITE_SIZE" not in cs:
             continue
