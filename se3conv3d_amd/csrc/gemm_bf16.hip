@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
 #ifndef SE3_T24_NT_LOADS
 #define SE3_T24_NT_LOADS 0  // 1: the row stream is loaded non-temporally (read once; keeps the weight tiles in L2)
 #endif
+// (256-row workgroups -- 8 wavefronts, the weight planes fetched from L2 half as often -- were measured in round 3:
+// nothing at the headline shape, 15 % slower on a 150 k-row scene whose 586 workgroups no longer divide into full rounds:
+// profiles/r03_gemm_256row_ab.txt.)
 template <int OUT_MODE, int NB>
 __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restrict__ a,
                                                           const uint16_t* __restrict__ bt_hi,
@@ -246,19 +249,24 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
                                                           int64_t m, int n, int k, int st_per_split,
                                                           const float* __restrict__ alpha_num, float alpha_scale) {
   constexpr int BNW = BN * NB;
-  __shared__ __attribute__((aligned(16))) uint16_t ash[2][BM][BK + 8];   // 80-byte pitch
-  __shared__ __attribute__((aligned(16))) uint8_t asl[2][BM][BK + 16];   // 48-byte pitch
+  constexpr int RB = BM;           // rows per workgroup
+  constexpr int RP = 32;           // rows one load pass of the hi plane covers (8 threads per row): 4 passes = RB rows
+  constexpr int RPL = 64;          // rows one load pass of the lo plane covers (4 threads per row): 2 passes = RB rows
+  constexpr int CP = 32;           // weight columns one load pass covers: 2 * NB passes per plane
+  constexpr int NBP = 2 * NB;
+  __shared__ __attribute__((aligned(16))) uint16_t ash[2][RB][BK + 8];   // 80-byte pitch
+  __shared__ __attribute__((aligned(16))) uint8_t asl[2][RB][BK + 16];   // 48-byte pitch
   __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BNW][B_LD];
   __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
   // SE3_T24_REVERSE: row blocks last-written first (the producer wrote the rows front to back just before this launch)
-  const int64_t m0 = (int64_t)(SE3_T24_REVERSE ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * BM;
+  const int64_t m0 = (int64_t)(SE3_T24_REVERSE ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * RB;
   const int n0 = blockIdx.y * BNW;
   const int st_begin = blockIdx.z * st_per_split;
   const int ns = min(k / 64 - st_begin, st_per_split);  // super tiles of this block (> 0 by construction)
 
-  struct Super { u32x4 ah[4], al[2], bh[2 * NB], bl[2 * NB]; };
+  struct Super { u32x4 ah[4], al[2], bh[NBP], bl[NBP]; };
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(a), (short)0, (int)(uint32_t)(m * k * 3), 0x00020000);
   const __amdgpu_buffer_rsrc_t bh_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -274,17 +282,17 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
     const uint32_t k0 = (uint32_t)(st_begin + st) * 64u;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const uint32_t off = (uint32_t)(m0 + p * 32 + (tid >> 3)) * rb + k0 * 2u + (uint32_t)((tid & 7) ^ ((p & 1) << 2)) * 16u;
+      const uint32_t off = (uint32_t)(m0 + p * RP + (tid >> 3)) * rb + k0 * 2u + (uint32_t)((tid & 7) ^ ((p & 1) << 2)) * 16u;
       t.ah[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, SE3_T24_NT_LOADS ? 2 : 0));
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const uint32_t off = (uint32_t)(m0 + p * 64 + (tid >> 2)) * rb + (uint32_t)k * 2u + k0 + (uint32_t)((tid & 3) ^ (p << 1)) * 16u;
+      const uint32_t off = (uint32_t)(m0 + p * RPL + (tid >> 2)) * rb + (uint32_t)k * 2u + k0 + (uint32_t)((tid & 3) ^ (p << 1)) * 16u;
       t.al[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, SE3_T24_NT_LOADS ? 2 : 0));
     }
 #pragma unroll
-    for (int j = 0; j < 2 * NB; ++j) {  // j = 2 * nb + p: columns 64 nb + 32 p + (tid >> 3)
-      const uint32_t off = ((uint32_t)(n0 + 32 * j + (tid >> 3)) * (uint32_t)k + k0 + (uint32_t)((tid & 7) ^ ((j & 1) << 2)) * 8u) * 2u;
+    for (int j = 0; j < NBP; ++j) {  // pass j: columns CP * j + (tid >> 3); passes alternate which 32-k half a thread holds
+      const uint32_t off = ((uint32_t)(n0 + CP * j + (tid >> 3)) * (uint32_t)k + k0 + (uint32_t)((tid & 7) ^ ((j & 1) << 2)) * 8u) * 2u;
       t.bh[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, off, 0, 0));
       t.bl[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, off, 0, 0));
     }
@@ -293,13 +301,14 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
   auto store_half = [&](const Super& t, int hf, int buf) {
     const bool q = (hf ^ hsel) != 0, ql = (hf ^ lsel) != 0;
     const int r8 = tid >> 3, c4 = (tid & 3) * 8;
-    *reinterpret_cast<u32x4*>(&ash[buf][(q ? 32 : 0) + r8][c4]) = q ? t.ah[1] : t.ah[0];
-    *reinterpret_cast<u32x4*>(&ash[buf][(q ? 96 : 64) + r8][c4]) = q ? t.ah[3] : t.ah[2];
-    *reinterpret_cast<u32x4*>(&asl[buf][(ql ? 64 : 0) + (tid >> 2)][(tid & 1) * 16]) = ql ? t.al[1] : t.al[0];
+    *reinterpret_cast<u32x4*>(&ash[buf][(q ? RP : 0) + r8][c4]) = q ? t.ah[1] : t.ah[0];
+    *reinterpret_cast<u32x4*>(&ash[buf][(q ? 3 * RP : 2 * RP) + r8][c4]) = q ? t.ah[3] : t.ah[2];
+    *reinterpret_cast<u32x4*>(&asl[buf][(ql ? RPL : 0) + (tid >> 2)][(tid & 1) * 16]) = ql ? t.al[1] : t.al[0];
+    // weight passes come in pairs (2 g, 2 g + 1): the even pass holds this thread's half-0 piece iff q == 0
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      *reinterpret_cast<u32x4*>(&bsh[buf][64 * nb + (q ? 32 : 0) + r8][c4]) = q ? t.bh[2 * nb + 1] : t.bh[2 * nb];
-      *reinterpret_cast<u32x4*>(&bsl[buf][64 * nb + (q ? 32 : 0) + r8][c4]) = q ? t.bl[2 * nb + 1] : t.bl[2 * nb];
+    for (int g = 0; g < NBP / 2; ++g) {
+      *reinterpret_cast<u32x4*>(&bsh[buf][CP * (2 * g) + (q ? CP : 0) + r8][c4]) = q ? t.bh[2 * g + 1] : t.bh[2 * g];
+      *reinterpret_cast<u32x4*>(&bsl[buf][CP * (2 * g) + (q ? CP : 0) + r8][c4]) = q ? t.bl[2 * g + 1] : t.bl[2 * g];
     }
   };
   f32x16 acc[2 * NB];
@@ -787,19 +796,29 @@ int gemm_nn_bf16_splits(int64_t m, int n, int k) {
   int64_t s_max = target / tiles;
   if (s_max > nkt / 4) s_max = nkt / 4;
   if (s_max < 1) s_max = 1;
-  // Cost model in microseconds (rocprofv3 times of the small levels, profiles/r03_small_level_kernels.txt): a block's
-  // k loop is serial at ~0.35 us per 32-k tile; the A stream (~3.5 bytes per element) runs at 4.5 TB/s times the share
-  // of the chip the blocks cover; a split costs the reduction launch (5 us) and its partials written and read back
-  // (~0.5 us per MB and split).  64 splits of a 512 x 256 output spent more on 33 MB of partials than on the GEMM.
+  static const int forced = [] {  // A/B knob: SE3_NN_SPLITS=n forces the split count (clamped to what the shape allows)
+    const char* e = getenv("SE3_NN_SPLITS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return (int)(forced < s_max ? forced : s_max);
+  // Cost model in microseconds, fitted to the stage times of the small and mid-sized levels (profiles/r03_nn_split_sweep.txt:
+  // forced split counts on the 18 k-row headline level and the 4 k-row / 128-channel DFaust level): a block's k loop is
+  // serial at ~0.75 us per 32-k tile (1.1 us with 128-column tiles); the A stream (~3.5 bytes per element) runs at the
+  // rate of the level it comes from -- rows of up to ~200 MB were written by the kernel in front and are still in the
+  // memory-side cache (9 TB/s), larger ones come from HBM (4.5 TB/s) -- times the share of the 512 workgroup slots that
+  // are filled; a split costs its reduction launch (~12 us with the gap in front of it) and the partials written and
+  // read back (~0.5 us per MB and split).  64 splits of a 512 x 256 output spent more on 33 MB of partials than on the
+  // GEMM; 2 or 4 instead of 3 splits of the 18 k-row level cost 10 us each way.
   const double a_bytes = (double)m * k * 3.5, out_bytes = (double)m * n * 4.0;
+  const double t_tile = bnw > BN ? 1.1 : 0.75, rate = a_bytes <= 200e6 ? 9.0e6 : 4.5e6;
   int best = 1;
   double best_cost = 1e30;
   for (int64_t s = 1; s <= s_max; ++s) {
     const int per = (int)((nkt + s - 1) / s);
     const int s_eff = (nkt + per - 1) / per;
-    const double fill = (double)(tiles * s_eff) / 256.0;
-    const double t_loop = per * 0.35, t_stream = a_bytes / (4.5e6 * (fill < 1.0 ? fill : 1.0));
-    const double cost = (t_loop > t_stream ? t_loop : t_stream) + (s_eff > 1 ? 5.0 + s_eff * out_bytes * 0.5e-6 : 0.0);
+    const double fill = (double)(tiles * s_eff) / (double)target;
+    const double t_loop = per * t_tile, t_stream = a_bytes / (rate * (fill < 1.0 ? fill : 1.0));
+    const double cost = (t_loop > t_stream ? t_loop : t_stream) + (s_eff > 1 ? 12.0 + s_eff * out_bytes * 0.5e-6 : 0.0);
     if (cost < best_cost) best_cost = cost, best = s_eff;
   }
   return best;
