@@ -329,16 +329,8 @@ def run_rank(args):
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
-        best_rd = 1e9
-        for _ in range(6):  # read-only: a 1 GiB sum (one pass over a, a scalar out)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            a.sum()
-            e1.record()
-            torch.cuda.synchronize()
-            best_rd = min(best_rd, e0.elapsed_time(e1))
         del a, b
-        return 2 * (1 << 30) / (best * 1e-3) / 1e9, (1 << 30) / (best_rd * 1e-3) / 1e9
+        return 2 * (1 << 30) / (best * 1e-3) / 1e9
 
     launch = "eager" if args.no_graph else "hipGraph replay of the captured step"
     if args.no_graph:
@@ -437,7 +429,7 @@ def run_rank(args):
         # contraction cannot share a CU (the contraction's weight operand is 512 KB of split bf16 against 160 KB of LDS,
         # DESIGN.md 4.6a), so T / U / grad_T cross HBM and this -- not the 8 TB/s roofline on algorithmic bytes -- is the
         # ceiling of the design as built.
-        rate, rate_read = streaming_rate_gbps()
+        rate = streaming_rate_gbps()
         least_stack = 0
         for lv in levels:
             shp_l = _lib.Se3Shape(lv["n"], lv["n"], lv["e"], frames, frames, lv["c"], lv["c"], W.NUM_BASIS,
@@ -448,8 +440,6 @@ def run_rank(args):
         ceil_stack_ms = least_stack / (rate * 1e9) * 1e3
         result["design_ceiling"] = {
             "streaming_rate_GBps": round(rate, 1), "rate_method": "1 GiB device-to-device copy, 2 GiB moved, best of 6 (HIP events)",
-            "read_only_rate_GBps": round(rate_read, 1),
-            "layer_ms_at_read_only_rate": round(sum(moved.values()) / (rate_read * 1e9) * 1e3, 4),
             "layer": {"least_bytes_with_intermediates": sum(moved.values()), "ms": round(ceil_layer_ms, 4),
                       "value": mpts(ceil_layer_ms), "achieved_over_ceiling": round(ceil_layer_ms / ms_layer, 4)},
             "stack": {"least_bytes_with_intermediates": least_stack, "ms": round(ceil_stack_ms, 4),

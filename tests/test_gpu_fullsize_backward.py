@@ -100,7 +100,7 @@ def check_param_grads_masked(amd, pc, nbh, conv, x, g, samples):
     g_m = torch.zeros_like(g)
     rows = rows_of(samples.to(DEV), f)
     g_m[rows] = g[rows]
-    _, _, da, db, dw = gpu_backward(conv, pc, nbh, x, g_m)
+    out_full, _, da, db, dw = gpu_backward(conv, pc, nbh, x, g_m)
     nb = nbh.neighbors_.cpu()
     keep = torch.zeros(pc.pts_.shape[0], dtype=torch.bool)
     keep[samples] = True
@@ -109,6 +109,8 @@ def check_param_grads_masked(amd, pc, nbh, conv, x, g, samples):
     ref = oracle_subproblem(pc, conv, nb_sub, samples, sources, x.cpu()[rows_of(sources, f)], g.cpu()[rows_of(samples, f)])
     for name, u, v in (("dA", da, ref[2]), ("dbeta", db, ref[3]), ("dW", dw, ref[4])):
         assert rel_err(u, v) < tol(amd), (name, rel_err(u, v))
+    # the forward rows of these samples as well: every source with an edge into them is part of the sub-problem
+    assert rel_err(out_full[rows], ref[0]) < tol(amd), ("out rows", rel_err(out_full[rows], ref[0]))
 
 
 def check_directional(amd, pc, nbh, conv, x, g, grads, eps=2e-2, tol_fd=4e-3):
@@ -159,6 +161,22 @@ def test_scannet150k_backward_against_oracle(amd, c_in, c_out):
     pc = amd.pc.PointcloudRotEquiv(pts, torch.zeros(n, dtype=torch.int32, device=DEV),
                                    {"pca": False, "n_frames": 1, "fixed_axis": 2})
     full_checks(amd, pc, 0.12, c_in, c_out, seed=20 + c_in)
+
+
+def test_dfaust_f4_full_bodies_against_oracle(amd):
+    """configs[3] at its stated size: DFaust with F = 4 SO(3) frames, ~6.9 k points per body -- 16 bodies x 6 900 points,
+    the four sign-flipped PCA frames of every point (16-NN), 32 -> 32 channels (441 600 feature rows, ~40 M frame-edges:
+    the single-wavefront C = 32 kernels with two centre frames per wavefront and F_nb = 4).  Forward rows, source slices of
+    dX and masked parameter gradients against the oracle, directional derivatives at full size."""
+    torch.manual_seed(6)
+    bodies, n_per, f = 16, 6900, 4
+    n = bodies * n_per
+    pts = torch.rand(n, 3, device=DEV)
+    bid = torch.arange(bodies, dtype=torch.int32, device=DEV).repeat_interleave(n_per)
+    pc = amd.pc.PointcloudRotEquiv(pts, bid, {"pca": True, "n_frames": f, "fixed_axis": False, "neigh_method": "knn",
+                                              "neigh_kwargs": {"neigh_k": 16}})
+    assert pc.local_frames_.shape == (n, f, 9)
+    full_checks(amd, pc, radius_for_degree(n_per, 24), 32, 32, seed=60)
 
 
 _DFAUST_ORACLE = {}
