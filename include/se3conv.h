@@ -64,10 +64,12 @@ typedef struct se3conv_shape {
   int32_t f_out;   /* frames per output point                               */
   int32_t c_in;    /* input feature channels                                */
   int32_t c_out;   /* output feature channels                               */
-  int32_t num_basis; /* K = p_num_basis; the MFMA kernels implement K == 32 (SE3_ERR_UNSUPPORTED otherwise).  The sum
-                      * over k is separable: other K (the reference's CUDA op takes 8, 16, 32, 64,
-                      * feat_basis_utils.cuh:35-41) are slices of 32 padded with basis functions whose conv weights are
-                      * zero -- the host-side module does exactly that (se3conv3d_amd/layers.py) */
+  int32_t num_basis; /* K = p_num_basis, any K >= 1 (the reference's CUDA op takes 8, 16, 32, 64,
+                      * feat_basis_utils.cuh:35-41).  The MFMA kernels work on 32 basis functions: for K != 32
+                      * se3conv_fwd / se3conv_bwd run ceil(K / 32) slices of 32 -- the sum over k is separable, a short
+                      * slice is padded with basis functions whose axes, bias and conv weights are zero (exact) --
+                      * accumulate the outputs and write every slice's columns of the parameter gradients.  For
+                      * K != 32 `t_save` is neither written nor read (pass NULL): backward recomputes T per slice */
   int32_t precision; /* SE3_PRECISION_*: arithmetic of the contractions (inputs/outputs are fp32)  */
 } se3conv_shape;
 

@@ -436,6 +436,76 @@ struct ForkJoin {
   ~ForkJoin() { (void)join(); }
 };
 
+// ---- any number of basis functions on the K = 32 kernels (se3conv_fwd / se3conv_bwd with num_basis != 32) ---------------
+// The sum over k is separable: K basis functions are ceil(K / 32) slices of 32, the last one padded with basis functions
+// whose projection axes, bias and conv weights are zero (GELU(0) = 0 meets W = 0: exact).  Per slice the padded parameter
+// copies are built in the workspace, the K = 32 operator runs on them, outputs are accumulated and the parameter gradients
+// copied back into their slice of the caller's tensors.  T is not kept between the calls for K != 32 (`t_save` ignored).
+__global__ void slice_params_kernel(const float* __restrict__ axes, const float* __restrict__ biases,
+                                    const float* __restrict__ w, int kb, int k0, int kn, int c_in, int c_out,
+                                    float* __restrict__ a32, float* __restrict__ b32, float* __restrict__ w32) {
+  const int64_t n_w = (int64_t)c_in * kBasis * c_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_w; i += (int64_t)gridDim.x * blockDim.x) {
+    const int o = (int)(i % c_out);
+    const int k = (int)((i / c_out) % kBasis);
+    const int ci = (int)(i / ((int64_t)c_out * kBasis));
+    w32[i] = k < kn ? w[((int64_t)ci * kb + k0 + k) * c_out + o] : 0.f;
+    if (i < SE3_DESC_DIMS * kBasis) {
+      const int j = (int)(i / kBasis), kk = (int)(i % kBasis);
+      a32[i] = kk < kn ? axes[j * kb + k0 + kk] : 0.f;
+    }
+    if (i < kBasis) b32[i] = i < kn ? biases[k0 + i] : 0.f;
+  }
+}
+
+__global__ void unslice_grads_kernel(const float* __restrict__ da32, const float* __restrict__ db32,
+                                     const float* __restrict__ dw32, int kb, int k0, int kn, int c_in, int c_out,
+                                     float* __restrict__ grad_axes, float* __restrict__ grad_biases,
+                                     float* __restrict__ grad_weights) {
+  const int64_t n_w = (int64_t)c_in * kBasis * c_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_w; i += (int64_t)gridDim.x * blockDim.x) {
+    const int o = (int)(i % c_out);
+    const int k = (int)((i / c_out) % kBasis);
+    const int ci = (int)(i / ((int64_t)c_out * kBasis));
+    if (grad_weights && k < kn) grad_weights[((int64_t)ci * kb + k0 + k) * c_out + o] = dw32[i];
+    if (grad_axes && i < SE3_DESC_DIMS * kBasis) {
+      const int j = (int)(i / kBasis), kk = (int)(i % kBasis);
+      if (kk < kn) grad_axes[j * kb + k0 + kk] = da32[i];
+    }
+    if (grad_biases && i < kn) grad_biases[k0 + i] = db32[i];
+  }
+}
+
+__global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+struct AnyBasisLayout { size_t a32, b32, w32, out_tmp, da32, db32, dw32, inner, total; int slices; };
+AnyBasisLayout any_basis_layout(const se3conv_shape* s, size_t out_tmp_bytes, bool grads, size_t inner_bytes) {
+  AnyBasisLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t wsz = (size_t)s->c_in * kBasis * s->c_out * 4;
+  l.slices = (s->num_basis + kBasis - 1) / kBasis;
+  l.a32 = take(SE3_DESC_DIMS * kBasis * 4);
+  l.b32 = take(kBasis * 4);
+  l.w32 = take(wsz);
+  l.out_tmp = take(l.slices > 1 ? out_tmp_bytes : 0);
+  if (grads) {
+    l.da32 = take(SE3_DESC_DIMS * kBasis * 4);
+    l.db32 = take(kBasis * 4);
+    l.dw32 = take(wsz);
+  }
+  l.inner = take(inner_bytes);
+  l.total = off;
+  return l;
+}
+se3conv_shape with_32_basis(const se3conv_shape* s) {
+  se3conv_shape t = *s;
+  t.num_basis = kBasis;
+  return t;
+}
+
 EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
                       const int32_t* neighbors, const int32_t* ends, const se3conv_shape* s) {
   EdgeGeom g{};
@@ -457,7 +527,7 @@ extern "C" const char* se3_error_string(int code) {
   switch (code) {
     case SE3_OK: return "ok";
     case SE3_ERR_INVALID_ARGUMENT: return "invalid argument (null pointer, negative size or bad shape)";
-    case SE3_ERR_UNSUPPORTED: return "unsupported shape (the MFMA kernels need num_basis == 32 and int32-sized clouds)";
+    case SE3_ERR_UNSUPPORTED: return "unsupported shape (int32-sized clouds; API-parity ops: K in {8, 16, 32, 64})";
     case SE3_ERR_WORKSPACE: return "workspace too small";
     case SE3_ERR_LAUNCH: return "HIP launch/runtime error";
     default: return "unknown error";
@@ -557,7 +627,12 @@ extern "C" int se3conv_intermediate_bytes_per_element(const se3conv_shape* s, in
 }
 
 extern "C" size_t se3conv_fwd_workspace_bytes(const se3conv_shape* s, int save_t) {
-  return shape_ok(s) ? fwd_layout(s, save_t).total : 0;
+  if (!shape_ok(s)) return 0;
+  if (s->num_basis != kBasis) {
+    const se3conv_shape s32 = with_32_basis(s);
+    return any_basis_layout(s, (size_t)s->n_out * s->f_out * s->c_out * 4, false, fwd_layout(&s32, 0).total).total;
+  }
+  return fwd_layout(s, save_t).total;
 }
 
 extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
@@ -566,6 +641,30 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
                            const se3conv_shape* s, float* out, float* t_save, void* workspace, size_t workspace_bytes,
                            void* stream_) {
   if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->num_basis != kBasis) {
+    // slices of 32 basis functions on the K = 32 operator (see slice_params_kernel); t_save is not written
+    if (s->n_out == 0) return SE3_OK;
+    if (!proj_axes || !proj_biases || !conv_weights || !out || !workspace) return SE3_ERR_INVALID_ARGUMENT;
+    const se3conv_shape s32 = with_32_basis(s);
+    const int64_t n_out_el = s->n_out * s->f_out * s->c_out;
+    const AnyBasisLayout l = any_basis_layout(s, (size_t)n_out_el * 4, false, fwd_layout(&s32, 0).total);
+    if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float *a32 = (float*)(ws + l.a32), *b32 = (float*)(ws + l.b32), *w32 = (float*)(ws + l.w32);
+    for (int sl = 0; sl < l.slices; ++sl) {
+      const int k0 = sl * kBasis, kn = s->num_basis - k0 < kBasis ? s->num_basis - k0 : kBasis;
+      hipLaunchKernelGGL(slice_params_kernel, dim3(grid_for((int64_t)s->c_in * kBasis * s->c_out)), dim3(256), 0, stream,
+                         proj_axes, proj_biases, conv_weights, s->num_basis, k0, kn, s->c_in, s->c_out, a32, b32, w32);
+      float* dst = sl == 0 ? out : (float*)(ws + l.out_tmp);
+      if (int rc = se3conv_fwd(pts_in, pts_out, frames_in, frames_out, neighbors, ends, feat, a32, b32, w32, rho, nu, &s32, dst,
+                               nullptr, ws + l.inner, l.total - l.inner, stream_))
+        return rc;
+      if (sl > 0)
+        hipLaunchKernelGGL(add_into_kernel, dim3(grid_for(n_out_el)), dim3(256), 0, stream, out, dst, n_out_el);
+    }
+    return check_launch();
+  }
   if (int rc = shape_supported(s)) return rc;
   if (s->n_out == 0) return SE3_OK;
   if (!pts_out || !frames_out || !ends || !proj_axes || !proj_biases || !conv_weights || !rho || !nu || !out ||
@@ -616,7 +715,13 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
 }
 
 extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
-  return shape_ok(s) ? bwd_layout(s, want_feat, want_params, have_t).total : 0;
+  if (!shape_ok(s)) return 0;
+  if (s->num_basis != kBasis) {
+    const se3conv_shape s32 = with_32_basis(s);
+    return any_basis_layout(s, want_feat ? (size_t)s->n_in * s->f_in * s->c_in * 4 : 0, want_params != 0,
+                            bwd_layout(&s32, want_feat, want_params, 0).total).total;
+  }
+  return bwd_layout(s, want_feat, want_params, have_t).total;
 }
 
 extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
@@ -627,6 +732,38 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                            float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
                            void* stream_) {
   if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->num_basis != kBasis) {
+    // slices of 32 basis functions (see slice_params_kernel): T is recomputed per slice (t_save ignored), dX is the sum of
+    // the slices' feature gradients, every slice writes its own columns of the parameter gradients
+    const bool wf = grad_feat != nullptr, wp = grad_axes || grad_biases || grad_weights;
+    if (!wf && !wp) return SE3_OK;
+    if (!proj_axes || !proj_biases || !conv_weights || !workspace) return SE3_ERR_INVALID_ARGUMENT;
+    const se3conv_shape s32 = with_32_basis(s);
+    const int64_t n_in_el = s->n_in * s->f_in * s->c_in;
+    const AnyBasisLayout l = any_basis_layout(s, wf ? (size_t)n_in_el * 4 : 0, wp, bwd_layout(&s32, wf, wp, 0).total);
+    if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float *a32 = (float*)(ws + l.a32), *b32 = (float*)(ws + l.b32), *w32 = (float*)(ws + l.w32);
+    float *da32 = wp ? (float*)(ws + l.da32) : nullptr, *db32 = wp ? (float*)(ws + l.db32) : nullptr;
+    float* dw32 = wp ? (float*)(ws + l.dw32) : nullptr;
+    const dim3 pgrid(grid_for((int64_t)s->c_in * kBasis * s->c_out));
+    for (int sl = 0; sl < l.slices; ++sl) {
+      const int k0 = sl * kBasis, kn = s->num_basis - k0 < kBasis ? s->num_basis - k0 : kBasis;
+      hipLaunchKernelGGL(slice_params_kernel, pgrid, dim3(256), 0, stream, proj_axes, proj_biases, conv_weights,
+                         s->num_basis, k0, kn, s->c_in, s->c_out, a32, b32, w32);
+      float* dx = !wf ? nullptr : (sl == 0 ? grad_feat : (float*)(ws + l.out_tmp));
+      if (int rc = se3conv_bwd(pts_in, pts_out, frames_in, frames_out, neighbors, ends, t_samples, t_ends, feat, a32, b32, w32, rho,
+                               nu, nullptr, grad_out, &s32, dx, da32, db32, dw32, ws + l.inner, l.total - l.inner, stream_))
+        return rc;
+      if (wf && sl > 0 && n_in_el > 0)
+        hipLaunchKernelGGL(add_into_kernel, dim3(grid_for(n_in_el)), dim3(256), 0, stream, grad_feat, dx, n_in_el);
+      if (wp)
+        hipLaunchKernelGGL(unslice_grads_kernel, pgrid, dim3(256), 0, stream, da32, db32, dw32, s->num_basis, k0, kn, s->c_in,
+                           s->c_out, grad_axes, grad_biases, grad_weights);
+    }
+    return check_launch();
+  }
   if (int rc = shape_supported(s)) return rc;
   const bool want_feat = grad_feat != nullptr;
   const bool want_params = grad_axes || grad_biases || grad_weights;

@@ -147,29 +147,12 @@ def _conv_materialised(feat, axes, biases, weights, geom, rho, nu, act, rel_rot=
 
 
 _REL_ROT_DIMS = {"6D": 9, "matrix": 12, "quaternion": 7}  # p_rel_rot -> p_dims (RotationFunctions.py:593-600)
-_KB = 32  # basis functions per call of the MFMA operator (include/se3conv.h: num_basis == 32)
-
-
 def _conv_any_num_basis(feat, axes, biases, weights, geom, rho, nu):
-    """The operator for any number of basis functions K on the K = 32 kernels.  The sum over k is separable, so
-    K > 32 is the sum of the operator over slices of 32 basis functions, and a slice shorter than 32 is padded with
-    basis functions whose conv weights are zero (their value GELU(beta_k) is multiplied by W[:, k, :] = 0: exact).
-    The reference's CUDA op accepts K in {8, 16, 32, 64} (feat_basis_utils.cuh:35-41); every shipped configuration
-    uses 32.  Gradients flow through the slicing / padding by autograd (zero rows and columns drop out)."""
-    k = axes.shape[1]
-    if k == _KB:
-        return ops.SE3ConvFunction.apply(feat, axes, biases, weights, geom, rho, nu)
-    out = None
-    for k0 in range(0, k, _KB):
-        a, b, w = axes[:, k0:k0 + _KB], biases[k0:k0 + _KB], weights[:, k0:k0 + _KB, :]
-        pad = _KB - a.shape[1]
-        if pad:
-            a = torch.cat([a, a.new_zeros((a.shape[0], pad))], dim=1)
-            b = torch.cat([b, b.new_zeros((pad,))], dim=0)
-            w = torch.cat([w, w.new_zeros((w.shape[0], pad, w.shape[2]))], dim=1)
-        part = ops.SE3ConvFunction.apply(feat, a.contiguous(), b.contiguous(), w.contiguous(), geom, rho, nu)
-        out = part if out is None else out + part
-    return out
+    """The fused operator for any number of basis functions K.  The MFMA kernels work on 32 basis functions; the library
+    itself runs other K as slices of 32 (the sum over k is separable; a short slice is padded with basis functions whose
+    conv weights are zero: exact) -- `se3conv_fwd` / `se3conv_bwd` with `num_basis != 32`, include/se3conv.h.  The
+    reference's CUDA op accepts K in {8, 16, 32, 64} (feat_basis_utils.cuh:35-41); every shipped configuration uses 32."""
+    return ops.SE3ConvFunction.apply(feat, axes, biases, weights, geom, rho, nu)
 
 
 class PNEConvLayerRotEquiv(IConvLayer):

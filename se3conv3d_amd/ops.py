@@ -664,7 +664,9 @@ def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weigh
     shp = geom.shape(c_in, c_out, kb, precision)
     rows = geom.pts_out.shape[0] * geom.frames_out.shape[1]
     out = torch.empty((rows, c_out), dtype=f32, device=dev)
-    t_save = torch.empty((rows, c_in, kb), dtype=f32, device=dev) if save_t else None
+    # T is kept for the weight gradient only on the K = 32 kernels' own layout; other K run as slices of 32 inside the
+    # library, which recomputes T in backward (include/se3conv.h)
+    t_save = torch.empty((rows, c_in, kb), dtype=f32, device=dev) if (save_t and kb == 32) else None
     ws = _workspace(lib.se3conv_fwd_workspace_bytes(C.byref(shp), 1 if save_t else 0), dev)
     rho_t, nu_t = _scalar(rho, "rho", dev), _scalar(nu, "nu", dev)
     _lib.check(lib.se3conv_fwd(*_geom_ptrs(geom), _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),

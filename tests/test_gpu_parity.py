@@ -546,11 +546,45 @@ def test_symmetric_neighbourhood_needs_no_transposed_copy(amd):
 
 
 
+@pytest.mark.parametrize("kb", [8, 40, 70])
+def test_other_basis_counts_at_the_c_abi(amd, kb):
+    """se3conv_fwd / se3conv_bwd with num_basis != 32 called directly (no module, no autograd in between): one, two and
+    three slices of 32 inside the library; a two-cloud geometry, gradients requested separately and together."""
+    from se3conv3d_amd import ops
+
+    g = torch.Generator().manual_seed(100 + kb)
+    n_in, n_out, f_in, f_out, c_in, c_out = 700, 260, 2, 1, 24, 40
+    pts_in, pts_out = torch.rand(n_in, 3, generator=g), torch.rand(n_out, 3, generator=g)
+    bi, bo = torch.zeros(n_in, dtype=torch.int32), torch.zeros(n_out, dtype=torch.int32)
+    fr_in, fr_out = O.random_frames(n_in, f_in, g), O.random_frames(n_out, f_out, g)
+    r = O.radius_for_degree(n_in, 18)
+    nb_ref, ends_ref = O.ball_query(pts_in, pts_out, bi, bo, r)
+    a, b, w = O.init_parameters(9, c_in, c_out, kb, g)
+    b = torch.rand(kb, generator=g) - 0.5
+    x = torch.randn(n_in * f_in, c_in, generator=g)
+    go = torch.randn(n_out * f_out, c_out, generator=g)
+    rho, nu = torch.tensor(1.0 / r), torch.tensor(n_out / nb_ref.shape[0])
+    ref = O.conv_forward_backward(pts_in, pts_out, fr_in, fr_out, nb_ref, x, a, b, w, rho, nu, go)
+    d = lambda t: t.to(DEV)
+    geom = ops.ConvGeometry.build(d(pts_in), d(pts_out), d(fr_in), d(fr_out), d(nb_ref.to(torch.int32)), d(ends_ref))
+    out, t_save = ops.se3conv_forward(geom, d(x), d(a), d(b), d(w), rho, nu, save_t=True)
+    assert t_save is None                      # T is only kept on the K = 32 layout
+    assert rel_err(out, ref[0]) < tol(amd)
+    dx, da, db, dw = ops.se3conv_backward(geom, d(x), d(a), d(b), d(w), rho, nu, None, d(go))
+    assert da.shape == (9, kb) and db.shape == (kb,) and dw.shape == (c_in, kb, c_out)
+    for name, u, v in zip(("dX", "dA", "dbeta", "dW"), (dx, da, db, dw), ref[1:]):
+        assert rel_err(u, v) < tol(amd), (kb, name, rel_err(u, v))
+    dx2, none_a, _, _ = ops.se3conv_backward(geom, d(x), d(a), d(b), d(w), rho, nu, None, d(go), want_params=False)
+    assert none_a is None and torch.equal(dx2, dx)
+    _, da2, db2, dw2 = ops.se3conv_backward(geom, d(x), d(a), d(b), d(w), rho, nu, None, d(go), want_feat=False)
+    assert torch.equal(da2, da) and torch.equal(db2, db) and torch.equal(dw2, dw)
+
+
 @pytest.mark.parametrize("kb", [8, 16, 64, 40])
 def test_other_basis_counts_against_oracle(amd, kb):
-    """K in {8, 16, 64} (the set of the reference's CUDA op, feat_basis_utils.cuh:35-41) and an odd one: the module runs
-    them as zero-padded / summed slices of 32 basis functions on the K = 32 kernels -- output and all gradients against
-    the oracle evaluated with the true K."""
+    """K in {8, 16, 64} (the set of the reference's CUDA op, feat_basis_utils.cuh:35-41) and an odd one, through the module:
+    the library runs them as zero-padded / summed slices of 32 basis functions on the K = 32 kernels -- output and all
+    gradients against the oracle evaluated with the true K."""
     g = torch.Generator().manual_seed(kb)
     n, f, c_in, c_out = 500, 2, 64, 48
     pts = torch.rand(n, 3, generator=g)
