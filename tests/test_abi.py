@@ -45,8 +45,12 @@ def test_host_side_argument_checks(built_library):
     assert lib.se3_ball_query_count(null, null, null, null, null, null, 0.0, 1, 1, null, 0, null, null) == -1
     bad = _lib.Se3Shape(10, 10, 10, 0, 1, 8, 8, 32)  # f_in = 0
     assert lib.se3conv_fwd_workspace_bytes(C.byref(bad), 1) == 0
-    k16 = _lib.Se3Shape(10, 10, 10, 1, 1, 8, 8, 16)  # K != 32 -> unsupported by the MFMA kernels
-    args = [null] * 12 + [C.byref(k16), null, null, null, 0, null]
+    k16 = _lib.Se3Shape(10, 10, 10, 1, 1, 8, 8, 16)  # K != 32: slices of 32 inside the library -- a valid shape,
+    args = [null] * 12 + [C.byref(k16), null, null, null, 0, null]  # null arguments are what is wrong here
+    assert lib.se3conv_fwd(*args) == -1
+    assert lib.se3conv_fwd_workspace_bytes(C.byref(k16), 1) > 0 and lib.se3conv_bwd_workspace_bytes(C.byref(k16), 1, 1, 0) > 0
+    huge = _lib.Se3Shape(1 << 31, 10, 10, 2, 1, 8, 8, 32)  # row ids are int32 inside the kernels
+    args = [C.c_void_p(16)] * 12 + [C.byref(huge), C.c_void_p(16), null, C.c_void_p(16), 1 << 62, null]
     assert lib.se3conv_fwd(*args) == -2
     assert lib.se3_feat_basis_proj(null, null, null, null, 0, 0, 0, 8, 12, null, null) == -2
     assert b"workspace" in lib.se3_error_string(-3)
