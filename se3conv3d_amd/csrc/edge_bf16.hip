@@ -1019,7 +1019,15 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       const char* e = getenv("SE3_PG_PAIR");
       return e == nullptr || atoi(e) != 0;
     }();
-    if (pair_on && two && channels >= 64) {
+    // 32-channel rows (DFaust's first level) take the pair form too, with half the grad_T image (CH16 = 2): 0.258 against
+    // 0.284 ms on the DFaust F = 2 batch (profiles/r03_c32_pair_forms_ab.txt); SE3_PG_PAIR_C32=0 keeps the 512-thread form.
+    // (The same idea for the edge_t kernel -- a split-K wave pair for 32-channel rows -- measured 7-10 % SLOWER than the
+    // single-wavefront kernel and is not kept, same file.)
+    static const bool pair32_on = [] {
+      const char* e = getenv("SE3_PG_PAIR_C32");
+      return e == nullptr || atoi(e) != 0;
+    }();
+    if (pair_on && two && (channels >= 64 || (channels == 32 && pair32_on))) {
       static int n_cu = 0;
       if (n_cu == 0) {
         int dev = 0;
@@ -1037,7 +1045,13 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       if (wgs < 1) wgs = 1;
       *n_used = (int)wgs * blocks_y;
       const dim3 pgrid((unsigned)wgs, (unsigned)blocks_y);
-      if (shift >= 0)
+      if (channels == 32 && shift >= 0)
+        hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<2, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
+                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+      else if (channels == 32)
+        hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<2, 2, true, false>), pgrid, dim3(128), 0, stream, g, feat, channels,
+                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+      else if (shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
                            feat_rows, axes_ext, rho, grad_t, partials, items, shift);
       else
