@@ -605,11 +605,11 @@ extern "C" int se3_feat_basis_proj_grad(const float* basis, const float* feat, c
 }
 
 // The row-sized intermediates (T, and U of the feature gradient) are kept in the 3-byte row format of common.h when
-// the wave-pair edge kernel produces them and the buffer-load GEMMs consume them (SE3_NO_T24=1: packed words
+// the edge kernel can produce them (edge_t_bf16_t24_rows) and the buffer-load GEMMs consume them (SE3_NO_T24=1: packed words
 // everywhere).  tn_cols = the column count of the TN product that also reads the rows (0: none).
 static bool t24_rows(const EdgeGeom& g, int channels, int64_t rows, int tn_cols) {
   static const bool on = getenv("SE3_NO_T24") == nullptr;
-  return on && kBasis == 32 && channels % 2 == 0 && edge_t_bf16_row_ranges(g, channels) &&
+  return on && kBasis == 32 && channels % 2 == 0 && edge_t_bf16_t24_rows(g, channels) &&
          2 * rows * (int64_t)channels * kBasis * 4 < (1ll << 32) - 64 && tn_cols % 4 == 0 &&
          2 * rows * (int64_t)(tn_cols > 0 ? tn_cols : 1) * 4 < (1ll << 32) - 64;
 }

@@ -335,6 +335,7 @@ struct ReduceBatch {
 // split-bf16 path (edge_bf16.hip, gemm_bf16.hip)
 int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream);
 bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels);
+bool edge_t_bf16_t24_rows(const EdgeGeom& g, int channels);
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream,
                        int64_t row_lo = -1, int64_t row_hi = -1, bool t24 = false);

@@ -96,28 +96,56 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], int
 // VALU is the bound of this kernel (MFMA ~15 % busy), so everything here is about instruction count:
 // 32-bit buffer addressing, ds_bpermute for the per-row source offsets, branch-free GELU.
 // ------------------------------------------------------------------------------------------------
-template <int VW, int FC, bool FULL>
-__global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
+#ifndef SE3_ITEM_WAVES
+#define SE3_ITEM_WAVES 2
+#endif
+template <int VW, int FC, bool FULL, bool T24 = false>
+__global__ __launch_bounds__(256, FC == 1 ? 3 : (VW == 1 ? SE3_ITEM_WAVES : 2)) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
                                                              int64_t feat_rows, const float* __restrict__ axes_ext,
                                                              const float* __restrict__ rho_p,
                                                              uint32_t* __restrict__ t_out, int64_t n_items,
                                                              int fnb_shift) {
+  static_assert(!T24 || VW == 1, "3-byte rows need adjacent channels in accumulator registers r, r + 1");
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
   if (threadIdx.x < 64) mlp_weights_to_lds<FC>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
   const int64_t item = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (item >= n_items) return;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * channels * 4);
-  uint32_t* t_rows = t_out + item * FC * (int64_t)channels * kBasis;  // rows FC*item .. FC*item + FC-1
   const int row_words = channels * kBasis;
-  edge_item_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, item, fnb_shift,
-                               [&](int a, int off, uint32_t w) {
+  const int kcol = threadIdx.x & 31;
+  if constexpr (T24) {  // 3-byte rows (common.h): channels ch0, ch0 + 1 of this lane = one hi word + one lo half-word
+    char* rows = reinterpret_cast<char*>(t_out) + item * FC * t24_row_bytes(channels);
+    edge_item_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, item, fnb_shift,
+                                 [&](int a, int ch0, int, float x0, float x1, bool ok0, bool ok1) {
+                                   if (!ok0) return;  // channels is even and ch0 is: ok1 == ok0
+                                   uint32_t hp, lp;
+                                   t24_pack2(x0, ok1 ? x1 : 0.f, hp, lp);
+                                   char* row = rows + a * t24_row_bytes(channels);
+                                   const int idx = (ch0 >> 1) * kBasis + kcol;
 #if SE3_NT_STORES
-                                 __builtin_nontemporal_store(w, &t_rows[a * row_words + off]);
+                                   __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
+                                   __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)row_words * 2) + idx);
 #else
-                                 t_rows[a * row_words + off] = w;
+                                   reinterpret_cast<uint32_t*>(row)[idx] = hp;
+                                   reinterpret_cast<uint16_t*>(row + (int64_t)row_words * 2)[idx] = (uint16_t)lp;
 #endif
-                               });
+                                 });
+  } else {
+    uint32_t* t_rows = t_out + item * FC * (int64_t)channels * kBasis;  // rows FC*item .. FC*item + FC-1
+    edge_item_bf16<VW, FC, FULL>(g, feat_rs, channels, lds_w, *rho_p, item, fnb_shift,
+                                 [&](int a, int ch0, int ch1, float x0, float x1, bool ok0, bool ok1) {
+                                   uint32_t w0, w1;
+                                   split_pack2(x0, x1, w0, w1);
+#if SE3_NT_STORES
+                                   if (ok0) __builtin_nontemporal_store(w0, &t_rows[a * row_words + ch0 * kBasis + kcol]);
+                                   if (ok1) __builtin_nontemporal_store(w1, &t_rows[a * row_words + ch1 * kBasis + kcol]);
+#else
+                                   if (ok0) t_rows[a * row_words + ch0 * kBasis + kcol] = w0;
+                                   if (ok1) t_rows[a * row_words + ch1 * kBasis + kcol] = w1;
+#endif
+                                 });
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -138,7 +166,7 @@ __global__ __launch_bounds__(256, FC == 1 ? 3 : 2) void edge_t_bf16_kernel(EdgeG
                          // 16 no geometry gathers / descriptor / descriptor split (upper bound of what a descriptor stash written by the forward could save)
 #endif
 #ifndef SE3_PAIR_ABLATE
-#define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi
+#define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi, 64 no barrier between the partner wavefronts
 #endif
 #ifndef SE3_PAIR_PIN
 #define SE3_PAIR_PIN 1  // centre record passed through an empty asm at the top of every chunk: nothing derived from it is hoisted out
@@ -307,7 +335,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
           }
         }
       }
-      __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
+      if (!(SE3_PAIR_ABLATE & 64)) __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s * 16 < cnt) {
@@ -917,6 +945,13 @@ bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels) {
   return channels >= 64 && getenv("SE3_NO_PAIR") == nullptr;
 }
 
+// Which launches can write their rows in the 3-byte format: the wave-pair kernel, and the single-wavefront kernel at
+// one channel per lane (rows of up to 32 channels, DFaust's first level), whose accumulator registers r, r + 1 are
+// adjacent channels
+bool edge_t_bf16_t24_rows(const EdgeGeom& g, int channels) {
+  return channels % 2 == 0 && (edge_t_bf16_row_ranges(g, channels) || channels <= 32);
+}
+
 // row_lo / row_hi (multiples of 2 for even F; < 0: everything): only the rows in that range are produced -- the
 // wave-pair kernel supports it (edge_t_bf16_row_ranges), which lets the caller interleave producer and consumer
 // launches over slices of the rows
@@ -925,8 +960,8 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
                        int64_t row_hi, bool t24) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (rows == 0) return SE3_OK;
-  if ((row_lo >= 0 || t24) && !edge_t_bf16_row_ranges(g, channels)) return SE3_ERR_UNSUPPORTED;
-  if (t24 && channels % 2 != 0) return SE3_ERR_UNSUPPORTED;
+  if (row_lo >= 0 && !edge_t_bf16_row_ranges(g, channels)) return SE3_ERR_UNSUPPORTED;
+  if (t24 && !edge_t_bf16_t24_rows(g, channels)) return SE3_ERR_UNSUPPORTED;
   // 32-bit byte offsets into the gathered operand; kOobOffset must lie beyond it
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
@@ -978,18 +1013,24 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     return check_launch();
   }
   const dim3 grid((unsigned)((items + 3) / 4));
-#define SE3_LAUNCH(VW, FC, FULL)                                                                                      \
-  hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL>), grid, block, 0, stream, g, feat, channels, feat_rows,          \
+#define SE3_LAUNCH(VW, FC, FULL, T24)                                                                                 \
+  hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL, T24>), grid, block, 0, stream, g, feat, channels, feat_rows,     \
                      axes_ext, rho, t_out, items, shift)
+#define SE3_LAUNCH1(FC, FULL)                        \
+  do {                                               \
+    if (t24) SE3_LAUNCH(1, FC, FULL, true);          \
+    else SE3_LAUNCH(1, FC, FULL, false);             \
+  } while (0)
   if (channels % 128 == 0) {
-    SE3_LAUNCH(4, 1, true);
+    SE3_LAUNCH(4, 1, true, false);
   } else if (channels % 64 == 0) {
-    if (fc == 2) SE3_LAUNCH(2, 2, true); else SE3_LAUNCH(2, 1, true);
+    if (fc == 2) SE3_LAUNCH(2, 2, true, false); else SE3_LAUNCH(2, 1, true, false);
   } else if (channels % 32 == 0) {
-    if (fc == 2) SE3_LAUNCH(1, 2, true); else SE3_LAUNCH(1, 1, true);
+    if (fc == 2) SE3_LAUNCH1(2, true); else SE3_LAUNCH1(1, true);
   } else {
-    if (fc == 2) SE3_LAUNCH(1, 2, false); else SE3_LAUNCH(1, 1, false);
+    if (fc == 2) SE3_LAUNCH1(2, false); else SE3_LAUNCH1(1, false);
   }
+#undef SE3_LAUNCH1
 #undef SE3_LAUNCH
   return check_launch();
 }

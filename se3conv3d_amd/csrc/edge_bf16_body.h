@@ -61,8 +61,8 @@ __device__ __forceinline__ void mlp_weights_to_lds(uint32_t (*lds_w)[2][64][4], 
   }
 }
 
-// One item = FC frames of one centre point.  sink(a, offset_in_row, word) receives every packed word of
-// row (ctr*f_ctr + a0 + a): offset_in_row = channel*32 + k.
+// One item = FC frames of one centre point.  sink(a, ch0, ch1, x0, x1, ok0, ok1) receives the values of row
+// (ctr*f_ctr + a0 + a), channels ch0 / ch1 (ch1 = ch0 + VW), basis function k = lane & 31, and packs / stores them.
 template <int VW, int FC, bool FULL, class Sink>
 __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu_buffer_rsrc_t feat_rs, int channels,
                                                const uint32_t (*lds_w)[2][64][4], float rho, int64_t item,
@@ -227,7 +227,8 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
         }
       }
     }
-    // acc[a][t] register r, lane (kcol, h) = T[row a][cbase + VW*acc_row(r,h) + t][kcol]
+    // acc[a][t] register r, lane (kcol, h) = T[row a][cbase + VW*acc_row(r,h) + t][kcol]; registers r, r + 1 (r even) are
+    // channels ch0 and ch0 + VW: with VW = 1 an adjacent pair, which is what the 3-byte row format stores together
 #pragma unroll
     for (int a = 0; a < FC; ++a)
 #pragma unroll
@@ -235,14 +236,11 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
-          uint32_t w0, w1;
-          split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
 #if SE3_ABLATE_MASK & 8
-          asm volatile("" ::"v"(w0), "v"(w1));
-          if (w0 == 0x12345678u) sink(a, ch0 * kBasis + kcol, w0);
+          asm volatile("" ::"v"(acc[a][t][r]), "v"(acc[a][t][r + 1]));
+          if (__float_as_uint(acc[a][t][r]) == 0x12345678u) sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], true, true);
 #else
-          if (FULL || ch0 < channels) sink(a, ch0 * kBasis + kcol, w0);
-          if (FULL || ch1 < channels) sink(a, ch1 * kBasis + kcol, w1);
+          sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], FULL || ch0 < channels, FULL || ch1 < channels);
 #endif
         }
   }

@@ -70,8 +70,10 @@ def test_intermediate_format_query(built_library):
     assert [q(headline, w) for w in range(3)] == [3, 3, 4]
     exact = _lib.Se3Shape(65536, 65536, 2_000_000, 2, 2, 64, 64, 32, _lib.PRECISIONS["fp32"])
     assert [q(exact, w) for w in range(3)] == [4, 4, 4]
-    narrow = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 32, 32, 32, _lib.PRECISIONS["bf16x3"])  # below the wave-pair kernel's width
-    assert [q(narrow, w) for w in range(3)] == [4, 4, 4]
+    narrow = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 32, 32, 32, _lib.PRECISIONS["bf16x3"])  # single-wavefront kernel, one channel per lane
+    assert [q(narrow, w) for w in range(3)] == [3, 3, 4]
+    between = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 48, 48, 32, _lib.PRECISIONS["bf16x3"])  # two channels per lane: packed words
+    assert [q(between, w) for w in range(3)] == [4, 4, 4]
     assert q(headline, 3) < 0 and q(_lib.Se3Shape(10, 10, 10, 0, 1, 8, 8, 32, 1), 0) < 0
 
 
