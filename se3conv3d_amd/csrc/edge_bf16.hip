@@ -100,7 +100,7 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], int
 #define SE3_ITEM_WAVES 2
 #endif
 template <int VW, int FC, bool FULL, bool T24 = false>
-__global__ __launch_bounds__(256, FC == 1 ? 3 : (VW == 1 ? SE3_ITEM_WAVES : 2)) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
+__global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : (VW == 1 ? SE3_ITEM_WAVES : 2))) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
                                                              int64_t feat_rows, const float* __restrict__ axes_ext,
                                                              const float* __restrict__ rho_p,
                                                              uint32_t* __restrict__ t_out, int64_t n_items,

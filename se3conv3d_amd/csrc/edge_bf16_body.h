@@ -93,19 +93,16 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 #pragma unroll
       for (int t = 0; t < VW; ++t) acc[a][t] = zero16();
 
-    // frame-edge -> (neighbour id, source row): lane n of both halves handles frame-edge c0 + n
-    auto edge_of = [&](int c0, int& nb, int& q) {
+    // frame-edge -> neighbour id / source row: lane n of both halves handles frame-edge c0 + n (indices past the end
+    // clamp to the last one)
+    auto nbr_of = [&](int c0) {
       const int fe = min(c0 + kcol, n_total - 1);
-      int e, fn;
-      if (fnb_shift >= 0) {
-        e = start + (fe >> fnb_shift);
-        fn = fe & ((1 << fnb_shift) - 1);
-      } else {
-        e = start + fe / g.f_nb;
-        fn = fe % g.f_nb;
-      }
-      nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-      q = nb * g.f_nb + fn;
+      const int e = start + (fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+      return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+    };
+    auto row_of = [&](int nb, int c0) {
+      const int fe = min(c0 + kcol, n_total - 1);
+      return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
     };
     auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
 #if SE3_ABLATE_MASK & 4
@@ -117,25 +114,63 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
       load_geom_record(nbg_rs, q, xn, rn);
 #endif
     };
-    // software pipeline: the neighbour ids and geometry of chunk c0+32 are fetched while chunk c0 computes
-    int nb_nx = 0, q_nx = 0;
+    // Software pipeline (as in the wave-pair kernel): neighbour ids are fetched two chunks ahead and geometry records
+    // one chunk ahead, and the chunk's own feature words go out at its top and are only turned into MFMA fragments
+    // where the first product needs them -- no load result is needed by the instructions right behind the load (the
+    // first version converted the words where they were loaded: one full memory latency per k-step with nothing of
+    // this wavefront to overlap it).
+    int nb_b = 0, q_a = 0;
     float xn_nx[3], rn_nx[9];
     if (n_total > 0) {
-      edge_of(0, nb_nx, q_nx);
-      geom_of(nb_nx, q_nx, xn_nx, rn_nx);
+      const int nb_a = nbr_of(0);
+      nb_b = nbr_of(32);
+      q_a = row_of(nb_a, 0);
+      geom_of(nb_a, q_a, xn_nx, rn_nx);
     }
     for (int c0 = 0; c0 < n_total; c0 += 32) {
       const int cnt = min(32, n_total - c0);
-      const int q = q_nx;
       // rows past the end of the edge list are read out of bounds (raw buffer loads return 0), so phi needs no mask
-      const int qoff = c0 + kcol < n_total ? q * row_bytes : kOobOffset;
+      const int qoff = c0 + kcol < n_total ? q_a * row_bytes : kOobOffset;
       float xn[3], rn[9], d[9];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
 #pragma unroll
       for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
-      const bool more = c0 + 32 < n_total;  // wave-uniform
-      if (more) edge_of(c0 + 32, nb_nx, q_nx);
+      const int q_b = row_of(nb_b, c0 + 32);
+      const int nb_q = nb_b;
+      nb_b = nbr_of(c0 + 64);
+
+      // gathered feature words of the chunk's two k-steps (shared by the FC rows)
+      uint32_t fw[2][VW][8];
+      // (no branch around the second k-step's loads: a conditional load makes every counted s_waitcnt behind it assume
+      // the loads were not issued, i.e. wait for all of them; past the end of the list they read out of bounds)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // byte offset of the source row of frame-edge acc_row(8s+j, h), fetched from the lane that owns it
+          const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+          const int voff = ch_ok ? src_off + cb4 : kOobOffset;
+#if SE3_ABLATE_MASK & 2
+          if constexpr (VW >= 1) {
+#pragma unroll
+            for (int t = 0; t < VW; ++t) fw[s][t][j] = (uint32_t)voff * 2654435761u + t;
+          } else
+#endif
+          if constexpr (VW == 4) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
+            fw[s][0][j] = v[0], fw[s][1][j] = v[1], fw[s][2][j] = v[2], fw[s][3][j] = v[3];
+          } else if constexpr (VW == 2) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(feat_rs, voff, 0, 0);
+            fw[s][0][j] = v[0], fw[s][1][j] = v[1];
+          } else {
+            fw[s][0][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, voff, 0, 0);
+          }
+        }
+      }
+      geom_of(nb_q, q_b, xn_nx, rn_nx);
+      q_a = q_b;
+
       if (!g.transposed)
         edge_descriptor(xn, rn, yc, rc, rho, d);
       else
@@ -157,43 +192,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
         oth_lo = u32x4{p_lo, 0u, 0u, 0u};
       }
 
-      // gathered feature fragments of the chunk's two k-steps (shared by the FC rows)
       u32x4 fa_hi[2][VW], fa_lo[2][VW];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (s * 16 < cnt) {  // wave-uniform
-          uint32_t w[VW][8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            // byte offset of the source row of frame-edge acc_row(8s+j, h), fetched from the lane that owns it
-            const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
-            const int voff = src_off + cb4;
-#if SE3_ABLATE_MASK & 2
-            if constexpr (VW >= 1) {
-#pragma unroll
-              for (int t = 0; t < VW; ++t) w[t][j] = (uint32_t)voff * 2654435761u + t;
-            } else
-#endif
-            if constexpr (VW == 4) {
-              const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
-              w[0][j] = v[0], w[1][j] = v[1], w[2][j] = v[2], w[3][j] = v[3];
-            } else if constexpr (VW == 2) {
-              const auto v = __builtin_amdgcn_raw_buffer_load_b64(feat_rs, voff, 0, 0);
-              w[0][j] = v[0], w[1][j] = v[1];
-            } else {
-              w[0][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, voff, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < VW; ++t) {
-            frags_from_words(w[t], fa_hi[s][t], fa_lo[s][t]);
-            if (!ch_ok) fa_hi[s][t] = fa_lo[s][t] = u32x4{0u, 0u, 0u, 0u};
-          }
-        }
-      }
-
-      if (more) geom_of(nb_nx, q_nx, xn_nx, rn_nx);
-
 #pragma unroll
       for (int a = 0; a < FC; ++a) {
         const bool dims07 = FC == 1 ? h == 0 : h == a;
@@ -222,7 +221,10 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);
 #pragma unroll
-            for (int t = 0; t < VW; ++t) acc[a][t] = mfma_bf16x3(fa_hi[s][t], fa_lo[s][t], b_hi, b_lo, acc[a][t]);
+            for (int t = 0; t < VW; ++t) {
+              if (a == 0) frags_from_words(fw[s][t], fa_hi[s][t], fa_lo[s][t]);  // first use: the words have had a chunk's work to arrive
+              acc[a][t] = mfma_bf16x3(fa_hi[s][t], fa_lo[s][t], b_hi, b_lo, acc[a][t]);
+            }
           }
         }
       }
