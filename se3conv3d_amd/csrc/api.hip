@@ -13,14 +13,6 @@ namespace se3 {
 
 namespace {
 
-// [A; beta] as one [10, K] matrix: the constant-1 descriptor slot carries the bias through the MFMA.
-__global__ void build_axes_ext_kernel(const float* __restrict__ axes, const float* __restrict__ biases,
-                                      float* __restrict__ ext) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < SE3_DESC_DIMS * kBasis) ext[i] = axes[i];
-  else if (i < kDescExt * kBasis) ext[i] = biases[i - SE3_DESC_DIMS * kBasis];
-}
-
 // dst[c][r] = src[r][c]   (src [rows, cols])
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
   const int64_t total = (int64_t)rows * cols;
@@ -255,9 +247,9 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
     l.bt_hi = take(plane);
     l.bt_lo = take(plane);
     l.split = take(gemm_nn_bf16_split_bytes((int64_t)s->n_out * s->f_out, s->c_out, s->c_in * (int)kb));
-    l.geom_in = take((size_t)s->n_in * s->f_in * 64);
-    l.geom_out = take((size_t)s->n_out * s->f_out * 64);
   }
+  l.geom_in = take((size_t)s->n_in * s->f_in * 64);
+  l.geom_out = take((size_t)s->n_out * s->f_out * 64);
   l.total = off;
   return l;
 }
@@ -290,8 +282,6 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     l.bt_lo = take(plane);
     l.featpk = want_params ? take(rows_in * s->c_in * 4) : 0;
     l.gpk = take(rows_out * s->c_out * 4);
-    l.geom_in = take(rows_in * 64);
-    l.geom_out = take(rows_out * 64);
     size_t sp = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_out, s->c_in * (int)kb, s->c_out) : 0;
     const size_t sp3 = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_out * (int)kb, s->c_in) : 0;
     if (sp3 > sp) sp = sp3;
@@ -299,6 +289,8 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     if (sp2 > sp) sp = sp2;
     l.split = take(sp);
   }
+  l.geom_in = take(rows_in * 64);
+  l.geom_out = take(rows_out * 64);
   size_t big = 0;
   if (want_params) big = rows_out * s->c_in * kb * 4;
   if (want_feat && rows_in * s->c_out * kb * 4 > big) big = rows_in * s->c_out * kb * 4;
@@ -683,9 +675,18 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   const int ck = s->c_in * s->num_basis;
   const float inv_fin = 1.0f / (float)s->f_in;
   // einsum('nik,iko->no') :210, /F_in :213, *norm_num_neighs_ :216 are the GEMM + its alpha
+  float* geom_in = (float*)(ws + l.geom_in);
+  float* geom_out = (float*)(ws + l.geom_out);
+  const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
+  if (same_cloud) geom_out = geom_in;  // a cloud against itself: one set of records serves both sides
   if (s->precision == SE3_PRECISION_FP32) {
-    hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
-    if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, axes_ext, rho, t, stream)) return rc;
+    PrepBatch pb;  // one launch: [A; beta] table and the packed geometry records
+    pb.axes(proj_axes, proj_biases, axes_ext);
+    pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+    if (!same_cloud) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    if (int rc = pb.launch(stream)) return rc;
+    g.ctr_geom = geom_out, g.nb_geom = geom_in;
+    if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, s->n_in * s->f_in, axes_ext, rho, t, stream)) return rc;
     return launch_gemm_nn("gemm_out", t, conv_weights, out, rows_out, s->c_out, ck, nu, inv_fin, stream);
   }
   uint32_t* featpk = (uint32_t*)(ws + l.featpk);
@@ -694,14 +695,10 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   const float inv_phi = inv_fin / kGeluOut;  // the bf16 edge kernels produce kGeluOut * phi (gelu_scaled)
   const bool t24 = t24_rows(g, s->c_in, rows_out, s->c_out);  // se3conv_bwd decides the same way
   {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
-    float* geom_in = (float*)(ws + l.geom_in);
-    float* geom_out = (float*)(ws + l.geom_out);
-    const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
     PrepBatch pb;
     pb.axes(proj_axes, proj_biases, axes_ext);
     pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
-    if (same_cloud) geom_out = geom_in;  // a cloud against itself: one set of records serves both sides
-    else pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    if (!same_cloud) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     pb.split(feat, featpk, s->n_in * s->f_in * s->c_in);
     pb.weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, nullptr, 1.0f, false, t24);
     if (int rc = pb.launch(stream)) return rc;
@@ -796,7 +793,19 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   float* tn_partials = (float*)(ws + l.tn_partials);
 
   if (s->precision == SE3_PRECISION_FP32) {
-    hipLaunchKernelGGL(build_axes_ext_kernel, dim3(2), dim3(256), 0, stream, proj_axes, proj_biases, axes_ext);
+    {  // one launch: [A; beta] table and the packed geometry records of both sides
+      float* geom_in = (float*)(ws + l.geom_in);
+      float* geom_out = (float*)(ws + l.geom_out);
+      const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
+      PrepBatch pb;
+      pb.axes(proj_axes, proj_biases, axes_ext);
+      pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+      if (same_cloud) geom_out = geom_in;
+      else pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+      if (int rc = pb.launch(stream)) return rc;
+      g.ctr_geom = geom_out, g.nb_geom = geom_in;
+      gt.ctr_geom = geom_in, gt.nb_geom = geom_out;
+    }
     if (want_params) {
       // gT[m,(i,k)] = alpha * sum_o g[m,o] W[i,k,o]
       float* wt = (float*)(ws + l.wt);
@@ -805,7 +814,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       if (int rc = launch_gemm_nn("gemm_gradT", grad_out, wt, big, rows_out, ck, s->c_out, nu, inv_fin, stream)) return rc;
       if (grad_axes || grad_biases) {
         int n_part = 0;
-        if (int rc = launch_edge_param_grad("edge_param_grad", g, feat, s->c_in, axes_ext, rho, big, partials,
+        if (int rc = launch_edge_param_grad("edge_param_grad", g, feat, s->c_in, rows_in, axes_ext, rho, big, partials,
                                             l.n_param_partials, &n_part, stream))
           return rc;
         hipLaunchKernelGGL(reduce_param_partials_kernel, dim3(kDescExt * kBasis), dim3(256), 0, stream, partials,
@@ -815,7 +824,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
         const float* t = t_save;
         if (!t) {
           float* tt = (float*)(ws + l.t);
-          if (int rc = launch_edge_t("edge_t_recompute", g, feat, s->c_in, axes_ext, rho, tt, stream)) return rc;
+          if (int rc = launch_edge_t("edge_t_recompute", g, feat, s->c_in, rows_in, axes_ext, rho, tt, stream)) return rc;
           t = tt;
         }
         // dW[(i,k),o] = alpha * sum_m T[m,(i,k)] g[m,o]
@@ -827,7 +836,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (want_feat && rows_in > 0) {
       // Transposed convolution instead of scatter atomics:
       //   U[(p,b),o,k] = sum_{edges into p} sum_a phi(s,a,p,b)[k] g[(s,a),o];  dX[(p,b),i] = alpha * sum_{o,k} U W[i,k,o]
-      if (int rc = launch_edge_t("edge_t_transposed", gt, grad_out, s->c_out, axes_ext, rho, big, stream)) return rc;
+      if (int rc = launch_edge_t("edge_t_transposed", gt, grad_out, s->c_out, rows_out, axes_ext, rho, big, stream)) return rc;
       float* w2 = (float*)(ws + l.w2);
       hipLaunchKernelGGL(permute_weights_oki_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream,
                          conv_weights, w2, s->c_in, kb, s->c_out);

@@ -259,6 +259,30 @@ __device__ __forceinline__ void edge_descriptor(const float x_in[3], const float
       d[3 + 3 * r + c] = r_out[r] * r_in[c] + r_out[3 + r] * r_in[3 + c] + r_out[6 + r] * r_in[6 + c];
 }
 
+// ---- gather helpers shared by the edge kernels of both arithmetic modes ------------------------------------------
+// byte offset no gathered buffer reaches: a raw buffer load from it returns 0
+constexpr int kOobOffset = 0x7fff0000;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* p, int64_t bytes) {
+  const uint32_t n = bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)n, 0x00020000);
+}
+
+// Packed geometry record of one (point, frame) row: 16 floats = [x, y, z, R8 | R0..R3 | R4..R7 | pad] (64 bytes, built
+// by pack_geometry_kernel).  A lane fetches its row with three 16-byte loads out of ONE cache line; from the
+// reference's separate [N,3] / [N,F,9] arrays it took 12 dword loads, and a gather instruction costs the L1 one
+// cycle per distinct line it touches -- that alone (12 x 32..64 lines per 32 frame-edges) bounded the edge kernels.
+__device__ __forceinline__ void load_geom_record(const __amdgpu_buffer_rsrc_t rs, int row, float x[3], float r[9]) {
+  const int off = row * 64;
+  const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+  const auto v2 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 32, 0, 0);
+  x[0] = __uint_as_float(v0[0]), x[1] = __uint_as_float(v0[1]), x[2] = __uint_as_float(v0[2]);
+  r[8] = __uint_as_float(v0[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __uint_as_float(v1[i]), r[4 + i] = __uint_as_float(v2[i]);
+}
+
 inline int check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
@@ -293,9 +317,9 @@ struct EdgeGeom {            // one side-agnostic view of the geometry for the e
   int transposed;            // 0: centre = output point (descriptor "out" side); 1: centre = input point
 };
 
-int launch_edge_t(const char* tag, const EdgeGeom& g, const float* feat, int channels, const float* axes_ext,
-                  const float* rho, float* t_out, hipStream_t stream);
-int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat, int channels,
+int launch_edge_t(const char* tag, const EdgeGeom& g, const float* feat, int channels, int64_t feat_rows,
+                  const float* axes_ext, const float* rho, float* t_out, hipStream_t stream);
+int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat, int channels, int64_t feat_rows,
                            const float* axes_ext, const float* rho, const float* grad_t, float* partials,
                            int n_partials, int* n_used, hipStream_t stream);
 int edge_param_grad_blocks(int64_t rows);
