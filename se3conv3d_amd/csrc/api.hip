@@ -247,6 +247,8 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
     l.bt_hi = take(plane);
     l.bt_lo = take(plane);
     l.split = take(gemm_nn_bf16_split_bytes((int64_t)s->n_out * s->f_out, s->c_out, s->c_in * (int)kb));
+  } else {
+    l.split = take(gemm_nn_split_bytes((int64_t)s->n_out * s->f_out, s->c_out, s->c_in * (int)kb));
   }
   l.geom_in = take((size_t)s->n_in * s->f_in * 64);
   l.geom_out = take((size_t)s->n_out * s->f_out * 64);
@@ -271,6 +273,7 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   if (!fast) {
     l.wt = want_params ? take(wsz) : 0;
     l.w2 = want_feat ? take(wsz) : 0;
+    l.split = want_feat ? take(gemm_nn_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb)) : 0;
   } else {
     // the largest of the three pre-split weight layouts (see prep_weights_kernel)
     size_t plane = (size_t)s->c_in * kb * align_up((size_t)s->c_out, 32) * 2;
@@ -687,7 +690,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
     if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, s->n_in * s->f_in, axes_ext, rho, t, stream)) return rc;
-    return launch_gemm_nn("gemm_out", t, conv_weights, out, rows_out, s->c_out, ck, nu, inv_fin, stream);
+    return launch_gemm_nn("gemm_out", t, conv_weights, out, rows_out, s->c_out, ck, nu, inv_fin, stream, (float*)(ws + l.split));
   }
   uint32_t* featpk = (uint32_t*)(ws + l.featpk);
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
@@ -840,7 +843,8 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       float* w2 = (float*)(ws + l.w2);
       hipLaunchKernelGGL(permute_weights_oki_kernel, dim3(grid_for((int64_t)ck * s->c_out)), dim3(256), 0, stream,
                          conv_weights, w2, s->c_in, kb, s->c_out);
-      if (int rc = launch_gemm_nn("gemm_gradX", big, w2, grad_feat, rows_in, s->c_in, s->c_out * kb, nu, inv_fin, stream))
+      if (int rc = launch_gemm_nn("gemm_gradX", big, w2, grad_feat, rows_in, s->c_in, s->c_out * kb, nu, inv_fin, stream,
+                                  (float*)(ws + l.split)))
         return rc;
     }
     return check_launch();

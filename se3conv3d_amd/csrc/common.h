@@ -325,7 +325,8 @@ int launch_edge_param_grad(const char* tag, const EdgeGeom& g, const float* feat
 int edge_param_grad_blocks(int64_t rows);
 
 int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, int64_t m, int n, int k,
-                   const float* alpha_num, float alpha_scale, hipStream_t stream);
+                   const float* alpha_num, float alpha_scale, hipStream_t stream, float* split_ws = nullptr);
+size_t gemm_nn_split_bytes(int64_t m, int n, int k);  // room for split_ws (0: the shape is not split)
 int launch_gemm_tn(const char* tag, const float* a, const float* b, float* c, float* partials, int splits, int64_t m,
                    int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream);
 int gemm_tn_splits(int64_t m, int ka, int n);

@@ -151,9 +151,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 // All three read through buffer resources (out-of-range rows / columns return 0: no guards, no branches around loads).
 
 constexpr int FK = 16;  // k-tile of gemm_nn_fast_kernel: 25 KB of LDS per workgroup -> up to 6 workgroups per CU
+// tiles_per_split > 0: grid.z splits the k loop (levels whose row tiles cannot fill the chip: a block's k loop is serial,
+// 128 tiles of 1 024 MFMA cycles whatever M is); block z writes its unscaled partial product to c + z * m * n.
 __global__ __launch_bounds__(256) void gemm_nn_fast_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                            float* __restrict__ c, int64_t m, int n, int k,
-                                                           const float* __restrict__ alpha_num, float alpha_scale) {
+                                                           int tiles_per_split, const float* __restrict__ alpha_num,
+                                                           float alpha_scale) {
   __shared__ float as[2][BM][FK + 1];
   __shared__ __attribute__((aligned(16))) float bs[2][FK][BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,12 +185,13 @@ __global__ __launch_bounds__(256) void gemm_nn_fast_kernel(const float* __restri
     *reinterpret_cast<u32x4*>(&bs[buf][bkr][bnq]) = rb;
   };
   f32x16 acc0 = zero16(), acc1 = zero16();
-  const int nk = k / FK;
-  load_tile(0);
+  const int kt0 = tiles_per_split > 0 ? blockIdx.z * tiles_per_split : 0;
+  const int nk = tiles_per_split > 0 ? min(k / FK, kt0 + tiles_per_split) : k / FK;  // > kt0 by construction
+  load_tile(kt0 * FK);
   store_tile(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int buf = (kt - kt0) & 1;
     load_tile(kt + 1 < nk ? (kt + 1) * FK : 0);  // unconditional (the last one re-reads tile 0 and is dropped)
 #pragma unroll
     for (int t = 0; t < FK / 2; ++t) {
@@ -199,7 +203,8 @@ __global__ __launch_bounds__(256) void gemm_nn_fast_kernel(const float* __restri
     store_tile(buf ^ 1);
     __syncthreads();
   }
-  const float alpha = (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+  const float alpha = tiles_per_split > 0 ? 1.0f : (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+  if (tiles_per_split > 0) c += (int64_t)blockIdx.z * m * n;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t gr = m0 + wave * 32 + acc_row(r, h);
@@ -343,8 +348,24 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, float
 
 }  // namespace
 
+// k splits of gemm_nn_fast_kernel: only when the row tiles leave most of the chip idle; at most ~1024 workgroups, at least
+// 8 k-tiles per split (the partials cost their traffic and one reduction launch)
+int gemm_nn_splits(int64_t m, int n, int k) {
+  const int64_t tiles = ((m + BM - 1) / BM) * ((n + BN - 1) / BN);
+  const int nk = k / FK;
+  if (tiles >= 256 || k % FK != 0 || n % 4 != 0 || nk < 16) return 1;
+  int64_t s = 1024 / tiles;
+  if (s > nk / 8) s = nk / 8;
+  return (int)(s < 1 ? 1 : s);
+}
+
+size_t gemm_nn_split_bytes(int64_t m, int n, int k) {
+  const int s = gemm_nn_splits(m, n, k);
+  return s > 1 ? (size_t)s * m * n * 4 : 0;
+}
+
 int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, int64_t m, int n, int k,
-                   const float* alpha_num, float alpha_scale, hipStream_t stream) {
+                   const float* alpha_num, float alpha_scale, hipStream_t stream, float* split_ws) {
   if (m == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   const int64_t row_blocks = (m + BM - 1) / BM;
@@ -364,8 +385,15 @@ int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, in
     return check_launch();
   }
   const dim3 grid((unsigned)row_blocks, (unsigned)((n + BN - 1) / BN));
+  const int splits = small && split_ws ? gemm_nn_splits(m, n, k) : 1;
+  if (splits > 1) {
+    const int per = (k / FK + splits - 1) / splits;
+    const dim3 sgrid(grid.x, grid.y, (unsigned)((k / FK + per - 1) / per));
+    hipLaunchKernelGGL(gemm_nn_fast_kernel, sgrid, dim3(256), 0, stream, a, b, split_ws, m, n, k, per, alpha_num, alpha_scale);
+    return launch_reduce_partials(split_ws, c, m * n, (int)sgrid.z, alpha_num, alpha_scale, stream);
+  }
   if (small && k % FK == 0 && n % 4 == 0)
-    hipLaunchKernelGGL(gemm_nn_fast_kernel, grid, dim3(256), 0, stream, a, b, c, m, n, k, alpha_num, alpha_scale);
+    hipLaunchKernelGGL(gemm_nn_fast_kernel, grid, dim3(256), 0, stream, a, b, c, m, n, k, 0, alpha_num, alpha_scale);
   else
     hipLaunchKernelGGL(gemm_nn_kernel, grid, dim3(256), 0, stream, a, b, c, m, n, k, alpha_num, alpha_scale);
   return check_launch();

@@ -13,6 +13,7 @@ import bench
 dev = torch.device("cuda:0")
 lib = _lib.load()
 from se3conv3d_amd import workloads as W
+amd.set_precision(os.environ.get("SE3CONV_PRECISION", "bf16x3"))  # fp32: the exact mode's levels
 levels = W.build_stack(W.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'headline'], dev, 0)
 for i, lv in enumerate(levels):
     for _ in range(3):
