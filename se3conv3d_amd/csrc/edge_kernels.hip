@@ -75,8 +75,14 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], con
 // frames from the reference's separate arrays -> descriptor -> MLP -> GELU -> gathers in four guarded groups, each
 // link waiting for the one before: 0.78 ms at the headline level against 0.28 ms of MFMA issue.)
 // ------------------------------------------------------------------------------------------------
+#ifndef SE3_E32_ABLATE
+#define SE3_E32_ABLATE 0  // diagnostic builds of edge_t_kernel (wrong results): 1 no GELU, 2 no feature gather, 4 no stores, 8 no aggregation MFMAs
+#endif
+#ifndef SE3_EDGE32_WAVES
+#define SE3_EDGE32_WAVES 3
+#endif
 template <int VW>
-__global__ __launch_bounds__(256, VW == 4 ? 2 : 3) void edge_t_kernel(EdgeGeom g, const float* __restrict__ feat,
+__global__ __launch_bounds__(256, VW == 4 ? 2 : SE3_EDGE32_WAVES) void edge_t_kernel(EdgeGeom g, const float* __restrict__ feat,
                                                                       int channels, int64_t feat_rows,
                                                                       const float* __restrict__ axes_ext,
                                                                       const float* __restrict__ rho_p,
@@ -147,7 +153,10 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : 3) void edge_t_kernel(EdgeGeom g
       for (int r = 0; r < 16; ++r) {
         const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(r, 0), qoff);
         const int voff = ch_ok ? src_off + cb4 : kOobOffset;
-        if constexpr (VW == 4) {
+        if constexpr ((SE3_E32_ABLATE & 2) != 0) {
+#pragma unroll
+          for (int t = 0; t < VW; ++t) a[r][t] = __uint_as_float((uint32_t)(voff + t) * 2654435761u) * 1e-30f;
+        } else if constexpr (VW == 4) {
           const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
 #pragma unroll
           for (int t = 0; t < 4; ++t) a[r][t] = __uint_as_float(v[t]);
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : 3) void edge_t_kernel(EdgeGeom g
       d[9] = 1.0f;
       f32x16 phi = mlp_preactivation(d, bmlp, h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) phi[r] = gelu_erf(phi[r]);
+      for (int r = 0; r < 16; ++r) phi[r] = (SE3_E32_ABLATE & 1) ? phi[r] : gelu_erf(phi[r]);
 
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -176,7 +185,10 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : 3) void edge_t_kernel(EdgeGeom g
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-            for (int t = 0; t < VW; ++t) acc[t] = mfma32(a[g4 * 4 + rr][t], phi[g4 * 4 + rr], acc[t]);
+            for (int t = 0; t < VW; ++t) {
+              if (SE3_E32_ABLATE & 8) acc[t][rr] += a[g4 * 4 + rr][t] * phi[g4 * 4 + rr];
+              else acc[t] = mfma32(a[g4 * 4 + rr][t], phi[g4 * 4 + rr], acc[t]);
+            }
         }
       }
     }
@@ -187,6 +199,7 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : 3) void edge_t_kernel(EdgeGeom g
       for (int r = 0; r < 16; ++r) {
         const int ch = cbase + VW * acc_row(r, h) + t;
         // non-temporal: the GEMM that follows does not run against this kernel's write-back (see edge_bf16.hip)
+        if ((SE3_E32_ABLATE & 4) && __float_as_uint(acc[t][r]) != 0x12345678u) continue;
         if (ch < channels) __builtin_nontemporal_store(acc[t][r], &t_row[(int64_t)ch * kBasis + kcol]);
       }
   }
