@@ -90,8 +90,8 @@ int se3_abi_version(void);
 const char* se3_error_string(int code);
 /* Bytes per element of the row-sized intermediates [rows, C, K] the operator moves through memory for this shape --
  * which = 0: T (forward; read again by the weight gradient), 1: U (feature gradient), 2: grad_T.  4 = fp32 / packed
- * hi|lo words, 3 = 3-byte rows, 0 = never written (fused small-level kernel); negative = SE3_ERR_*.  For traffic
- * models (bench.py), so that they need not hard-code what the library picked. */
+ * hi|lo words, 3 = 3-byte rows (the library picks per shape: rows of <= 32 or >= 64 channels, even); negative = SE3_ERR_*.
+ * For traffic models (bench.py), so that they need not hard-code what the library picked. */
 int se3conv_intermediate_bytes_per_element(const se3conv_shape* s, int which);
 
 /* ---------------------------------------------------------------------------------------------
