@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void edge_param_grad_kernel(EdgeGeom g, const 
             }
           }
         } else {
-#pragma unroll 4
+          // (rolled: channel counts that are not multiples of 4 are the rare case)
           for (int t = 0; t < hs; ++t) {
             const int ch = my0 + t;
             const bool ok = ch < cb0 + crem;
