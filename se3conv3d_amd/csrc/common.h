@@ -196,50 +196,6 @@ __device__ __forceinline__ void gelu_scaled_grad(float xp, float& y2, float& dy2
   dy2 = fmaf(__builtin_copysignf(1.0f, xp), fmaf(a * e, 0.79788456080286535588f / kGeluIn, hq2), 1.0f);
 }
 
-// Pairwise entry points used by the bf16 edge kernels.  SE3_GELU_PK=1 builds evaluate the pair on the packed
-// fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32); the default evaluates the two values with scalar VALU ops.
-#ifndef SE3_GELU_PK
-#define SE3_GELU_PK 0
-#endif
-#if SE3_GELU_PK
-__device__ __forceinline__ void gelu_erf_core2(f32x2 x, f32x2& s, f32x2& a, f32x2& e, f32x2& hq) {
-  a = __builtin_elementwise_abs(x);
-  const f32x2 one = {1.0f, 1.0f};
-  s = __builtin_elementwise_copysign(one, x);
-  f32x2 t = a * 0.23164189f + 1.0f;
-  t[0] = __builtin_amdgcn_rcpf(t[0]);
-  t[1] = __builtin_amdgcn_rcpf(t[1]);
-  f32x2 p = t * 0.5307027145f - 0.7265760135f;
-  p = p * t + 0.7107068705f;
-  p = p * t - 0.142248368f;
-  p = p * t + 0.127414796f;
-  const f32x2 xe = (x * x) * -0.72134752044448170368f;
-  e[0] = __builtin_amdgcn_exp2f(xe[0]);
-  e[1] = __builtin_amdgcn_exp2f(xe[1]);
-  hq = 0.5f - (p * t) * e;
-}
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  f32x2 s, a, e, hq;
-  gelu_erf_core2(x, s, a, e, hq);
-  return x * (s * hq + 0.5f);
-}
-__device__ __forceinline__ void gelu_erf_grad2(f32x2 x, f32x2& y, f32x2& dy) {
-  f32x2 s, a, e, hq;
-  gelu_erf_core2(x, s, a, e, hq);
-  y = x * (s * hq + 0.5f);
-  dy = s * ((a * e) * 0.39894228040143267794f + hq) + 0.5f;
-}
-#else
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) { return f32x2{gelu_erf(x[0]), gelu_erf(x[1])}; }
-__device__ __forceinline__ void gelu_erf_grad2(f32x2 x, f32x2& y, f32x2& dy) {
-  float y0, y1, d0, d1;
-  gelu_erf_grad(x[0], y0, d0);
-  gelu_erf_grad(x[1], y1, d1);
-  y = f32x2{y0, y1};
-  dy = f32x2{d0, d1};
-}
-#endif
-
 // 9-D edge descriptor (reference PNEConvLayerRotEquiv.py:68-90):
 //   d[0..2] = (rho * (x_in - y_out))^T R_out          (RotationFunctions.py:637-665)
 //   d[3..8] = rows 0,1 of R_out^T R_in                 (RotationFunctions.py:549-600, 236-252)

@@ -96,11 +96,8 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], int
 // VALU is the bound of this kernel (MFMA ~15 % busy), so everything here is about instruction count:
 // 32-bit buffer addressing, ds_bpermute for the per-row source offsets, branch-free GELU.
 // ------------------------------------------------------------------------------------------------
-#ifndef SE3_ITEM_WAVES
-#define SE3_ITEM_WAVES 2
-#endif
 template <int VW, int FC, bool FULL, bool T24 = false>
-__global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : (VW == 1 ? SE3_ITEM_WAVES : 2))) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
+__global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_bf16_kernel(EdgeGeom g, const uint32_t* __restrict__ feat, int channels,
                                                              int64_t feat_rows, const float* __restrict__ axes_ext,
                                                              const float* __restrict__ rho_p,
                                                              uint32_t* __restrict__ t_out, int64_t n_items,
@@ -172,9 +169,6 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : (VW == 1 ? SE3_IT
 #define SE3_PAIR_PIN 1  // centre record passed through an empty asm at the top of every chunk: nothing derived from it is hoisted out
                         // of the loop (fewer live registers, another schedule).  Measured -2 % (0.366 / 0.360 -> 0.359 / 0.353 ms)
 #endif
-#ifndef SE3_PAIR_MLP_FP32
-#define SE3_PAIR_MLP_FP32 0  // 1: kernel MLP on v_mfma_f32_32x32x2_f32 (fewer VALU ops, measured 14 % slower: 0.41 vs 0.36 ms)
-#endif
 // POW2: fnb_shift >= 0 is known (no division path, no branch on it).  TR: 0 forward, 1 transposed pass, -1 decided by
 // g.transposed at run time (both descriptor paths in the loop)
 template <int CT, bool FULL, int NF, bool POW2 = false, int TR = -1>
@@ -182,23 +176,12 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift,
     int t24) {
-#if !SE3_PAIR_MLP_FP32
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
-#endif
   __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kcol = lane & 31, h = lane >> 5;
-#if SE3_PAIR_MLP_FP32
-  // kernel-MLP weights as the B operand of v_mfma_f32_32x32x2_f32: lane (k = kcol, h) holds rows 2t + h of
-  // kGeluIn * [A; beta].  Exact fp32 products, and the descriptor needs no hi/lo split (5 selects instead of ~32
-  // VALU ops per chunk); the fp32 MFMA is 16x slower than the bf16 one, which the idle MFMA pipe absorbs.
-  float bm[5];
-#pragma unroll
-  for (int t = 0; t < 5; ++t) bm[t] = kGeluIn * axes_ext[(2 * t + h) * kBasis + kcol];
-#else
   if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
-#endif
   const float rho = *rho_p;
   const int row_bytes = C * 4;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
@@ -300,14 +283,6 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       // kernel MLP + GELU for this wavefront's frame; both lane halves hold the same descriptor: half 0 feeds
       // dims 0..7, half 1 dims 8, 9
       {
-#if SE3_PAIR_MLP_FP32
-        f32x16 phi = zero16();
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-          const float hi_k = t < 4 ? d[2 * t + 1] : 1.0f;  // descriptor dim 9 is the constant 1 that carries beta
-          phi = mfma32(h ? hi_k : d[2 * t], bm[t], phi);
-        }
-#else
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
@@ -316,7 +291,6 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
         const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
         const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
         const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
-#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s * 16 < cnt && (NF == 2 || s == wv)) {
@@ -533,19 +507,6 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 #ifndef SE3_PG_SINGLE_WAVES
 #define SE3_PG_SINGLE_WAVES 3  // one frame per wavefront (odd F).  4 (40 KB of LDS per 4-wave workgroup = 4 per CU) was measured:
 #endif                         // at 128 VGPRs the 64-channel form spills 11 registers and runs 0.65 instead of 0.47 ms (ScanNet-like)
-#ifndef SE3_PG_GT_BUFFER
-#define SE3_PG_GT_BUFFER 1  // grad_T rows through a per-row buffer resource (0: guarded global loads = one branch per load)
-#endif
-#ifndef SE3_PG_PAIR_GEOM_AT_END
-#define SE3_PG_PAIR_GEOM_AT_END 0  // pair form: next chunk's geometry record issued at the end of the chunk body
-#endif
-#ifndef SE3_PG_PAIR_PIN
-#define SE3_PG_PAIR_PIN 0  // 1: pair form, centre record passed through an empty asm per chunk (as SE3_PAIR_PIN in the edge_t pair kernel).
-                           // Measured slower here: 0.429 vs 0.419 ms (profiles/r02_param_grad_pin_ab.txt)
-#endif
-#ifndef SE3_PG_SEQ
-#define SE3_PG_SEQ 0  // 1: the two frames of a chunk one after the other (GELU' of one frame live at a time: fewer VGPRs)
-#endif
 // PAIR (round 2, two frames only): a 128-thread workgroup = two wavefronts share ONE item -- one grad_T image (16 KB
 // instead of 16 KB per wavefront: 26 KB of LDS per workgroup, 6 workgroups = 3 wavefronts per SIMD instead of 2),
 // wavefront v builds the image of frame v (32 of the 64 row loads) and takes the chunks v, v + 2, ... of the item for
@@ -650,8 +611,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
-                          : SE3_PG_GT_BUFFER ? __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0)
-                          : (c_off + 16 * st < row_ch ? gt_row[(16 * st + 8 * h + j) * kBasis + kcol] : 0u);
+                          : __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0);
     }
     int q_a = row_of(nb_a, c_first);
     float xn_nx[3], rn_nx[9];
@@ -673,13 +633,6 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;
       float d[9];
-      if (PAIR && SE3_PG_PAIR_PIN) {
-        // keep the centre's record as the 12 values it is (nothing derived from it is hoisted out of the loop)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(yc[i]));
-#pragma unroll
-        for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(rc[i]));
-      }
       const int q_b = row_of(nb_b, c0 + CSTEP);
       nb_b = nbr_of(c0 + 2 * CSTEP);
 
@@ -709,9 +662,9 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         edge_descriptor(xn_nx, rn_nx, yc, rc, rho, d);
       else
         edge_descriptor(yc, rc, xn_nx, rn_nx, rho, d);
-      // the next chunk's record goes out once this chunk's has been consumed (SE3_PG_PAIR_GEOM_AT_END=1: only at the
+      // the next chunk's record goes out once this chunk's has been consumed (issuing it only at the
       // end of the chunk body -- measured slower, 0.434 vs 0.419 ms)
-      if (!(SE3_PG_ABLATE & 16) && !LEAN && !(PAIR && SE3_PG_PAIR_GEOM_AT_END)) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      if (!(SE3_PG_ABLATE & 16) && !LEAN) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
 
       u32x4 own_hi, own_lo, oth_hi = {0u, 0u, 0u, 0u}, oth_lo = {0u, 0u, 0u, 0u};
       if (SE3_PG_ABLATE & 16) {  // what the stash would deliver: the split descriptor as two 16-byte words per plane
@@ -851,20 +804,6 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         }
         continue;
       }
-#if SE3_PG_SEQ
-      // one frame at a time: GELU' of frame 0 (pure VALU, covers the gather latency), the gathered words become
-      // fragments, frame 0 is accumulated; then the same for frame 1 -- 16 instead of 32 GELU' values live
-#pragma unroll
-      for (int a = 0; a < NFR; ++a) {
-        float dy[16];
-        gelu_grad_of_frame(a, dy);
-        if (a == 0) {
-#pragma unroll
-          for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
-        }
-        accumulate_frame(a, fa_hi, fa_lo, dy);
-      }
-#else
       // GELU' of both frames first (pure VALU, covers the gather latency) ...
       float dyv[NFR][16];
 #pragma unroll
@@ -874,8 +813,6 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
 #pragma unroll
       for (int a = 0; a < NFR; ++a) accumulate_frame(a, fa_hi, fa_lo, dyv[a]);
-#endif
-      if (PAIR && SE3_PG_PAIR_GEOM_AT_END && !LEAN && c0 + CSTEP < n_total) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }

@@ -78,11 +78,8 @@ __device__ __forceinline__ f32x16 mlp_preactivation(const float d[kDescExt], con
 #ifndef SE3_E32_ABLATE
 #define SE3_E32_ABLATE 0  // diagnostic builds of edge_t_kernel (wrong results): 1 no GELU, 2 no feature gather, 4 no stores, 8 no aggregation MFMAs
 #endif
-#ifndef SE3_EDGE32_WAVES
-#define SE3_EDGE32_WAVES 3
-#endif
 template <int VW>
-__global__ __launch_bounds__(256, VW == 4 ? 2 : SE3_EDGE32_WAVES) void edge_t_kernel(EdgeGeom g, const float* __restrict__ feat,
+__global__ __launch_bounds__(256, VW == 4 ? 2 : 3) void edge_t_kernel(EdgeGeom g, const float* __restrict__ feat,
                                                                       int channels, int64_t feat_rows,
                                                                       const float* __restrict__ axes_ext,
                                                                       const float* __restrict__ rho_p,

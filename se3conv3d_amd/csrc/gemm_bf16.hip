@@ -20,9 +20,6 @@ namespace {
 #ifndef SE3_GEMM_ABLATE
 #define SE3_GEMM_ABLATE 0  // diagnostic builds: 1 no MFMA stage, 2 no LDS staging, 4 no barriers
 #endif
-#ifndef SE3_GEMM_REVERSE
-#define SE3_GEMM_REVERSE 0  // measured: no difference (0.245 ms either way)
-#endif
 #ifndef SE3_GEMM_DEPTH
 #define SE3_GEMM_DEPTH 4
 #endif
@@ -59,14 +56,9 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
   __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
-  // Row blocks are taken last-to-first: A was written front-to-back by the kernel just before this one, so its tail
-  // (up to the 256 MB of the memory-side cache) is still on chip when this kernel starts; reading it first turns
-  // that part of the stream into cache hits instead of letting the front-to-back walk evict it unread.
-#if SE3_GEMM_REVERSE
-  const int64_t m0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * BM;
-#else
+  // (row blocks last-to-first -- A was written front-to-back just before, its tail is still in the memory-side cache --
+  // was measured: no difference, 0.245 ms either way)
   const int64_t m0 = (int64_t)blockIdx.x * BM;
-#endif
   const int n0 = blockIdx.y * BNW;
   const bool a_vec = (k % 4) == 0;
   const int kt_begin = blockIdx.z * kt_per_split;
@@ -233,12 +225,7 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
 // k: 128 B of hi and 64 B of lo per row and instruction.  LDS and the MFMA stage keep the 32-k tiles of the kernel
 // above: the two halves of a super tile are the two LDS buffers.  Lane l of load p reads 16-byte column
 // (l & 7) ^ (4 * (p & 1)), so every thread holds as many pieces of either half and the stores stay full-width.
-#ifndef SE3_T24_REVERSE
-#define SE3_T24_REVERSE 0
-#endif
-#ifndef SE3_T24_NT_LOADS
-#define SE3_T24_NT_LOADS 0  // 1: the row stream is loaded non-temporally (read once; keeps the weight tiles in L2)
-#endif
+// (Measured and not kept: row blocks last-written first -- no difference; the row stream loaded non-temporally -- slower.)
 // (256-row workgroups -- 8 wavefronts, the weight planes fetched from L2 half as often -- were measured in round 3:
 // nothing at the headline shape, 15 % slower on a 150 k-row scene whose 586 workgroups no longer divide into full rounds:
 // profiles/r03_gemm_256row_ab.txt.)
@@ -260,8 +247,7 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
   __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rl = lane & 31, h = lane >> 5;
-  // SE3_T24_REVERSE: row blocks last-written first (the producer wrote the rows front to back just before this launch)
-  const int64_t m0 = (int64_t)(SE3_T24_REVERSE ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * RB;
+  const int64_t m0 = (int64_t)blockIdx.x * RB;
   const int n0 = blockIdx.y * BNW;
   const int st_begin = blockIdx.z * st_per_split;
   const int ns = min(k / 64 - st_begin, st_per_split);  // super tiles of this block (> 0 by construction)
@@ -283,12 +269,12 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const uint32_t off = (uint32_t)(m0 + p * RP + (tid >> 3)) * rb + k0 * 2u + (uint32_t)((tid & 7) ^ ((p & 1) << 2)) * 16u;
-      t.ah[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, SE3_T24_NT_LOADS ? 2 : 0));
+      t.ah[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const uint32_t off = (uint32_t)(m0 + p * RPL + (tid >> 2)) * rb + (uint32_t)k * 2u + k0 + (uint32_t)((tid & 3) ^ (p << 1)) * 16u;
-      t.al[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, SE3_T24_NT_LOADS ? 2 : 0));
+      t.al[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
     }
 #pragma unroll
     for (int j = 0; j < NBP; ++j) {  // pass j: columns CP * j + (tid >> 3); passes alternate which 32-k half a thread holds
