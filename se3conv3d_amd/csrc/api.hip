@@ -227,9 +227,9 @@ int shape_supported(const se3conv_shape* s) {
   if (s->n_in * s->f_in >= (1ll << 31) || s->n_out * s->f_out >= (1ll << 31) ||
       s->n_edges * s->f_in * s->f_out >= (1ll << 31))
     return SE3_ERR_UNSUPPORTED;  // row / frame-edge ids are int32 inside the kernels
-  if (s->precision == SE3_PRECISION_BF16X3 &&
-      (s->n_in * s->f_in * s->c_in >= (1ll << 30) || s->n_out * s->f_out * s->c_out >= (1ll << 30)))
-    return SE3_ERR_UNSUPPORTED;  // gathered operands are addressed with 32-bit byte offsets
+  if (s->n_in * s->f_in * s->c_in >= (1ll << 29) || s->n_out * s->f_out * s->c_out >= (1ll << 29) ||
+      s->n_in * s->f_in >= (1ll << 25) || s->n_out * s->f_out >= (1ll << 25))
+    return SE3_ERR_UNSUPPORTED;  // gathered operands (< 2 GB) and the 64-byte geometry records are addressed with 32-bit byte offsets
   return SE3_OK;
 }
 
