@@ -367,6 +367,11 @@ int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, i
  *                     into gate)
  *   se3_skip_bwd      dx = g * gamma[c] * gate (dx may be NULL), dgamma[c] = sum_r g * x * gate   (dy = g)
  *   se3_bias_gelu_bwd dz = g * GELU'(z + bias), dbias[c] = sum_r dz   (bias NULL = 0)
+ *   se3_linear_wgrad  grad_w[n_out, n_in] = grad_y[rows, n_out]^T x[rows, n_in]: the weight gradient of the block's
+ *                     torch.nn.Linear layers (linear_1_, linear_2_, skip_conv_; ResNetFormer.py:42-49, 80-86) -- a reduction
+ *                     over every row of the cloud into a small matrix, which generic BLAS heuristics run on the few
+ *                     workgroups its output tiles give; here the rows are split over the chip (fp32 MFMA, fixed-order
+ *                     reduction of the partials).  `workspace`: se3_linear_wgrad_workspace_bytes(rows, n_out, n_in)
  * ------------------------------------------------------------------------------------------- */
 size_t se3_glue_workspace_bytes(int32_t c);
 int se3_bn_fwd(const float* x, const float* weight, const float* bias, int64_t rows, int32_t c, float eps, float momentum,
@@ -384,6 +389,9 @@ int se3_skip_bwd(const float* g, const float* x, const float* gamma, const float
                  void* stream);
 int se3_bias_gelu_bwd(const float* g, const float* z, const float* bias, int64_t rows, int32_t c, float* dz,
                       float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+size_t se3_linear_wgrad_workspace_bytes(int64_t rows, int32_t n_out, int32_t n_in);
+int se3_linear_wgrad(const float* grad_y, const float* x, int64_t rows, int32_t n_out, int32_t n_in, float* grad_w,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optional per-kernel timing for bench.py's roofline line (no reference counterpart: the reference

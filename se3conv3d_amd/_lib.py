@@ -81,6 +81,8 @@ SIGNATURES = {
     "se3_skip_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "se3_skip_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),
     "se3_bias_gelu_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),
+    "se3_linear_wgrad_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
+    "se3_linear_wgrad": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
     "se3_side_stream_stats": (C.c_int, [_P]),
     "se3_profile_enable": (C.c_int, [C.c_int]),
     "se3_profile_reset": (C.c_int, []),

@@ -3,7 +3,8 @@ batch ids, the residual connection with its learned gain, the point-cloud batch 
 the reference's attribute names so that a reference ``state_dict`` loads key for key.  On GPU tensors the row-wise
 passes run as the library's fused kernels (csrc/glue.hip through ops.BatchNormTrain / SkipDropPath / BiasGelu): training
 batch norm in 3 launches each way, skip + layer scale + drop-path gate in one, bias + GELU behind a bias-free GEMM in
-one (timings per block: profiles/r02_block_glue_timing.txt); the dense C x C products stay rocBLAS GEMMs.
+one, the linear layers' weight gradients on the library's row-split TN GEMM (timings per block:
+profiles/r03_block_glue_timing.txt); the forward and input-gradient C x C products stay BLAS GEMMs.
 ``FUSED = False`` (or SE3_BLOCKS_FUSED=0) keeps the plain torch formulation (the A/B of tools/time_block.py).
 
   DropPathPC      layers/DropPathPC.py:30-46      one keep / drop decision per batch element, scaled by 1 / keep_prob
@@ -119,10 +120,15 @@ class ResNetFormer(Block):
                                p_neighborhood=p_neighborhood)
         x = self.skip_path_1_(x, p_in_features, p_pc_in)
         h = self.norm_2_(x, p_pc_in)
-        if _fused(h):  # bias + GELU in one pass behind a bias-free GEMM
-            h = ops.BiasGelu.apply(torch.nn.functional.linear(h, self.linear_1_.weight), self.linear_1_.bias)
+        if _fused(h):
+            # bias + GELU in one pass behind a bias-free GEMM; the linear layers' weight gradients on the row-split GEMM
+            h = ops.BiasGelu.apply(ops.Linear.apply(h, self.linear_1_.weight, None), self.linear_1_.bias)
+            y = ops.Linear.apply(h, self.linear_2_.weight, self.linear_2_.bias)
+            skip = x
+            if self.feat_input_size_ != self.feat_output_size_:
+                skip = ops.Linear.apply(x, self.skip_conv_.weight, self.skip_conv_.bias)
         else:
             h = self.act_func_(self.linear_1_(h))
-        y = self.linear_2_(h)
-        skip = self.skip_conv_(x) if self.feat_input_size_ != self.feat_output_size_ else x
+            y = self.linear_2_(h)
+            skip = self.skip_conv_(x) if self.feat_input_size_ != self.feat_output_size_ else x
         return self.skip_path_2_(y, skip, p_pc_in)

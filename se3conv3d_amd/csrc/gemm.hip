@@ -346,6 +346,28 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, float
   }
 }
 
+// The same sum for MANY partials of a SMALL result (the weight gradient of a point-wise linear layer: 512 row ranges of a
+// 128 x 64 matrix): one thread per output would add 512 values one after the other on 32 workgroups (90 us); here a block
+// owns 32 consecutive outputs, its 8 groups of 32 threads take every 8th partial (128-byte reads), and LDS folds the groups.
+__global__ __launch_bounds__(256) void reduce_partials_grouped_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                                      int64_t count, int splits,
+                                                                      const float* __restrict__ alpha_num, float alpha_scale) {
+  __shared__ float red[8][32];
+  const int ol = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + ol;
+  float s = 0.f;
+  if (i < count)
+    for (int p = grp; p < splits; p += 8) s += partials[(int64_t)p * count + i];
+  red[grp][ol] = s;
+  __syncthreads();
+  if (grp == 0 && i < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][ol];  // fixed order
+    out[i] = (alpha_num ? *alpha_num : 1.0f) * alpha_scale * t;
+  }
+}
+
 }  // namespace
 
 // k splits of gemm_nn_fast_kernel: only when the row tiles leave most of the chip idle; at most ~1024 workgroups, at least
@@ -429,6 +451,11 @@ int launch_gemm_tn(const char* tag, const float* a, const float* b, float* c, fl
 
 int launch_reduce_partials(const float* partials, float* out, int64_t count, int splits, const float* alpha_num,
                            float alpha_scale, hipStream_t stream) {
+  if (splits >= 64 && count <= (1 << 16)) {
+    hipLaunchKernelGGL(reduce_partials_grouped_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, stream, partials, out,
+                       count, splits, alpha_num, alpha_scale);
+    return check_launch();
+  }
   const int rb = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(rb), dim3(256), 0, stream, partials, out, count, splits, alpha_num,
                      alpha_scale);

@@ -433,3 +433,23 @@ extern "C" int se3_bias_gelu_bwd(const float* g, const float* z, const float* bi
   SE3_GLUE_DISPATCH(bias_gelu_bwd_kernel, g, z, bias, rows, (int)c, dz, partials);
   return finish_channel_sums(partials, blocks, c, 1, dbias, nullptr, stream);
 }
+
+// Weight gradient of a point-wise linear layer y = x W^T (+ b): grad_w[n_out, n_in] = grad_y^T x, a reduction over all rows
+// of the cloud into a small matrix.  The BLAS heuristics run this shape on the handful of workgroups its output tiles give
+// (131 072 rows into 128 x 64 outputs: 0.28-0.36 ms, half of a ResNetFormer block's glue); gemm_tn splits the rows over the
+// chip and reduces the partials (gemm.hip: ~512 workgroups, two operand batches in flight each).
+extern "C" size_t se3_linear_wgrad_workspace_bytes(int64_t rows, int32_t n_out, int32_t n_in) {
+  if (rows < 0 || n_out < 1 || n_in < 1) return 0;
+  return (size_t)gemm_tn_splits(rows, n_out, n_in) * n_out * n_in * 4;
+}
+
+extern "C" int se3_linear_wgrad(const float* grad_y, const float* x, int64_t rows, int32_t n_out, int32_t n_in, float* grad_w,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+  if (rows < 0 || n_out < 1 || n_in < 1 || !grad_w || !workspace || (rows > 0 && (!grad_y || !x)))
+    return SE3_ERR_INVALID_ARGUMENT;
+  if (workspace_bytes < se3_linear_wgrad_workspace_bytes(rows, n_out, n_in)) return SE3_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (rows == 0) return hipMemsetAsync(grad_w, 0, (size_t)n_out * n_in * 4, stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  return launch_gemm_tn("linear_wgrad", grad_y, x, grad_w, (float*)workspace, gemm_tn_splits(rows, n_out, n_in), rows, n_out,
+                        n_in, nullptr, 1.0f, stream);
+}

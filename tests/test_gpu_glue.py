@@ -92,6 +92,34 @@ def test_bias_gelu_matches_torch(amd, rows, c):
     assert rel_err(out, ref) < TOL and rel_err(z.grad, z2.grad) < TOL and rel_err(b.grad, b2.grad) < 1e-5
 
 
+@pytest.mark.parametrize("rows,n_in,n_out,bias", [(131072, 64, 128, True), (18414, 128, 64, True), (2652, 64, 64, False),
+                                                  (1, 32, 5, True), (777, 13, 130, True), (0, 16, 8, True)])
+def test_linear_weight_gradient_on_the_row_split_gemm_matches_torch(amd, rows, n_in, n_out, bias):
+    """ops.Linear: forward / input gradient are the BLAS GEMMs, the weight gradient is se3_linear_wgrad (fp32 MFMA, rows
+    split over the chip, fixed-order reduction) -- against torch.nn.functional.linear's own backward in fp64."""
+    from se3conv3d_amd import ops
+    torch.manual_seed(rows + n_in)
+    x = torch.randn(rows, n_in, device=DEV, requires_grad=True)
+    w = torch.randn(n_out, n_in, device=DEV, requires_grad=True)
+    b = torch.randn(n_out, device=DEV, requires_grad=True) if bias else None
+    g = torch.randn(rows, n_out, device=DEV)
+    y = ops.Linear.apply(x, w, b)
+    y.backward(g)
+    xd, wd, gd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), g.double()
+    bd = b.detach().double().requires_grad_(True) if bias else None
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    yd.backward(gd)
+    assert y.shape == (rows, n_out) and w.grad.shape == (n_out, n_in)
+    if rows == 0:
+        assert float(w.grad.abs().max()) == 0.0
+        return
+    assert rel_err(y, yd.float()) < 1e-5
+    assert rel_err(w.grad, wd.grad.float()) < 1e-5
+    assert rel_err(x.grad, xd.grad.float()) < 1e-5
+    if bias:
+        assert rel_err(b.grad, bd.grad.float()) < 1e-5
+
+
 def test_fused_block_equals_torch_block_with_drop_path(amd):
     """A whole ResNetFormer in training mode with drop path on: the fused formulation and the plain torch one draw the
     same gates from the same seed and agree on output, gradients and batch-norm statistics."""
