@@ -357,14 +357,17 @@ int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, i
  * sums are accumulated in fp64 in a fixed order (no atomics).  `workspace`: se3_glue_workspace_bytes(C) bytes.
  *   se3_bn_fwd        training-mode torch.nn.BatchNorm1d: save_mean[c], save_invstd[c] = 1 / sqrt(biased var + eps),
  *                     y = (x - mean) * invstd * weight + bias, running_mean / running_var (may be NULL) updated in place
- *                     with `momentum` and the unbiased variance; weight / bias NULL = 1 / 0
+ *                     with `momentum` and the unbiased variance, *num_batches_tracked (int64, may be NULL) += 1;
+ *                     weight / bias NULL = 1 / 0
  *   se3_affine_act    y = act((x - center[c]) * scale[c] + shift[c]); center / scale / shift may be NULL (0 / 1 / 0);
  *                     act 0 = none, 1 = exact-erf GELU: eval-mode batch norm (center = running mean, scale = weight /
  *                     sqrt(running var + eps), shift = bias), bias + GELU behind a bias-free GEMM
  *   se3_bn_bwd        dbeta[c] = sum dy, dgamma[c] = sum dy * xhat, dx = gamma * invstd * (dy - dbeta/N - xhat * dgamma/N)
  *                     with xhat = (x - mean) * invstd  (gamma NULL = 1)
- *   se3_skip_fwd      out = x * gamma[c] * gate[row_batch[r]] + y   (gate NULL: no drop path; the caller folds 1/keep
- *                     into gate)
+ *   se3_skip_fwd      out = x * gamma[c] * factor(row_batch[r]) + y.  gate NULL: factor 1 (no drop path); gate_keep == 0:
+ *                     factor = gate[b] (the caller built floor(keep + u) / keep); gate_keep = keep_prob > 0: gate holds
+ *                     the uniform draws u themselves (torch.rand, DropPathPC.py:38) and factor = floor(keep + u) *
+ *                     float(1 / keep) is evaluated in the kernel -- torch's add / floor / div launches folded in
  *   se3_skip_bwd      dx = g * gamma[c] * gate (dx may be NULL), dgamma[c] = sum_r g * x * gate   (dy = g)
  *   se3_bias_gelu_bwd dz = g * GELU'(z + bias), dbias[c] = sum_r dz   (bias NULL = 0)
  *   se3_linear_wgrad  grad_w[n_out, n_in] = grad_y[rows, n_out]^T x[rows, n_in]: the weight gradient of the block's
@@ -375,18 +378,18 @@ int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, i
  * ------------------------------------------------------------------------------------------- */
 size_t se3_glue_workspace_bytes(int32_t c);
 int se3_bn_fwd(const float* x, const float* weight, const float* bias, int64_t rows, int32_t c, float eps, float momentum,
-               float* running_mean, float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
-               size_t workspace_bytes, void* stream);
+               float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y, float* save_mean,
+               float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
 int se3_affine_act(const float* x, const float* center, const float* scale, const float* shift, int64_t rows, int32_t c,
                    int32_t act, float* y, void* stream);
 int se3_bn_bwd(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
                int64_t rows, int32_t c, float* dx, float* dgamma, float* dbeta, void* workspace,
                size_t workspace_bytes, void* stream);
-int se3_skip_fwd(const float* x, const float* y, const float* gamma, const float* gate, const int32_t* row_batch,
-                 int64_t rows, int32_t c, float* out, void* stream);
-int se3_skip_bwd(const float* g, const float* x, const float* gamma, const float* gate, const int32_t* row_batch,
-                 int64_t rows, int32_t c, float* dx, float* dgamma, void* workspace, size_t workspace_bytes,
-                 void* stream);
+int se3_skip_fwd(const float* x, const float* y, const float* gamma, const float* gate, float gate_keep,
+                 const int32_t* row_batch, int64_t rows, int32_t c, float* out, void* stream);
+int se3_skip_bwd(const float* g, const float* x, const float* gamma, const float* gate, float gate_keep,
+                 const int32_t* row_batch, int64_t rows, int32_t c, float* dx, float* dgamma, void* workspace,
+                 size_t workspace_bytes, void* stream);
 int se3_bias_gelu_bwd(const float* g, const float* z, const float* bias, int64_t rows, int32_t c, float* dz,
                       float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 size_t se3_linear_wgrad_workspace_bytes(int64_t rows, int32_t n_out, int32_t n_in);

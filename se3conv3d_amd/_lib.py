@@ -75,11 +75,11 @@ SIGNATURES = {
     "se3_knn_query_grid": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_size_t, _P]),
     "se3_pca_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_glue_workspace_bytes": (_SZ, [_I32]),
-    "se3_bn_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "se3_bn_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "se3_affine_act": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _SZ, _P]),
-    "se3_skip_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
-    "se3_skip_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),
+    "se3_skip_fwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _I64, _I32, _P, _P]),
+    "se3_skip_bwd": (C.c_int, [_P, _P, _P, _P, _F, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),
     "se3_bias_gelu_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _SZ, _P]),
     "se3_linear_wgrad_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
     "se3_linear_wgrad": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),

@@ -60,14 +60,15 @@ class SkipConnection(torch.nn.Module):
         if not _fused(p_x) or p_x.shape != p_y.shape:
             return self.drop_path_(p_x * self.gamma_, p_pc) + p_y
         gate = ids = None
+        keep = 0.0
         if self.drop_path_.drop_prob_ != 0.0 and self.training:
             keep = 1.0 - self.drop_path_.drop_prob_
-            # the same draw as DropPathPC: floor(keep + u) per batch element, with the 1 / keep scale folded in
-            gate = torch.floor(keep + torch.rand((_num_batches(p_pc),), dtype=p_x.dtype, device=p_x.device)) / keep
+            # the same draw as DropPathPC (one uniform per batch element); floor(keep + u) / keep is evaluated in the kernel
+            gate = torch.rand((_num_batches(p_pc),), dtype=p_x.dtype, device=p_x.device)
             ids = getattr(p_pc, "batch_ids_considering_frames_", None)
             if ids is None:
                 ids = p_pc.batch_ids_
-        return ops.SkipDropPath.apply(p_x, p_y, self.gamma_, gate, ids)
+        return ops.SkipDropPath.apply(p_x, p_y, self.gamma_, gate, ids, keep)
 
 
 class NormLayerPC(torch.nn.Module):
@@ -85,8 +86,8 @@ class BatchNormPC(NormLayerPC):
         bn = self.layer_
         if not (_fused(p_x) and bn.training and bn.track_running_stats and bn.momentum is not None):
             return bn(p_x)
-        bn.num_batches_tracked.add_(1)
-        return ops.BatchNormTrain.apply(p_x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        return ops.BatchNormTrain.apply(p_x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                        bn.num_batches_tracked)
 
 
 class Block(PreProcessModule):

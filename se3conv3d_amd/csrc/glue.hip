@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256) void reduce_channel_partials_kernel(const doub
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, int n_blocks, int c,
                                                            int64_t rows, const float* __restrict__ weight, float eps,
                                                            float momentum, float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, float* __restrict__ mean,
-                                                           float* __restrict__ invstd, float* __restrict__ scale) {
+                                                           float* __restrict__ running_var,
+                                                           int64_t* __restrict__ num_batches_tracked,
+                                                           float* __restrict__ mean, float* __restrict__ invstd,
+                                                           float* __restrict__ scale) {
   __shared__ double red[256];
   const int ch = blockIdx.x;
   double s = 0.0, ss = 0.0;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   scale[ch] = (weight ? weight[ch] : 1.0f) * is;
   if (running_mean) running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * (float)mu;
   if (running_var) running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)(rows > 1 ? var * n / (n - 1.0) : var);
+  if (num_batches_tracked && ch == 0) *num_batches_tracked += 1;  // BatchNorm1d's own counter (one launch less than add_(1))
 }
 
 template <int VEC>
@@ -236,10 +239,20 @@ __global__ __launch_bounds__(kGlueThreads) void bn_bwd_apply_kernel(const float*
 }
 
 // out = x * gamma[c] * gate[batch(row)] + y;   gate = NULL: no drop path (eval mode or drop probability 0)
+// drop-path factor of a row: gate_keep == 0: gate[b] is the factor itself; gate_keep > 0: gate[b] is the uniform draw u of
+// DropPathPC.py:38-41 and the factor is floor(keep + u) * (1 / keep) -- torch's add, floor and div launches folded in
+__device__ __forceinline__ float gate_factor(const float* __restrict__ gate, float gate_keep, float gate_scale,
+                                             const int32_t* __restrict__ row_batch, int64_t r) {
+  if (!gate) return 1.0f;
+  const float u = gate[row_batch[r]];
+  return gate_keep > 0.f ? floorf(gate_keep + u) * gate_scale : u;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kGlueThreads) void skip_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                  const float* __restrict__ gamma,
-                                                                 const float* __restrict__ gate,
+                                                                 const float* __restrict__ gate, float gate_keep,
+                                                                 float gate_scale,
                                                                  const int32_t* __restrict__ row_batch, int64_t rows,
                                                                  int c, float* __restrict__ out) {
   const RowWalk w = row_walk<VEC>(c);
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(kGlueThreads) void skip_fwd_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < VEC; ++i) ga[i] = gamma[w.col + i];
   for (int64_t r = (int64_t)blockIdx.x * w.rpb + w.row0; r < rows; r += (int64_t)gridDim.x * w.rpb) {
-    const float gt = gate ? gate[row_batch[r]] : 1.0f;
+    const float gt = gate_factor(gate, gate_keep, gate_scale, row_batch, r);
     float a[VEC], b[VEC];
     load_vec<VEC>(x + r * c + w.col, a);
     load_vec<VEC>(y + r * c + w.col, b);
@@ -262,7 +275,8 @@ __global__ __launch_bounds__(kGlueThreads) void skip_fwd_kernel(const float* __r
 template <int VEC>
 __global__ __launch_bounds__(kGlueThreads) void skip_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                  const float* __restrict__ gamma,
-                                                                 const float* __restrict__ gate,
+                                                                 const float* __restrict__ gate, float gate_keep,
+                                                                 float gate_scale,
                                                                  const int32_t* __restrict__ row_batch, int64_t rows,
                                                                  int c, float* __restrict__ dx,
                                                                  double* __restrict__ partials) {
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(kGlueThreads) void skip_bwd_kernel(const float* __r
   for (int i = 0; i < VEC; ++i) acc[0][i] = 0.0, ga[i] = w.row0 >= 0 ? gamma[w.col + i] : 0.f;
   if (w.row0 >= 0)
     for (int64_t r = (int64_t)blockIdx.x * w.rpb + w.row0; r < rows; r += (int64_t)gridDim.x * w.rpb) {
-      const float gt = gate ? gate[row_batch[r]] : 1.0f;
+      const float gt = gate_factor(gate, gate_keep, gate_scale, row_batch, r);
       float gv[VEC], xv[VEC];
       load_vec<VEC>(g + r * c + w.col, gv);
       load_vec<VEC>(x + r * c + w.col, xv);
@@ -347,8 +361,8 @@ extern "C" size_t se3_glue_workspace_bytes(int32_t c) {
   } while (0)
 
 extern "C" int se3_bn_fwd(const float* x, const float* weight, const float* bias, int64_t rows, int32_t c, float eps,
-                          float momentum, float* running_mean, float* running_var, float* y, float* save_mean,
-                          float* save_invstd, void* workspace, size_t workspace_bytes, void* stream_) {
+                          float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* y,
+                          float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream_) {
   if (!glue_shape_ok(rows, c) || !save_mean || !save_invstd || !workspace || (rows > 0 && (!x || !y)))
     return SE3_ERR_INVALID_ARGUMENT;
   if (c > kGlueThreads && c % 4 != 0) return SE3_ERR_UNSUPPORTED;
@@ -360,7 +374,8 @@ extern "C" int se3_bn_fwd(const float* x, const float* weight, const float* bias
   float* scale = (float*)((char*)workspace + (size_t)2 * kGlueMaxBlocks * c * sizeof(double));
   SE3_GLUE_DISPATCH(bn_stats_kernel, x, rows, (int)c, partials);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, stream, (const double*)partials, blocks,
-                     (int)c, rows, weight, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale);
+                     (int)c, rows, weight, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd,
+                     scale);
   if (rows > 0)
     SE3_GLUE_DISPATCH(affine_act_kernel, x, (const float*)save_mean, (const float*)scale, bias, rows, (int)c, 0, y);
   return check_launch();
@@ -396,7 +411,7 @@ extern "C" int se3_bn_bwd(const float* dy, const float* x, const float* mean, co
   return check_launch();
 }
 
-extern "C" int se3_skip_fwd(const float* x, const float* y, const float* gamma, const float* gate,
+extern "C" int se3_skip_fwd(const float* x, const float* y, const float* gamma, const float* gate, float gate_keep,
                             const int32_t* row_batch, int64_t rows, int32_t c, float* out, void* stream_) {
   if (!glue_shape_ok(rows, c)) return SE3_ERR_INVALID_ARGUMENT;
   if (c > kGlueThreads && c % 4 != 0) return SE3_ERR_UNSUPPORTED;
@@ -404,11 +419,12 @@ extern "C" int se3_skip_fwd(const float* x, const float* y, const float* gamma, 
   if (!x || !y || !out || !gamma || (gate && !row_batch)) return SE3_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
   const int vec = glue_vec(c), blocks = glue_blocks(rows, c, vec);
-  SE3_GLUE_DISPATCH(skip_fwd_kernel, x, y, gamma, gate, row_batch, rows, (int)c, out);
+  SE3_GLUE_DISPATCH(skip_fwd_kernel, x, y, gamma, gate, gate_keep, gate_keep > 0.f ? 1.0f / gate_keep : 1.0f,
+                    row_batch, rows, (int)c, out);
   return check_launch();
 }
 
-extern "C" int se3_skip_bwd(const float* g, const float* x, const float* gamma, const float* gate,
+extern "C" int se3_skip_bwd(const float* g, const float* x, const float* gamma, const float* gate, float gate_keep,
                             const int32_t* row_batch, int64_t rows, int32_t c, float* dx, float* dgamma, void* workspace,
                             size_t workspace_bytes, void* stream_) {
   if (!glue_shape_ok(rows, c) || !gamma || !dgamma || !workspace || (rows > 0 && (!g || !x || (gate && !row_batch))))
@@ -418,7 +434,8 @@ extern "C" int se3_skip_bwd(const float* g, const float* x, const float* gamma, 
   hipStream_t stream = (hipStream_t)stream_;
   const int vec = glue_vec(c), blocks = glue_blocks(rows, c, vec);
   double* partials = (double*)workspace;
-  SE3_GLUE_DISPATCH(skip_bwd_kernel, g, x, gamma, gate, row_batch, rows, (int)c, dx, partials);
+  SE3_GLUE_DISPATCH(skip_bwd_kernel, g, x, gamma, gate, gate_keep, gate_keep > 0.f ? 1.0f / gate_keep : 1.0f,
+                    row_batch, rows, (int)c, dx, partials);
   return finish_channel_sums(partials, blocks, c, 1, dgamma, nullptr, stream);
 }
 

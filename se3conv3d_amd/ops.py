@@ -808,7 +808,7 @@ class BatchNormTrain(torch.autograd.Function):
     a fixed order, running statistics updated in place, 3 launches forward and 3 backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, num_batches_tracked=None):
         lib = _lib.load()
         f32 = torch.float32
         x2 = _as(x, f32)
@@ -824,12 +824,14 @@ class BatchNormTrain(torch.autograd.Function):
         ws = _glue_ws(c, dev)
         _lib.check(lib.se3_bn_fwd(_ptr(x2, f32, "x"), _ptr(w, f32, "weight", dev), _ptr(b, f32, "bias", dev), rows, c,
                                   float(eps), float(momentum), _ptr(running_mean, f32, "running_mean", dev),
-                                  _ptr(running_var, f32, "running_var", dev), _ptr(y, f32, "y"), _ptr(mean, f32, "mean"),
+                                  _ptr(running_var, f32, "running_var", dev),
+                                  _ptr(num_batches_tracked, torch.int64, "num_batches_tracked", dev), _ptr(y, f32, "y"),
+                                  _ptr(mean, f32, "mean"),
                                   _ptr(invstd, f32, "invstd"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)),
                    "se3_bn_fwd")
         ctx.save_for_backward(x2, w if w is not None else torch.empty(0, device=dev), mean, invstd)
         ctx.has_w = w is not None
-        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var) if t is not None])
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, num_batches_tracked) if t is not None])
         return y
 
     @staticmethod
@@ -849,16 +851,17 @@ class BatchNormTrain(torch.autograd.Function):
                                   _ptr(dx, f32, "dx"), _ptr(dgamma, f32, "dgamma"), _ptr(dbeta, f32, "dbeta"),
                                   C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)), "se3_bn_bwd")
         ng = ctx.needs_input_grad
-        return (dx if ng[0] else None, dgamma if ng[1] else None, dbeta if ng[2] else None, None, None, None, None)
+        return (dx if ng[0] else None, dgamma if ng[1] else None, dbeta if ng[2] else None, None, None, None, None, None)
 
 
 class SkipDropPath(torch.autograd.Function):
     """``drop_path(x * gamma_) + y`` of layers/SkipConnection.py with the per-batch gate of layers/DropPathPC.py:30-46
-    (``gate [B]`` already holds keep-mask / keep_prob, ``row_batch [rows]`` int32 maps rows to batch elements; both
-    None: no drop path) -- one launch forward, two backward."""
+    (``gate [B]`` holds keep-mask / keep_prob -- or, with ``gate_keep = keep_prob > 0``, the uniform draws themselves, the
+    kernel then evaluates floor(keep + u) / keep; ``row_batch [rows]`` int32 maps rows to batch elements; both None: no drop
+    path) -- one launch forward, two backward."""
 
     @staticmethod
-    def forward(ctx, x, y, gamma, gate, row_batch):
+    def forward(ctx, x, y, gamma, gate, row_batch, gate_keep=0.0):
         lib = _lib.load()
         f32, i32 = torch.float32, torch.int32
         x2, y2 = _as(x, f32), _as(y, f32)
@@ -873,11 +876,11 @@ class SkipDropPath(torch.autograd.Function):
             raise ValueError("SkipDropPath: one batch id per row expected")
         out = torch.empty_like(x2)
         _lib.check(lib.se3_skip_fwd(_ptr(x2, f32, "x"), _ptr(y2, f32, "y", dev), _ptr(ga, f32, "gamma", dev),
-                                    _ptr(gt, f32, "gate", dev), _ptr(rb, i32, "row_batch", dev), rows, c,
+                                    _ptr(gt, f32, "gate", dev), float(gate_keep), _ptr(rb, i32, "row_batch", dev), rows, c,
                                     _ptr(out, f32, "out"), _stream(dev)), "se3_skip_fwd")
         ctx.save_for_backward(x2, ga, gt if gt is not None else torch.empty(0, device=dev),
                               rb if rb is not None else torch.empty(0, dtype=i32, device=dev))
-        ctx.gated, ctx.gamma_shape = gt is not None, gamma.shape
+        ctx.gated, ctx.gamma_shape, ctx.gate_keep = gt is not None, gamma.shape, float(gate_keep)
         return out
 
     @staticmethod
@@ -893,10 +896,10 @@ class SkipDropPath(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=f32, device=dev)
         ws = _glue_ws(c, dev)
         _lib.check(lib.se3_skip_bwd(_ptr(g2, f32, "g", dev), _ptr(x2, f32, "x"), _ptr(ga, f32, "gamma"),
-                                    _ptr(gt if ctx.gated else None, f32, "gate"), _ptr(rb if ctx.gated else None, i32, "row_batch"),
-                                    rows, c, _ptr(dx, f32, "dx"), _ptr(dgamma, f32, "dgamma"), C.c_void_p(ws.data_ptr()),
+                                    _ptr(gt if ctx.gated else None, f32, "gate"), ctx.gate_keep,
+                                    _ptr(rb if ctx.gated else None, i32, "row_batch"), rows, c, _ptr(dx, f32, "dx"), _ptr(dgamma, f32, "dgamma"), C.c_void_p(ws.data_ptr()),
                                     ws.numel(), _stream(dev)), "se3_skip_bwd")
-        return dx, (g2 if ng[1] else None), (dgamma.reshape(ctx.gamma_shape) if ng[2] else None), None, None
+        return dx, (g2 if ng[1] else None), (dgamma.reshape(ctx.gamma_shape) if ng[2] else None), None, None, None
 
 
 class BiasGelu(torch.autograd.Function):

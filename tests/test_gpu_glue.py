@@ -30,7 +30,9 @@ def test_batch_norm_train_matches_torch(amd, rows, c):
     g = torch.randn(rows, c, device=DEV)
     rm, rv = torch.randn(c, device=DEV), torch.rand(c, device=DEV) + 0.5
     rm_ref, rv_ref = rm.clone(), rv.clone()
-    y = amd.ops.BatchNormTrain.apply(x, w, b, rm, rv, 0.2, 1e-5)
+    tracked = torch.full((), 41, dtype=torch.int64, device=DEV)   # BatchNorm1d.num_batches_tracked: += 1 inside the op
+    y = amd.ops.BatchNormTrain.apply(x, w, b, rm, rv, 0.2, 1e-5, tracked)
+    assert int(tracked) == 42
     if rows == 0:
         assert y.shape == (0, c)
         return
@@ -59,11 +61,15 @@ def test_skip_with_drop_path_gate_matches_torch(amd, rows, c, frames, batches):
     pt_batch = torch.sort(torch.randint(0, batches, (rows // frames,), device=DEV)).values.to(torch.int32)
     row_batch = pt_batch.repeat_interleave(frames)            # batch_ids_considering_frames_
     keep = 0.7
-    gate = torch.floor(keep + torch.rand(batches, device=DEV)) / keep
-    for use_gate in (True, False):
+    u = torch.rand(batches, device=DEV)
+    gate = torch.floor(keep + u) / keep
+    for use_gate in (True, "in-kernel", False):   # "in-kernel": the op gets the uniform draws and keep_prob
         for t in (x, y, gamma):
             t.grad = None
-        out = amd.ops.SkipDropPath.apply(x, y, gamma, gate if use_gate else None, row_batch if use_gate else None)
+        if use_gate == "in-kernel":
+            out = amd.ops.SkipDropPath.apply(x, y, gamma, u, row_batch, keep)
+        else:
+            out = amd.ops.SkipDropPath.apply(x, y, gamma, gate if use_gate else None, row_batch if use_gate else None)
         x2, y2, ga2 = (t.detach().clone().requires_grad_(True) for t in (x, y, gamma))
         ref = x2 * ga2
         if use_gate:
