@@ -85,7 +85,12 @@ typedef struct se3conv_shape {
 #define SE3_PRECISION_FP32 0
 #define SE3_PRECISION_BF16X3 1
 
-/* Library / build identification. */
+/* Library / build identification.  SE3_ABI_VERSION changes whenever an entry point's signature does: 2 = round 3
+ * (se3_skip_fwd / se3_skip_bwd take gate_keep, se3_bn_fwd takes num_batches_tracked; entry points added since 1:
+ * se3_knn_query_pair, se3_grid_pick, se3_rows_gather / _scatter, se3_rot_tensors_rel, se3_csr_transpose_bounded,
+ * se3_side_stream_stats, se3_linear_wgrad).  A binding should compare se3_abi_version() with the header it was written
+ * against (se3conv3d_amd/_lib.py does). */
+#define SE3_ABI_VERSION 2
 int se3_abi_version(void);
 const char* se3_error_string(int code);
 /* Bytes per element of the row-sized intermediates [rows, C, K] the operator moves through memory for this shape --

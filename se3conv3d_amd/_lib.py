@@ -11,6 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", f"libse3conv_hip{os.environ.get('SE3_LIB_SUFFIX', '')}.so")  # suffix: variant builds, see build.py
 
 SE3_OK = 0
+ABI_VERSION = 2  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 REL_ROT = {"6D": (0, 9), "matrix": (1, 12), "quaternion": (2, 7)}  # p_rel_rot -> (SE3_REL_ROT_*, descriptor dims)
 
@@ -107,6 +108,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.se3_abi_version() != ABI_VERSION:
+        raise Se3LibraryError(f"{LIB_PATH} has ABI version {lib.se3_abi_version()}, this binding expects {ABI_VERSION}: "
+                              "rebuild it (`python -m se3conv3d_amd.build`)")
     _lib = lib
     return lib
 

@@ -516,7 +516,7 @@ EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* fr
 
 using namespace se3;
 
-extern "C" int se3_abi_version(void) { return 1; }
+extern "C" int se3_abi_version(void) { return SE3_ABI_VERSION; }
 
 extern "C" const char* se3_error_string(int code) {
   switch (code) {

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built_library):
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
     for name in syms:
         assert hasattr(lib, name), f"{name} declared in se3conv.h but not exported"
-    assert _lib.load().se3_abi_version() == 1
+    assert _lib.load().se3_abi_version() == _lib.ABI_VERSION == 2   # the binding refuses a library of another version
 
 
 def test_host_side_argument_checks(built_library):
