@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
                                                              const float* __restrict__ rho_p,
                                                              uint32_t* __restrict__ t_out, int64_t n_items,
                                                              int fnb_shift) {
-  static_assert(!T24 || VW == 1, "3-byte rows need adjacent channels in accumulator registers r, r + 1");
+  static_assert(!T24 || VW <= 2, "3-byte rows need the two channels of a pair in one lane (edge_bf16_body.h)");
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
   if (threadIdx.x < 64) mlp_weights_to_lds<FC>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
@@ -878,15 +878,24 @@ int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t st
   return check_launch();
 }
 
-bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels) {
-  return channels >= 64 && getenv("SE3_NO_PAIR") == nullptr;
+// Which kernel a shape takes: the wave pair for rows of >= 64 channels -- except 64-channel rows with an odd frame count
+// (ScanNet's F = 1), where both wavefronts of a pair would evaluate every descriptor for half the aggregation work each:
+// the single-wavefront kernel at two channels per lane is 5 % faster there since it is pipelined like the pair
+// (profiles/r03_f1_forms_ab.txt).  SE3_NO_PAIR=1: the single-wavefront kernel everywhere.
+static bool edge_t_bf16_uses_pair(const EdgeGeom& g, int channels) {
+  return channels >= 64 && getenv("SE3_NO_PAIR") == nullptr && !(channels == 64 && g.f_ctr % 2 == 1);
 }
 
-// Which launches can write their rows in the 3-byte format: the wave-pair kernel, and the single-wavefront kernel at
-// one channel per lane (rows of up to 32 channels, DFaust's first level), whose accumulator registers r, r + 1 are
-// adjacent channels
+// row ranges (producer / consumer interleaving over slices of the rows): the wave-pair kernel only
+bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels) { return edge_t_bf16_uses_pair(g, channels); }
+
+// Which launches can write their rows in the 3-byte format: the wave-pair kernel, and the single-wavefront kernel at one
+// or two channels per lane (rows of up to 32 channels, and the 64-channel rows it takes), where the two channels of a
+// pair are values of one lane
 bool edge_t_bf16_t24_rows(const EdgeGeom& g, int channels) {
-  return channels % 2 == 0 && (edge_t_bf16_row_ranges(g, channels) || channels <= 32);
+  if (channels % 2 != 0) return false;
+  if (edge_t_bf16_uses_pair(g, channels)) return true;
+  return channels <= 32 || channels == 64;
 }
 
 // row_lo / row_hi (multiples of 2 for even F; < 0: everything): only the rows in that range are produced -- the
@@ -909,8 +918,8 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   for (int sft = 0; sft < 8; ++sft)
     if ((1 << sft) == g.f_nb) shift = sft;
   const dim3 block(256);
-  if (channels >= 64 && getenv("SE3_NO_PAIR") == nullptr) {
-    // a 128-thread workgroup per two frames of a point (even F) or per single row (odd F, e.g. ScanNet's F = 1)
+  if (edge_t_bf16_uses_pair(g, channels)) {
+    // a 128-thread workgroup per two frames of a point (even F) or per single row (odd F)
     const bool two = g.f_ctr % 2 == 0;
     const int64_t pair_items = two ? rows / 2 : rows;
     // persistent blocks: enough to fill every CU at the kernel's occupancy, each walking a strided set of items
@@ -953,21 +962,21 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
 #define SE3_LAUNCH(VW, FC, FULL, T24)                                                                                 \
   hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL, T24>), grid, block, 0, stream, g, feat, channels, feat_rows,     \
                      axes_ext, rho, t_out, items, shift)
-#define SE3_LAUNCH1(FC, FULL)                        \
+#define SE3_LAUNCH_T(VW, FC, FULL)                   \
   do {                                               \
-    if (t24) SE3_LAUNCH(1, FC, FULL, true);          \
-    else SE3_LAUNCH(1, FC, FULL, false);             \
+    if (t24) SE3_LAUNCH(VW, FC, FULL, true);         \
+    else SE3_LAUNCH(VW, FC, FULL, false);            \
   } while (0)
   if (channels % 128 == 0) {
     SE3_LAUNCH(4, 1, true, false);
   } else if (channels % 64 == 0) {
-    if (fc == 2) SE3_LAUNCH(2, 2, true, false); else SE3_LAUNCH(2, 1, true, false);
+    if (fc == 2) SE3_LAUNCH_T(2, 2, true); else SE3_LAUNCH_T(2, 1, true);
   } else if (channels % 32 == 0) {
-    if (fc == 2) SE3_LAUNCH1(2, true); else SE3_LAUNCH1(1, true);
+    if (fc == 2) SE3_LAUNCH_T(1, 2, true); else SE3_LAUNCH_T(1, 1, true);
   } else {
-    if (fc == 2) SE3_LAUNCH1(2, false); else SE3_LAUNCH1(1, false);
+    if (fc == 2) SE3_LAUNCH_T(1, 2, false); else SE3_LAUNCH_T(1, 1, false);
   }
-#undef SE3_LAUNCH1
+#undef SE3_LAUNCH_T
 #undef SE3_LAUNCH
   return check_launch();
 }

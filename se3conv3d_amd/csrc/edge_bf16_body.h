@@ -206,22 +206,37 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
         }
       }
     }
-    // acc[a][t] register r, lane (kcol, h) = T[row a][cbase + VW*acc_row(r,h) + t][kcol]; registers r, r + 1 (r even) are
-    // channels ch0 and ch0 + VW: with VW = 1 an adjacent pair, which is what the 3-byte row format stores together
+    // acc[a][t] register r, lane (kcol, h) = T[row a][cbase + VW*acc_row(r,h) + t][kcol].  The values go to the sink in
+    // pairs of ADJACENT channels where the layout has them in one lane (what the 3-byte row format stores together):
+    // registers r, r + 1 of one tile at one channel per lane (VW = 1), tiles 0 and 1 of one register at two (VW = 2).
 #pragma unroll
-    for (int a = 0; a < FC; ++a)
+    for (int a = 0; a < FC; ++a) {
+      if constexpr (VW == 2) {
 #pragma unroll
-      for (int t = 0; t < VW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
+        for (int r = 0; r < 16; ++r) {
+          const int ch0 = cbase + 2 * acc_row(r, h);
 #if SE3_ABLATE_MASK & 8
-          asm volatile("" ::"v"(acc[a][t][r]), "v"(acc[a][t][r + 1]));
-          if (__float_as_uint(acc[a][t][r]) == 0x12345678u) sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], true, true);
+          asm volatile("" ::"v"(acc[a][0][r]), "v"(acc[a][1][r]));
+          if (__float_as_uint(acc[a][0][r]) == 0x12345678u) sink(a, ch0, ch0 + 1, acc[a][0][r], acc[a][1][r], true, true);
 #else
-          sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], FULL || ch0 < channels, FULL || ch1 < channels);
+          sink(a, ch0, ch0 + 1, acc[a][0][r], acc[a][1][r], FULL || ch0 < channels, FULL || ch0 + 1 < channels);
 #endif
         }
+      } else {
+#pragma unroll
+        for (int t = 0; t < VW; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
+#if SE3_ABLATE_MASK & 8
+            asm volatile("" ::"v"(acc[a][t][r]), "v"(acc[a][t][r + 1]));
+            if (__float_as_uint(acc[a][t][r]) == 0x12345678u) sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], true, true);
+#else
+            sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], FULL || ch0 < channels, FULL || ch1 < channels);
+#endif
+          }
+      }
+    }
   }
 }
 
