@@ -427,6 +427,10 @@ int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, in
 int gemm_tn_splits(int64_t m, int ka, int n) {
   const int64_t tiles = (int64_t)((ka + 127) / 128) * ((n + BN - 1) / BN);
   int64_t s = 512 / tiles;  // at most 512 workgroups (two per CU): one resident round
+  // rows beyond the reach of one launch's 32-bit operand offsets are walked as several groups of ranges (gemm_bf16.hip):
+  // a round's worth of ranges for every group
+  const int64_t reach_rows = ((1ll << 32) - 64) / ((int64_t)(ka > n ? ka : n) * 4);
+  if (s >= 1 && m > reach_rows) s *= (4 * m + 3 * reach_rows - 1) / (3 * reach_rows);
   const int64_t max_s = (m + 255) / 256;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;

@@ -837,11 +837,9 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
   return check_launch();
 }
 
-int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
-                        bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
-                        float alpha_scale, hipStream_t stream, bool a24, ReduceBatch* defer) {
-  if (m == 0 || n == 0) return SE3_OK;
-  ProfScope prof(tag, stream);
+static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c, bool out_packed,
+                             int64_t m, int n, int k, float* split_ws, const float* alpha_num, float alpha_scale,
+                             hipStream_t stream, bool a24, ReduceBatch* defer) {
   const int kp = (k + 31) / 32 * 32;
   const int nkt = kp / BK;
   int splits = split_ws ? gemm_nn_bf16_splits(m, n, k) : 1;
@@ -893,6 +891,28 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
   return check_launch();
 }
 
+// The kernels address A with 32-bit byte offsets (buffer loads): more rows than those reach -- 262 k rows of 2048 values
+// and up, i.e. clouds beyond ~130 k points at two frames -- go through the same kernels row block by row block (no split
+// of k at that size, so the blocks share nothing but the weights).
+int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
+                        bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
+                        float alpha_scale, hipStream_t stream, bool a24, ReduceBatch* defer) {
+  if (m == 0 || n == 0) return SE3_OK;
+  ProfScope prof(tag, stream);
+  const int64_t max_rows = (((1ll << 32) - 64) / ((int64_t)k * 4) - 2 * BM) / BM * BM;
+  if (m <= max_rows || max_rows < BM || k % 32 != 0)
+    return gemm_nn_bf16_rows(a, bt_hi, bt_lo, c, out_packed, m, n, k, split_ws, alpha_num, alpha_scale, stream, a24, defer);
+  const int64_t a_row_bytes = (int64_t)k * (a24 ? 3 : 4);
+  for (int64_t m0 = 0; m0 < m; m0 += max_rows) {
+    const int64_t mb = m - m0 < max_rows ? m - m0 : max_rows;
+    if (int rc = gemm_nn_bf16_rows(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a) + m0 * a_row_bytes), bt_hi,
+                                   bt_lo, static_cast<char*>(c) + m0 * (int64_t)n * 4, out_packed, mb, n, k, nullptr, alpha_num,
+                                   alpha_scale, stream, a24, nullptr))
+      return rc;
+  }
+  return SE3_OK;
+}
+
 size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k) {
   const int s = gemm_nn_bf16_splits(m, n, k);
   return s > 1 ? (size_t)s * m * n * 4 : 0;
@@ -906,16 +926,33 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
   int64_t chunk = (m + splits - 1) / splits;
   chunk = (chunk + BK - 1) / BK * BK;
   if (chunk == 0) chunk = BK;
-  const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)splits);
-  const bool fast = (n % 4 == 0) && ((m + chunk) * (int64_t)ka * 4 < (1ll << 32) - 64) &&
-                    ((m + chunk) * (int64_t)n * 4 < (1ll << 32) - 64);
-  if (a24 && (!fast || ka % 64 != 0)) return SE3_ERR_UNSUPPORTED;
-  if (a24)
-    hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
-  else if (fast)
-    hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
-  else
-    hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, stream, a, b, partials, m, ka, n, chunk);
+  // Both operands are addressed with 32-bit byte offsets from the pointers the kernel gets: row ranges (grid.z) beyond
+  // their reach are launched as further groups of ranges, each with its operands' pointers moved to its first row
+  // (the partials of group j start at range j * zs of the same buffer).
+  const int64_t widest = (int64_t)(ka > n ? ka : n) * 4;
+  int64_t zs = (((1ll << 32) - 64) / widest - chunk) / chunk;  // ranges one launch can address
+  if (zs < 1) zs = 1;
+  if (zs > splits) zs = splits;
+  const bool vec = n % 4 == 0, reach = (zs + 1) * chunk * widest < (1ll << 32) - 64;
+  if (a24 && (!vec || !reach || ka % 64 != 0)) return SE3_ERR_UNSUPPORTED;
+  for (int64_t z0 = 0; z0 < splits; z0 += zs) {
+    const int64_t zn = splits - z0 < zs ? splits - z0 : zs, r0 = z0 * chunk;
+    if (r0 >= m) {  // ranges past the last row (rounding of chunk): their partials are zeros
+      if (hipMemsetAsync(partials + z0 * ka * n, 0, (size_t)(splits - z0) * ka * n * 4, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+      break;
+    }
+    const int64_t mb = m - r0 < zn * chunk ? m - r0 : zn * chunk;
+    const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)zn);
+    const uint32_t* ab = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a) + r0 * (int64_t)ka * (a24 ? 3 : 4));
+    const uint32_t* bb = b + r0 * n;
+    float* pb = partials + z0 * ka * n;
+    if (a24)
+      hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
+    else if (vec && reach)
+      hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
+    else
+      hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
+  }
   if (defer) {
     defer->sum(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, false);
     return check_launch();
