@@ -32,11 +32,12 @@ def _run(amd, pts, batch, frames_t, conv, x, g, radius):
     return out.detach(), x.grad.detach(), [p.grad.detach().clone() for p in conv.parameters()]
 
 
-@pytest.mark.parametrize("n,frames", [(140_000, 2)])   # 2 x 280 000 = 560 000 rows: above both row limits
-def test_two_copies_of_a_body_equal_the_body_alone(n, frames):
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])   # fp32: beyond the reach of its buffer-load forms too
+@pytest.mark.parametrize("n,frames", [(140_000, 2)])         # 2 x 280 000 = 560 000 rows: above both row limits
+def test_two_copies_of_a_body_equal_the_body_alone(n, frames, precision):
     import se3conv3d_amd as amd
     from se3conv3d_amd.workloads import radius_for_degree
-    amd.set_precision("bf16x3")
+    amd.set_precision(precision)
     c = 64
     pts, fr = _body(amd, n, frames, 5)
     radius = radius_for_degree(n, 24)
@@ -60,3 +61,4 @@ def test_two_copies_of_a_body_equal_the_body_alone(n, frames):
         assert rel_err(part, dx1) < 2e-6
     for a, b in zip(gp2, gp1):
         assert rel_err(a, 2.0 * b) < 2e-5
+    amd.set_precision("bf16x3")
