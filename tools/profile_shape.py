@@ -23,6 +23,9 @@ conv.norm_neigh_dist_.fill_(1.0 / r)
 conv.norm_num_neighs_.fill_(0.03)
 lv = dict(pc=pc, nbh=nbh, conv=conv, x=torch.randn(n * f, ci, device=dev, requires_grad=True),
           g=torch.randn(n * f, co, device=dev), n=n, e=nbh.neighbors_.shape[0], r=r)
-st = bench.profile_level(lib, lv, 5)
+for _ in range(3):
+    bench.step([lv])          # warm-up: lazy builds, allocator, clocks (the first call would dominate a 5-step average)
+torch.cuda.synchronize()
+st = bench.profile_level(lib, lv, 10)
 print(f"N={n} F={f} C={ci}->{co} E={lv['e']}: sum {sum(v[0] for v in st.values()):.3f} ms")
 print("   ", {k: round(v[0], 4) for k, v in sorted(st.items())})
