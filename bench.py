@@ -470,6 +470,23 @@ def run_rank(args):
         result["eager"] = {"ms_per_step": round(ms_eager, 4), "value": mpts(ms_eager),
                            "note": "same step launched from Python every iteration (no graph replay)"}
 
+        # inference: the forward pass of the same stack alone (eval mode, no autograd graph, T in the workspace)
+        def forward_only(lvls):
+            with torch.no_grad():
+                for lv in lvls:
+                    lv["conv"](p_pc_in=lv["pc"], p_pc_out=lv["pc"], p_in_features=lv["x"], p_neighborhood=lv["nbh"])
+
+        try:
+            for lv in levels:
+                lv["conv"].eval()
+            run_fwd = (lambda: forward_only(levels)) if args.no_graph else GraphedStep(levels, fn=forward_only)
+            ms_fwd = timed(run_fwd, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
+            result["forward_only"] = {"ms_per_step": round(ms_fwd, 4), "value": mpts(ms_fwd), "unit": "Mpoints/s",
+                                      "note": "forward pass of the same stack alone (inference: eval mode, torch.no_grad)"}
+        finally:
+            for lv in levels:
+                lv["conv"].train()
+
         # "end-to-end" number of SURVEY.md section 8d: the conv step plus the per-step neighbourhood work of the levels.
         # Ball queries go into capacity-bounded edge buffers (1.25 x the known edge count; the edge count stays on the
         # device), so the whole thing -- 4 ball queries + 4 x (forward + backward) -- has no host synchronisation and
