@@ -483,6 +483,8 @@ def run_rank(args):
             ms_fwd = timed(run_fwd, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
             result["forward_only"] = {"ms_per_step": round(ms_fwd, 4), "value": mpts(ms_fwd), "unit": "Mpoints/s",
                                       "note": "forward pass of the same stack alone (inference: eval mode, torch.no_grad)"}
+        except RuntimeError as exc:  # an extra leg must not take the line down with it
+            result["forward_only"] = {"error": str(exc)[:200]}
         finally:
             for lv in levels:
                 lv["conv"].train()
