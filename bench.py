@@ -73,7 +73,9 @@ def launch_ranks(args, argv) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this pool
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # host threads per rank: the ranks share this box's cores (torch.distributed.run would pin 1 thread per rank; the
+    # ranks set their own count from the cores they may use, run_rank)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, usable_cores() // args.gpus))))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
         sys.stdout.write(line)
@@ -227,6 +229,10 @@ def run_rank(args):
     spec = W.WORKLOADS[args.workload]
     n0 = spec["points"] * spec["clouds"]
     dist = None
+    # host side of a rank: building its scene and launching kernels.  N ranks share the box's usable cores (affinity /
+    # cgroup quota), at most 8 threads each (MAX_NUM_THREADS of the reference's task scripts): 8 ranks never oversubscribe
+    cpu_threads = max(1, min(8, usable_cores() // world))
+    torch.set_num_threads(cpu_threads)
     # SE3_BENCH_FORCE_DIST=1: a one-rank job still goes through the process group (RCCL init, barrier, MAX reduce, result
     # gather, graph capture next to a live communicator) -- the rehearsal of the N-rank path a one-GPU box can run
     if world > 1 or os.environ.get("SE3_BENCH_FORCE_DIST") == "1":
@@ -257,7 +263,9 @@ def run_rank(args):
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "dry_run": True,
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "config": {"workload": args.workload}, "scenes": sorted(sums)}), flush=True)
+                              "config": {"workload": args.workload, "cpu_threads_per_rank": cpu_threads},
+                              "scenes": sorted(sums),
+                              "scene_checksums": {str(k): float(v[0]) for k, v in sorted(sums.items())}}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -373,7 +381,7 @@ def run_rank(args):
                    "channels": spec["widths"], "num_basis": W.NUM_BASIS,
                    "level_points": [lv["n"] for lv in levels], "level_edges": [lv["e"] for lv in levels],
                    "mean_degree_level0": round(levels[0]["e"] / levels[0]["n"], 2), "point_order": args.point_order,
-                   "launch": launch,
+                   "launch": launch, "cpu_threads_per_rank": cpu_threads,
                    "sharding": "one scene per rank, no data-path collective" + (" (REHEARSAL: ranks share GPUs)" if args.share_gpu else "")},
     }
 
@@ -483,8 +491,13 @@ def run_rank(args):
             ms_fwd = timed(run_fwd, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
             result["forward_only"] = {"ms_per_step": round(ms_fwd, 4), "value": mpts(ms_fwd), "unit": "Mpoints/s",
                                       "note": "forward pass of the same stack alone (inference: eval mode, torch.no_grad)"}
-        except RuntimeError as exc:  # an extra leg must not take the line down with it
+        except RuntimeError as exc:  # an extra leg must not take the line down with it ...
             result["forward_only"] = {"error": str(exc)[:200]}
+            try:  # ... but the later legs must not be timed on a stream a refused capture left half open
+                torch.cuda.synchronize()
+            except RuntimeError as exc2:
+                raise SystemExit(f"forward_only leg failed ({str(exc)[:120]}) and the device cannot be synchronised "
+                                 f"afterwards ({str(exc2)[:120]}): the remaining legs would time something undefined")
         finally:
             for lv in levels:
                 lv["conv"].train()

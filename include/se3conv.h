@@ -22,7 +22,10 @@
  *     These objects are only ever created by a call whose stream is NOT being captured into a HIP graph:
  *     every eager se3conv_fwd / se3conv_bwd keeps two spare sets per device ready, a capturing stream that
  *     is new to the library takes a spare, and if there is none (no eager call happened before the capture)
- *     the backward pass does not fork -- same results, branches back to back; (3) kernel-variant switches read ONCE from the environment at first
+ *     the backward pass does not fork -- same results, branches back to back (counted: se3_side_stream_stats).  At most 16
+ *     caller streams per device own a set at a time: past that the least recently used set goes back to the spares
+ *     and serves the next new caller stream (never rearranged while a capture is involved), so a process that makes
+ *     a stream per request does not grow the table; (3) kernel-variant switches read ONCE from the environment at first
  *     use (A/B knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP, SE3_OVERLAP_ROWS,
  *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32),
  *     SE3_NN_SPLITS.
@@ -90,7 +93,8 @@ typedef struct se3conv_shape {
  * se3_knn_query_pair, se3_grid_pick, se3_rows_gather / _scatter, se3_rot_tensors_rel, se3_csr_transpose_bounded,
  * se3_side_stream_stats, se3_linear_wgrad).  A binding should compare se3_abi_version() with the header it was written
  * against (se3conv3d_amd/_lib.py does). */
-#define SE3_ABI_VERSION 2
+/* 3 = round 4: se3_side_stream_stats fills FIVE counters (was three). */
+#define SE3_ABI_VERSION 3
 int se3_abi_version(void);
 const char* se3_error_string(int code);
 /* Bytes per element of the row-sized intermediates [rows, C, K] the operator moves through memory for this shape --
@@ -411,9 +415,12 @@ int se3_linear_wgrad(const float* grad_y, const float* x, int64_t rows, int32_t 
  * Off by default.
  * ------------------------------------------------------------------------------------------- */
 int se3_profile_enable(int on);
-/* Introspection of process-wide state (2) above, for tests of the capture contract: stats[0] = caller streams that own
- * an internal side stream, stats[1] = spare (stream, events) sets ready on the current device, stats[2] = sets created
- * so far in this process.  Sets are only created by calls whose stream is NOT being captured. */
+/* Introspection of process-wide state (2) above, for tests of the capture contract and as the diagnostic of a graph
+ * that was captured without an eager step in front of it.  stats[5]: [0] caller streams that own an internal side
+ * stream, [1] spare (stream, events) sets ready on the current device, [2] sets created so far in this process, [3]
+ * backward passes that wanted to fork inside a capture and could not (no set prepared: that graph replays its two
+ * branches back to back -- correct, slower on 4 k - 32 k-row levels), [4] sets the 16-owner cap handed back to the
+ * spares.  Sets are only created by calls whose stream is NOT being captured. */
 int se3_side_stream_stats(int32_t* stats);
 int se3_profile_reset(void);
 int se3_profile_read(const char* tag, double* total_ms, int64_t* launches);

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", f"libse3conv_hip{os.environ.get('SE3_LIB_SUFFIX', '')}.so")  # suffix: variant builds, see build.py
 
 SE3_OK = 0
-ABI_VERSION = 2  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
+ABI_VERSION = 3  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
 PRECISIONS = {"fp32": 0, "bf16x3": 1}
 REL_ROT = {"6D": (0, 9), "matrix": (1, 12), "quaternion": (2, 7)}  # p_rel_rot -> (SE3_REL_ROT_*, descriptor dims)
 

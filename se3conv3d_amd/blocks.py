@@ -57,7 +57,9 @@ class SkipConnection(torch.nn.Module):
         self.gamma_ = torch.nn.Parameter(torch.full((1, p_num_features), float(p_init_gamma)))
 
     def forward(self, p_x, p_y, p_pc):
-        if not _fused(p_x) or p_x.shape != p_y.shape:
+        # drop_prob >= 1 (keep <= 0): the reference divides by zero (DropPathPC.py:45) -- the plain formulation reproduces
+        # that instead of handing the kernel keep = 0, which it reads as "the gate is the factor itself"
+        if not _fused(p_x) or p_x.shape != p_y.shape or (self.training and self.drop_path_.drop_prob_ >= 1.0):
             return self.drop_path_(p_x * self.gamma_, p_pc) + p_y
         gate = ids = None
         keep = 0.0

@@ -337,21 +337,30 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   bool ok = false;
+  uint64_t last_use = 0;  // SideTable::clock at the last fork (LRU order)
 };
 constexpr size_t kSpareSideStreams = 2;
+// At most this many caller streams own a side stream at a time.  A server that makes a stream per request would grow the
+// table without limit otherwise: beyond the cap the least recently used set goes back to the spares (the runtime objects
+// live on and are handed to the next new caller stream).  Never inside a capture -- neither when the caller's stream is
+// being captured (nothing is rearranged then) nor a set whose own stream is part of a capture in progress.
+constexpr size_t kMaxOwnedSideStreams = 16;
 struct SideTable {
   std::mutex mu;
   std::map<std::pair<int, hipStream_t>, SideStream> by_stream;
   std::map<int, std::vector<SideStream>> spare;
+  uint64_t clock = 0;
+  int created = 0;             // (stream, events) sets made so far in this process
+  int unforked_in_capture = 0; // captured backward passes that wanted to fork and had no set to fork onto
+  int evicted = 0;             // sets taken back from a caller stream by the cap
 };
 SideTable& side_table() {
   static SideTable t;
   return t;
 }
-int g_side_streams_created = 0;  // under side_table().mu
-SideStream make_side_stream() {
+SideStream make_side_stream(SideTable& t) {  // t.mu held
   SideStream v;
-  ++g_side_streams_created;
+  ++t.created;
   v.ok = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&v.fork, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&v.join, hipEventDisableTiming) == hipSuccess;
@@ -380,43 +389,83 @@ void keep_side_streams_ready(hipStream_t caller) {
   std::lock_guard<std::mutex> lk(t.mu);
   auto& sp = t.spare[dev];
   while (sp.size() < kSpareSideStreams) {
-    SideStream v = make_side_stream();
+    SideStream v = make_side_stream(t);
     if (!v.ok) break;
     sp.push_back(v);
   }
 }
-SideStream* side_stream_for(hipStream_t caller) {
+// t.mu held, the caller's stream is not being captured: hand the least recently used sets of this device back to the spares
+// until the device owns at most kMaxOwnedSideStreams (sets that are part of a capture in progress stay where they are)
+void evict_side_streams(SideTable& t, int dev) {
+  for (;;) {
+    size_t owned = 0;
+    auto victim = t.by_stream.end();
+    for (auto it = t.by_stream.begin(); it != t.by_stream.end(); ++it) {
+      if (it->first.first != dev || !it->second.ok) continue;
+      ++owned;
+      if (victim == t.by_stream.end() || it->second.last_use < victim->second.last_use) victim = it;
+    }
+    if (owned <= kMaxOwnedSideStreams || victim == t.by_stream.end()) return;
+    if (stream_is_capturing(victim->second.stream)) {  // forked into a capture that has not ended: not now
+      victim->second.last_use = ++t.clock;
+      bool any_idle = false;
+      for (auto& kv : t.by_stream)
+        if (kv.first.first == dev && kv.second.ok && !stream_is_capturing(kv.second.stream)) any_idle = true;
+      if (!any_idle) return;
+      continue;
+    }
+    t.spare[dev].push_back(victim->second);
+    t.by_stream.erase(victim);
+    ++t.evicted;
+  }
+}
+// Returns a COPY of the set (the table may hand the entry to another caller later; the runtime objects are never
+// destroyed), ok = false when there is nothing to fork onto.
+SideStream side_stream_for(hipStream_t caller) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return SideStream{};
   SideTable& t = side_table();
   {
     std::lock_guard<std::mutex> lk(t.mu);
     auto it = t.by_stream.find({dev, caller});
-    if (it != t.by_stream.end()) return it->second.ok ? &it->second : nullptr;
+    if (it != t.by_stream.end()) {
+      it->second.last_use = ++t.clock;
+      return it->second;
+    }
   }
   const bool capturing = stream_is_capturing(caller);
   std::lock_guard<std::mutex> lk(t.mu);
+  auto known = t.by_stream.find({dev, caller});  // another thread of this caller stream got here first
+  if (known != t.by_stream.end()) return known->second;
   SideStream v;
+  auto& sp = t.spare[dev];
   if (capturing) {
-    auto& sp = t.spare[dev];
-    if (sp.empty()) return nullptr;  // nothing prepared outside the capture: no fork
+    if (sp.empty()) {  // nothing prepared outside the capture: no fork (run one eager step first)
+      ++t.unforked_in_capture;
+      return SideStream{};
+    }
+    v = sp.back();
+    sp.pop_back();
+  } else if (sp.size() > kSpareSideStreams) {  // sets the cap took back come first
     v = sp.back();
     sp.pop_back();
   } else {
-    v = make_side_stream();
+    v = make_side_stream(t);
   }
-  auto it = t.by_stream.emplace(std::make_pair(dev, caller), v).first;
-  return it->second.ok ? &it->second : nullptr;
+  v.last_use = ++t.clock;
+  t.by_stream.emplace(std::make_pair(dev, caller), v);
+  if (!capturing) evict_side_streams(t, dev);
+  return v;
 }
 // Joins the forked side stream back into the caller's stream on EVERY exit path of se3conv_bwd once the fork has
 // happened (an early `return rc` would otherwise leave the side stream writing into buffers the caller is about to
 // free, and a stream capture with an unjoined fork).
 struct ForkJoin {
-  SideStream* side = nullptr;
+  SideStream side;
   hipStream_t main = nullptr;
   bool forked = false;
-  int fork(SideStream* s, hipStream_t m) {
-    if (hipEventRecord(s->fork, m) != hipSuccess || hipStreamWaitEvent(s->stream, s->fork, 0) != hipSuccess)
+  int fork(const SideStream& s, hipStream_t m) {
+    if (hipEventRecord(s.fork, m) != hipSuccess || hipStreamWaitEvent(s.stream, s.fork, 0) != hipSuccess)
       return SE3_ERR_LAUNCH;
     side = s, main = m, forked = true;
     return SE3_OK;
@@ -424,7 +473,7 @@ struct ForkJoin {
   int join() {
     if (!forked) return SE3_OK;
     forked = false;
-    if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(main, side->join, 0) != hipSuccess)
+    if (hipEventRecord(side.join, side.stream) != hipSuccess || hipStreamWaitEvent(main, side.join, 0) != hipSuccess)
       return SE3_ERR_LAUNCH;
     return SE3_OK;
   }
@@ -440,11 +489,13 @@ __global__ void slice_params_kernel(const float* __restrict__ axes, const float*
                                     const float* __restrict__ w, int kb, int k0, int kn, int c_in, int c_out,
                                     float* __restrict__ a32, float* __restrict__ b32, float* __restrict__ w32) {
   const int64_t n_w = (int64_t)c_in * kBasis * c_out;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_w; i += (int64_t)gridDim.x * blockDim.x) {
+  // the axes / bias tables (288 + 32 entries) ride in the same loop: it runs to whichever is longer (c_in * c_out < 9)
+  const int64_t n_all = n_w > SE3_DESC_DIMS * kBasis ? n_w : SE3_DESC_DIMS * kBasis;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
     const int o = (int)(i % c_out);
     const int k = (int)((i / c_out) % kBasis);
     const int ci = (int)(i / ((int64_t)c_out * kBasis));
-    w32[i] = k < kn ? w[((int64_t)ci * kb + k0 + k) * c_out + o] : 0.f;
+    if (i < n_w) w32[i] = k < kn ? w[((int64_t)ci * kb + k0 + k) * c_out + o] : 0.f;
     if (i < SE3_DESC_DIMS * kBasis) {
       const int j = (int)(i / kBasis), kk = (int)(i % kBasis);
       a32[i] = kk < kn ? axes[j * kb + k0 + kk] : 0.f;
@@ -458,11 +509,12 @@ __global__ void unslice_grads_kernel(const float* __restrict__ da32, const float
                                      float* __restrict__ grad_axes, float* __restrict__ grad_biases,
                                      float* __restrict__ grad_weights) {
   const int64_t n_w = (int64_t)c_in * kBasis * c_out;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_w; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t n_all = n_w > SE3_DESC_DIMS * kBasis ? n_w : SE3_DESC_DIMS * kBasis;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
     const int o = (int)(i % c_out);
     const int k = (int)((i / c_out) % kBasis);
     const int ci = (int)(i / ((int64_t)c_out * kBasis));
-    if (grad_weights && k < kn) grad_weights[((int64_t)ci * kb + k0 + k) * c_out + o] = dw32[i];
+    if (grad_weights && i < n_w && k < kn) grad_weights[((int64_t)ci * kb + k0 + k) * c_out + o] = dw32[i];
     if (grad_axes && i < SE3_DESC_DIMS * kBasis) {
       const int j = (int)(i / kBasis), kk = (int)(i % kBasis);
       if (kk < kn) grad_axes[j * kb + k0 + kk] = da32[i];
@@ -494,6 +546,11 @@ AnyBasisLayout any_basis_layout(const se3conv_shape* s, size_t out_tmp_bytes, bo
   l.inner = take(inner_bytes);
   l.total = off;
   return l;
+}
+// work items of slice_params_kernel / unslice_grads_kernel: the weights or the 288-entry axes table, whichever is longer
+int64_t slice_items(const se3conv_shape* s) {
+  const int64_t n_w = (int64_t)s->c_in * kBasis * s->c_out;
+  return n_w > SE3_DESC_DIMS * kBasis ? n_w : SE3_DESC_DIMS * kBasis;
 }
 se3conv_shape with_32_basis(const se3conv_shape* s) {
   se3conv_shape t = *s;
@@ -648,7 +705,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
     float *a32 = (float*)(ws + l.a32), *b32 = (float*)(ws + l.b32), *w32 = (float*)(ws + l.w32);
     for (int sl = 0; sl < l.slices; ++sl) {
       const int k0 = sl * kBasis, kn = s->num_basis - k0 < kBasis ? s->num_basis - k0 : kBasis;
-      hipLaunchKernelGGL(slice_params_kernel, dim3(grid_for((int64_t)s->c_in * kBasis * s->c_out)), dim3(256), 0, stream,
+      hipLaunchKernelGGL(slice_params_kernel, dim3(grid_for(slice_items(s))), dim3(256), 0, stream,
                          proj_axes, proj_biases, conv_weights, s->num_basis, k0, kn, s->c_in, s->c_out, a32, b32, w32);
       float* dst = sl == 0 ? out : (float*)(ws + l.out_tmp);
       if (int rc = se3conv_fwd(pts_in, pts_out, frames_in, frames_out, neighbors, ends, feat, a32, b32, w32, rho, nu, &s32, dst,
@@ -746,7 +803,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     float *a32 = (float*)(ws + l.a32), *b32 = (float*)(ws + l.b32), *w32 = (float*)(ws + l.w32);
     float *da32 = wp ? (float*)(ws + l.da32) : nullptr, *db32 = wp ? (float*)(ws + l.db32) : nullptr;
     float* dw32 = wp ? (float*)(ws + l.dw32) : nullptr;
-    const dim3 pgrid(grid_for((int64_t)s->c_in * kBasis * s->c_out));
+    const dim3 pgrid(grid_for(slice_items(s)));
     for (int sl = 0; sl < l.slices; ++sl) {
       const int k0 = sl * kBasis, kn = s->num_basis - k0 < kBasis ? s->num_basis - k0 : kBasis;
       hipLaunchKernelGGL(slice_params_kernel, pgrid, dim3(256), 0, stream, proj_axes, proj_biases, conv_weights,
@@ -922,11 +979,11 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       const char* e = getenv("SE3_OVERLAP_ROWS");
       return e ? (int64_t)atoll(e) : (int64_t)kOverlapRows;
     }();
-    SideStream* side = nullptr;
+    SideStream side;
     if (want_params && l.big_u != 0 && rows_out <= overlap_rows && (rows_out > kOverlapMinRows || overlap_rows > kOverlapRows) &&
-        (side = side_stream_for(stream)) != nullptr) {
+        (side = side_stream_for(stream)).ok) {
       if (int rc = fj.fork(side, stream)) return rc;
-      fs = side->stream;
+      fs = side.stream;
       ubuf = (uint32_t*)(ws + l.big_u);
       fsplit = (float*)(ws + l.split2);
       branch_forked = true;
@@ -1029,7 +1086,9 @@ extern "C" int se3_side_stream_stats(int32_t* stats) {
   stats[0] = (int32_t)t.by_stream.size();
   auto it = t.spare.find(dev);
   stats[1] = it == t.spare.end() ? 0 : (int32_t)it->second.size();
-  stats[2] = se3::g_side_streams_created;
+  stats[2] = t.created;
+  stats[3] = t.unforked_in_capture;
+  stats[4] = t.evicted;
   return SE3_OK;
 }
 

@@ -427,12 +427,19 @@ int launch_gemm_nn(const char* tag, const float* a, const float* b, float* c, in
 int gemm_tn_splits(int64_t m, int ka, int n) {
   const int64_t tiles = (int64_t)((ka + 127) / 128) * ((n + BN - 1) / BN);
   int64_t s = 512 / tiles;  // at most 512 workgroups (two per CU): one resident round
+  if (s < 1) s = 1;         // wide layers (more than 512 output tiles, e.g. 512 -> 256 channels): one range per tile
   // rows beyond the reach of one launch's 32-bit operand offsets are walked as several groups of ranges (gemm_bf16.hip):
   // a round's worth of ranges for every group
   const int64_t reach_rows = ((1ll << 32) - 64) / ((int64_t)(ka > n ? ka : n) * 4);
-  if (s >= 1 && m > reach_rows) s *= (4 * m + 3 * reach_rows - 1) / (3 * reach_rows);
+  if (m > reach_rows) s *= (4 * m + 3 * reach_rows - 1) / (3 * reach_rows);
   const int64_t max_s = (m + 255) / 256;
   if (s > max_s) s = max_s;
+  // a launch of the buffer-load TN kernels must reach at least one range plus the rows it prefetches past it:
+  // 2 * chunk * widest < 2^32 (launch_gemm_tn_bf16's `reach`), chunk = ceil(m / s) rounded up to a 32-row stage --
+  // applied last, so that neither the 512-workgroup target nor the 256-row floor can leave a range out of reach
+  // (c_in * K = 16 384 columns: 32 k rows per range)
+  const int64_t max_chunk = reach_rows / 2 - 64;
+  if (max_chunk > 0 && (m + s - 1) / s > max_chunk) s = (m + max_chunk - 1) / max_chunk;
   if (s < 1) s = 1;
   return (int)s;
 }

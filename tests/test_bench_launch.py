@@ -31,6 +31,23 @@ def test_gpus_2_forks_two_ranks_and_reports_them():
     assert rec["config"]["workload"] == "headline"
 
 
+@pytest.mark.timeout(300)
+def test_gpus_8_dry_run_one_scene_per_rank():
+    """BASELINE configuration 5 (ScanNet scenes sharded by scene over 8 GPUs, no collectives) as far as a box without
+    GPUs can rehearse it: the parent forks 8 ranks, every rank gets exactly one scene, the 8 per-scene results reach
+    rank 0 through the one gather of the job, and the ranks split the host's cores instead of taking 8 threads each."""
+    p, lines = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run", "--workload", "scannet150k_f1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak" and rec["config"]["workload"] == "scannet150k_f1"
+    assert rec["scenes"] == list(range(8))                       # every scene exactly once
+    assert sorted(rec["scene_checksums"]) == [str(i) for i in range(8)]
+    assert [rec["scene_checksums"][str(i)] for i in range(8)] == [float(i) for i in range(8)]  # rank r sent scene r's record
+    cores = len(os.sched_getaffinity(0))
+    assert 1 <= rec["config"]["cpu_threads_per_rank"] <= max(1, cores // 8)
+
+
 @pytest.mark.timeout(120)
 def test_single_rank_dry_run_needs_no_launcher():
     p, lines = _run(["--dry-run", "--steps", "2", "--workload", "scannet150k_f1"])

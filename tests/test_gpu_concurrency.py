@@ -109,9 +109,18 @@ def _side_stats():
     import ctypes as C
     from se3conv3d_amd import _lib
 
-    buf = (C.c_int32 * 3)()
+    buf = (C.c_int32 * 5)()
     _lib.check(_lib.load().se3_side_stream_stats(C.cast(buf, C.c_void_p)), "se3_side_stream_stats")
-    return list(buf)   # [streams that own a side stream, spares on this device, sets created in this process]
+    return list(buf)[:3]   # [streams that own a side stream, spares on this device, sets created in this process]
+
+
+def _side_stats_all():
+    import ctypes as C
+    from se3conv3d_amd import _lib
+
+    buf = (C.c_int32 * 5)()
+    _lib.check(_lib.load().se3_side_stream_stats(C.cast(buf, C.c_void_p)), "se3_side_stream_stats")
+    return list(buf)   # ... + [forks skipped inside a capture, sets taken back by the 16-owner cap]
 
 
 def test_capture_creates_no_runtime_objects(amd):
@@ -164,6 +173,7 @@ graph = torch.cuda.CUDAGraph()
 with torch.cuda.graph(graph):
     outs = T._fwd_bwd(c)
 assert T._side_stats() == [0, 0, 0], T._side_stats()
+assert T._side_stats_all()[3] == 1, T._side_stats_all()   # the library says that this graph runs its branches back to back
 graph.replay(); torch.cuda.synchronize()
 ref = T._fwd_bwd(c); torch.cuda.synchronize()
 assert all(torch.equal(u, v) for u, v in zip(outs, ref))
@@ -172,6 +182,28 @@ print("ok")
 ''' % (root, root)
     proc = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0 and "ok" in proc.stdout, (proc.stdout + proc.stderr)[-2000:]
+
+
+def test_side_stream_table_is_capped(amd):
+    """A process that makes a stream per request: at most 16 caller streams own a side stream, the least recently used
+    sets go back to the spares and are handed out again -- the table and the number of runtime objects stop growing."""
+    c = _case(amd, 8)                       # 10 000 output rows: backward forks
+    ref = _fwd_bwd(c)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(24)]
+    created = []
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            outs = _fwd_bwd(c)
+        s.synchronize()
+        for u, v in zip(outs, ref):
+            assert torch.equal(u, v)
+        created.append(_side_stats_all()[2])
+    owners, spares, made, _, evicted = _side_stats_all()
+    assert owners <= 16 + 1, (owners, spares, made, evicted)    # + 1: torch's capture stream of an earlier test may still own one
+    assert evicted >= 24 - 17
+    assert created[-1] == created[-4], "runtime objects are still being created although the cap hands sets back"
 
 
 def test_tensors_on_another_device_are_refused(amd):

@@ -213,6 +213,28 @@ def test_dfaust_f2_batch_against_oracle(amd):
         assert rel_err(u, v) < tol(amd), (name, rel_err(u, v))
 
 
+def test_wide_layer_rows_beyond_one_weight_gradient_range(amd):
+    """512 -> 256 channels on 42 000 output rows: c_in * K = 16 384 values per row of T, so one launch of the
+    weight-gradient GEMM's 32-bit operand offsets reaches 65 535 rows and one of its row ranges (range + the stage it
+    prefetches past it) half of that; with more than 512 output tiles (128 x 4) the old split count was a single range
+    and se3conv_bwd returned SE3_ERR_UNSUPPORTED.  dX slices and masked parameter gradients against the
+    oracle, the adjoint identity at full size."""
+    torch.manual_seed(8)
+    n, f = 21000, 2
+    pc = amd.pc.PointcloudRotEquiv(torch.rand(n, 3, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV),
+                                   {"pca": False, "n_frames": f, "fixed_axis": False})
+    r = radius_for_degree(n, 12)
+    nbh, conv, x, g = make_layer(amd, pc, r, 512, 256, seed=70)
+    grads = gpu_backward(conv, pc, nbh, x, g)
+    assert all(bool(torch.isfinite(t).all()) for t in grads)
+    check_dx_slice(amd, pc, nbh, conv, x, g, grads[1], n - 24, 24)
+    check_dx_slice(amd, pc, nbh, conv, x, g, grads[1], 9000, 24)
+    check_param_grads_masked(amd, pc, nbh, conv, x, g, torch.cat((torch.arange(n - 16, n), torch.randperm(n)[:32])).unique())
+    lhs = float((grads[0].double() * g.double()).sum())
+    rhs = float((x.double() * grads[1].double()).sum())
+    assert abs(lhs - rhs) <= tol(amd) * max(abs(lhs), abs(rhs), 1.0)
+
+
 def test_cloud_beyond_4gib_of_row_tensors(amd):
     """300 000 points x 2 frames: the row-sized intermediates (600 k rows x 2048 values) pass 4 GiB, which takes the
     kernels off their 32-bit-offset fast paths (3-byte rows, buffer addressing with 32-bit offsets).  Size-independent

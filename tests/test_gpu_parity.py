@@ -546,14 +546,16 @@ def test_symmetric_neighbourhood_needs_no_transposed_copy(amd):
 
 
 
-@pytest.mark.parametrize("kb", [8, 40, 70])
-def test_other_basis_counts_at_the_c_abi(amd, kb):
+@pytest.mark.parametrize("kb,c_in,c_out", [(8, 24, 40), (40, 24, 40), (70, 24, 40), (8, 1, 8), (40, 2, 4)])
+def test_other_basis_counts_at_the_c_abi(amd, kb, c_in, c_out):
     """se3conv_fwd / se3conv_bwd with num_basis != 32 called directly (no module, no autograd in between): one, two and
-    three slices of 32 inside the library; a two-cloud geometry, gradients requested separately and together."""
+    three slices of 32 inside the library; a two-cloud geometry, gradients requested separately and together.  The
+    narrow cases (c_in * c_out < 9: fewer weights per basis function than the axes table has rows) are the ones whose
+    padded [A; beta] slice used to stay partly unwritten."""
     from se3conv3d_amd import ops
 
     g = torch.Generator().manual_seed(100 + kb)
-    n_in, n_out, f_in, f_out, c_in, c_out = 700, 260, 2, 1, 24, 40
+    n_in, n_out, f_in, f_out = 700, 260, 2, 1
     pts_in, pts_out = torch.rand(n_in, 3, generator=g), torch.rand(n_out, 3, generator=g)
     bi, bo = torch.zeros(n_in, dtype=torch.int32), torch.zeros(n_out, dtype=torch.int32)
     fr_in, fr_out = O.random_frames(n_in, f_in, g), O.random_frames(n_out, f_out, g)
