@@ -100,6 +100,55 @@ def build_stack(spec: dict, device, seed: int, n_levels: int = 4, order: str = "
     return levels
 
 
+def build_level_pair(spec: dict, device, seed: int, order: str = "random"):
+    """Levels 0 and 1 of the workload's hierarchy with their radii: the clouds of the encoder's first down-convolution
+    (level 0 -> 1, neighbourhood radius of the SOURCE level, models/Encoder.py:137-147,167-171) and of the decoder's last
+    up-convolution (level 1 -> 0, radius of the COARSER level, models/Decoder.py:66-74,83-88)."""
+    from . import pc as _pc
+
+    r0 = radius_for_degree(spec["points"], spec["degree"])
+    pc0 = build_cloud(spec, device, seed, order)
+    hier = _pc.PointHierarchyRotEquiv(pc0, 1, "grid_avg", grid_radii=[r0])
+    return hier.pcs_[0], hier.pcs_[1], r0, 2.0 * r0
+
+
+def build_down_up(spec: dict, device, seed: int, order: str = "random") -> List[dict]:
+    """The two level-to-level convolutions of ``build_level_pair`` as bench records (like ``build_stack``'s, with both
+    clouds): a ball-query neighbourhood between the levels, a conv with converged EMA buffers, features and an output
+    gradient.  Channels follow the workload's level widths (down: widths[0] -> widths[1], up: the reverse)."""
+    from . import layers, pc as _pc
+
+    pc0, pc1, r0, r1 = build_level_pair(spec, device, seed, order)
+    factory = layers.PNEConvLayerRotEquivFactory(9, NUM_BASIS, "mlp_gelu")
+    f = spec["frames"]
+    w0, w1 = spec["widths"][0], spec["widths"][1]
+    recs = []
+    for name, pc_in, pc_out, r, c_in, c_out in (("down", pc0, pc1, r0, w0, w1), ("up", pc1, pc0, r1, w1, w0)):
+        nbh = _pc.BQNeighborhood(pc_in, pc_out, r)
+        conv = factory.create_conv_layer(c_in, c_out).to(device)
+        conv.norm_neigh_dist_.fill_(1.0 / r)
+        conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.num_edges(), 1))
+        n_in, n_out = pc_in.pts_.shape[0], pc_out.pts_.shape[0]
+        x = torch.randn(n_in * f, c_in, device=device, requires_grad=True)
+        g = torch.randn(n_out * f, c_out, device=device)
+        recs.append(dict(name=name, pc_in=pc_in, pc_out=pc_out, nbh=nbh, conv=conv, x=x, g=g, n_in=n_in, n_out=n_out,
+                         e=nbh.num_edges(), r=r, c_in=c_in, c_out=c_out, f=f))
+    return recs
+
+
+def layer_bytes_two_clouds(n_in: int, n_out: int, e: int, f_in: int, f_out: int, c_in: int, c_out: int, kb: int = NUM_BASIS) -> int:
+    """SURVEY.md section 8d's algorithmic bytes of one layer forward + backward for N_in != N_out, as written there:
+    B_f = 8E + 4N_out + 12(N_in + N_out) + 36(F_in N_in + F_out N_out) + 4 E F_in C_in + 4 M' C_out + 4(10K + C_in K C_out),
+    B_b = the same geometry + 4 E F_in C_in (re-gather of f) + 4 E F_in C_in (dX by the source-sorted segmented reduce)
+          + 4 M' C_out (g) + 4 N_in F_in C_in (dX) + 8(10K + C_in K C_out).  Equals ``layer_bytes`` for one cloud."""
+    geom = 8 * e + 4 * n_out + 12 * (n_in + n_out) + 36 * (f_in * n_in + f_out * n_out)
+    params = 4 * (10 * kb + c_in * kb * c_out)
+    gather = 4 * e * f_in * c_in
+    b_f = geom + gather + 4 * n_out * f_out * c_out + params
+    b_b = geom + 2 * gather + 4 * n_out * f_out * c_out + 4 * n_in * f_in * c_in + 2 * params
+    return b_f + b_b
+
+
 # ---- algorithmic work of one layer (SURVEY.md section 8d) ---------------------------------------------------
 def layer_flops(n: int, e: int, f: int, c: int, kb: int = NUM_BASIS) -> Dict[str, int]:
     """Algorithmic FLOPs per stage (MLP counted with its bias row)."""
@@ -145,3 +194,20 @@ def stage_moved_bytes(n: int, e: int, f: int, c: int, bytes_per_el=(3, 3, 4), kb
             "edge_t_transposed": own["edge_t_transposed"] + u_bytes, "gemm_gradX": own["gemm_gradX"] + u_bytes,
             "edge_param_grad": own["edge_param_grad"] + g_bytes, "gemm_gradT": own["gemm_gradT"] + g_bytes,
             "gemm_gradW": own["gemm_gradW"] + t_bytes + act}
+
+
+def stage_gather_bytes(n: int, e: int, f: int, c: int) -> Dict[str, int]:
+    """The part of ``stage_owned_bytes`` that is the uncached-gather model's neighbour rows (every point-edge fetching its
+    neighbour's F*C block).  The gathered table itself is rows * C * 4 bytes (33.5 MB at the headline shape): it lives
+    in the 256 MiB memory-side cache for the whole launch, so these bytes are served on chip and are NOT HBM traffic."""
+    gather = 4 * e * f * c
+    return {"edge_t_fwd": gather, "edge_t_transposed": gather, "edge_param_grad": gather}
+
+
+def stage_hbm_bytes(n: int, e: int, f: int, c: int, bytes_per_el=(3, 3, 4), kb: int = NUM_BASIS) -> Dict[str, int]:
+    """What each launch must move through HBM at least: ``stage_moved_bytes`` with the cache-served gathers replaced by one
+    read of the gathered table (row-sized intermediates + compulsory bytes)."""
+    moved = stage_moved_bytes(n, e, f, c, bytes_per_el, kb)
+    table = 4 * n * f * c
+    return {t: v - stage_gather_bytes(n, e, f, c).get(t, 0) + (table if t in ("edge_t_fwd", "edge_t_transposed", "edge_param_grad") else 0)
+            for t, v in moved.items()}

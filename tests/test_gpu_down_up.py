@@ -1,0 +1,139 @@
+"""GPU: the convolutions BETWEEN two hierarchy levels at BASELINE.json's full sizes -- the encoder's down-convolution
+(level l -> l + 1, models/Encoder.py:167-171: radius of the source level) and the decoder's up-convolution (level l ->
+l - 1, models/Decoder.py:57-100: radius of the coarser level) -- against the oracle by restriction, like
+test_gpu_fullsize_backward.py does for the same-level layers:
+
+  * the output rows of a set S of samples, and d[A; beta] / dW with grad_out zeroed outside S, only involve the edges
+    INTO S: the oracle runs on (samples S, sources = every point with an edge into S);
+  * dX of a set P of source points only involves the edges that LEAVE P: the oracle runs on (sources P, samples =
+    every point with an edge from P).
+
+N_in != N_out, F on both sides, a non-symmetric edge relation: backward reads the source-major copy of the edge list
+(se3_csr_transpose), which the same-level tests never build.  `headline` (65 536 -> ~9 200 points, 64 channels) and
+`dfaust_f2` (32 bodies, PCA frames, 32 <-> 64 channels); both arithmetic modes."""
+import pytest
+import torch
+
+from conftest import canon_edges, rel_err
+from oracle import se3conv_oracle as O
+from se3conv3d_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOLS = {"fp32": 2e-5, "bf16x3": 5e-5}
+
+
+@pytest.fixture(scope="module", params=["bf16x3", "fp32"])
+def amd(built_library, request):
+    import se3conv3d_amd
+
+    se3conv3d_amd.set_precision(request.param)
+    yield se3conv3d_amd
+    se3conv3d_amd.set_precision("bf16x3")
+
+
+def rows_of(points: torch.Tensor, f: int) -> torch.Tensor:
+    return (points[:, None] * f + torch.arange(f, device=points.device)[None, :]).reshape(-1)
+
+
+def oracle_sub(pc_in, pc_out, conv, nb_sub, samples, sources, x_rows, g_rows):
+    """Oracle forward + backward on a sub-graph; `nb_sub` [E,2] in ORIGINAL ids sorted by sample."""
+    s_map = torch.full((pc_out.pts_.shape[0],), -1, dtype=torch.int64)
+    p_map = torch.full((pc_in.pts_.shape[0],), -1, dtype=torch.int64)
+    s_map[samples] = torch.arange(samples.shape[0])
+    p_map[sources] = torch.arange(sources.shape[0])
+    nb = torch.stack((s_map[nb_sub[:, 0]], p_map[nb_sub[:, 1]]), 1)
+    assert int(nb.min()) >= 0 and bool((nb[1:, 0] >= nb[:-1, 0]).all())
+    cpu = lambda t: t.detach().cpu()
+    return O.conv_forward_backward(cpu(pc_in.pts_)[sources], cpu(pc_out.pts_)[samples], cpu(pc_in.local_frames_)[sources],
+                                   cpu(pc_out.local_frames_)[samples], nb, x_rows, cpu(conv.proj_axes_), cpu(conv.proj_biases_),
+                                   cpu(conv.conv_weights_), cpu(conv.norm_neigh_dist_), cpu(conv.norm_num_neighs_), g_rows)
+
+
+def gpu_step(conv, pc_in, pc_out, nbh, x, g):
+    for p in conv.parameters():
+        p.grad = None
+    xg = x.clone().requires_grad_(True)
+    out = conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=xg, p_neighborhood=nbh)
+    out.backward(g)
+    return out.detach(), xg.grad, conv.proj_axes_.grad.clone(), conv.proj_biases_.grad.clone(), conv.conv_weights_.grad.clone()
+
+
+def check_two_cloud_layer(amd, pc_in, pc_out, r, c_in, c_out, seed):
+    tol = TOLS[amd.get_precision()]
+    torch.manual_seed(seed)
+    f_in, f_out = pc_in.n_frames_, pc_out.n_frames_
+    n_in, n_out = pc_in.pts_.shape[0], pc_out.pts_.shape[0]
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, r)
+    assert not nbh.symmetric_
+    nb = nbh.neighbors_.cpu()
+    # the edge set itself, on the samples the brute-force oracle can afford
+    some = torch.randperm(n_out)[:64].sort().values
+    nb_o, ends_o = O.ball_query(pc_in.pts_.cpu(), pc_out.pts_.cpu()[some], pc_in.batch_ids_.cpu(), pc_out.batch_ids_.cpu()[some], r)
+    keep = torch.zeros(n_out, dtype=torch.bool)
+    keep[some] = True
+    mine = nb[keep[nb[:, 0]]].clone()
+    nb_o = torch.stack((some[nb_o[:, 0]], nb_o[:, 1]), 1)
+    assert torch.equal(canon_edges(mine), canon_edges(nb_o))
+
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c_in, c_out).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r)
+    conv.norm_num_neighs_.fill_(n_out / nb.shape[0])
+    with torch.no_grad():
+        conv.proj_biases_.uniform_(-0.5, 0.5)
+    x = torch.randn(n_in * f_in, c_in, device=DEV)
+    g = torch.randn(n_out * f_out, c_out, device=DEV)
+    out, dx, da, db, dw = gpu_step(conv, pc_in, pc_out, nbh, x, g)
+    assert all(bool(torch.isfinite(t).all()) for t in (out, dx, da, db, dw))
+
+    # the source-major edge list backward used: a permutation of the edges grouped by source
+    geom = nbh._se3_geom[1] if hasattr(nbh, "_se3_geom") else None
+    if geom is not None:
+        ts, te = geom.transpose()
+        deg_in = torch.bincount(nb[:, 1], minlength=n_in)
+        assert torch.equal(te.cpu().long(), torch.cumsum(deg_in, 0))
+        srcs = torch.repeat_interleave(torch.arange(n_in), deg_in)
+        assert torch.equal(canon_edges(torch.stack((ts.cpu().long(), srcs), 1)), canon_edges(nb))
+
+    # dX rows of source slices (first, interior, last)
+    for p0 in (0, n_in // 2 + 5, n_in - 32):
+        sources = torch.arange(p0, p0 + 32)
+        m = (nb[:, 1] >= p0) & (nb[:, 1] < p0 + 32)
+        nb_sub = nb[m]
+        if nb_sub.shape[0] == 0:
+            continue
+        samples = torch.unique(nb_sub[:, 0])
+        ref = oracle_sub(pc_in, pc_out, conv, nb_sub, samples, sources, x.cpu()[rows_of(sources, f_in)], g.cpu()[rows_of(samples, f_out)])
+        got = dx[rows_of(sources.to(DEV), f_in)]
+        assert rel_err(got, ref[1]) < tol, ("dX slice", p0, rel_err(got, ref[1]))
+
+    # output rows + masked parameter gradients of sample sets (spread over the cloud; the last rows)
+    for samples in (torch.randperm(n_out)[:64].sort().values, torch.arange(n_out - 24, n_out)):
+        g_m = torch.zeros_like(g)
+        rows = rows_of(samples.to(DEV), f_out)
+        g_m[rows] = g[rows]
+        out_m, _, da_m, db_m, dw_m = gpu_step(conv, pc_in, pc_out, nbh, x, g_m)
+        keep = torch.zeros(n_out, dtype=torch.bool)
+        keep[samples] = True
+        nb_sub = nb[keep[nb[:, 0]]]
+        sources = torch.unique(nb_sub[:, 1])
+        ref = oracle_sub(pc_in, pc_out, conv, nb_sub, samples, sources, x.cpu()[rows_of(sources, f_in)], g.cpu()[rows_of(samples, f_out)])
+        assert rel_err(out_m[rows], ref[0]) < tol, ("out rows", rel_err(out_m[rows], ref[0]))
+        for name, u, v in (("dA", da_m, ref[2]), ("dbeta", db_m, ref[3]), ("dW", dw_m, ref[4])):
+            assert rel_err(u, v) < tol, (name, rel_err(u, v))
+
+    # adjoint identity at full size: <out, g> == <x, dX>
+    lhs, rhs = float((out.double() * g.double()).sum()), float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs) <= tol * max(abs(lhs), abs(rhs), 1.0)
+
+
+@pytest.mark.parametrize("workload", ["headline", "dfaust_f2"])
+@pytest.mark.parametrize("direction", ["down", "up"])
+def test_level_to_level_convolution_against_oracle(amd, workload, direction):
+    spec = W.WORKLOADS[workload]
+    pc0, pc1, r0, r1 = W.build_level_pair(spec, DEV, seed=0)
+    c0, c1 = spec["widths"][0], spec["widths"][1]
+    if direction == "down":
+        check_two_cloud_layer(amd, pc0, pc1, r0, c0, c1, seed=11)
+    else:
+        check_two_cloud_layer(amd, pc1, pc0, r1, c1, c0, seed=12)
