@@ -93,6 +93,47 @@ __device__ __forceinline__ uint32_t t24_lo_word(uint32_t H, uint32_t L) {
   return cvt_pk_bf16(l0, l1);
 }
 
+// ---- 2.25-byte row format ("T16", SE3_PRECISION_BF16X3_T16) of the row-sized intermediates ---------------------------
+// Block floating point: 4 consecutive channels of one basis function share a power-of-two exponent and keep 16-bit signed
+// mantissas -- the block a lane of the edge kernels owns as four consecutive accumulator registers, so the producer
+// needs no cross-lane reduction.  (What the block shape costs in accuracy was simulated on rows with the operator's
+// statistics, profiles/r04_t16_format_simulation.txt: 2.0e-5 on every output and gradient for this shape, 3.1e-5 for
+// a block per (row, k, 32 channels), 5.7e-5 for one scale per row -- against 6.5e-6 for the 3-byte rows.)
+// Row layout for C channels x 32 basis functions, C a multiple of 8:
+//   bytes [0, 64 C)        int16 mant[(c >> 2) * 128 + k * 4 + (c & 3)]      (k' order = channel quad, basis, channel)
+//   bytes [64 C, 72 C)     uint8 expo[t16_exp_pos(b)], b = (c >> 2) * 32 + k  (one per block = per 4 mantissas)
+//   value = mant * 2^(expo - kT16ExpBias) / 32767,   2^(expo - bias) > max |value| of the block
+// The exponent plane is stored piece-major inside "mega tiles" of 64 blocks (256 mantissas): the NN GEMM walks a row in
+// 16-byte pieces (8 mantissas = 2 blocks), thread c of the 8 threads of a row takes piece c of every 64-mantissa super
+// tile -- its exponents of 4 consecutive super tiles are 8 consecutive bytes, and the 8 threads of a row read one
+// 64-byte line per mega tile (the row stream is bound by the number of 64-byte requests, gemm_bf16.hip).
+constexpr int kT16ExpBias = 64;
+__host__ __device__ inline int64_t t16_row_bytes(int channels) { return (int64_t)channels * 72; }
+// position kq in a T16 row -> the index c*32 + k the fp32 / packed-word rows use
+__host__ __device__ inline int t16_k_of(int kq) { return ((((kq >> 7) << 2) | (kq & 3)) << 5) + ((kq >> 2) & 31); }
+// block b -> byte position in the exponent plane: [mega tile b >> 6][piece (b >> 1) & 7][super tile (b >> 4) & 3][b & 1]
+__host__ __device__ inline int t16_exp_pos(int b) { return (b & ~63) | (((b >> 1) & 7) << 3) | (((b >> 4) & 3) << 1) | (b & 1); }
+// four values -> two words of packed mantissas + the exponent byte
+__device__ __forceinline__ void t16_pack4(float x0, float x1, float x2, float x3, uint32_t& m01, uint32_t& m23, uint32_t& eb) {
+  const float m = fmaxf(fmaxf(fabsf(x0), fabsf(x1)), fmaxf(fabsf(x2), fabsf(x3)));
+  int e = __builtin_amdgcn_frexp_expf(m);  // m = f * 2^e, f in [0.5, 1): |x| * 2^-e < 1 (0 for m = 0)
+  e = e < -kT16ExpBias ? -kT16ExpBias : (e > 127 ? 127 : e);  // below 2^-64 of anything this operator produces: flushed
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 a = __builtin_amdgcn_cvt_pknorm_i16(__builtin_ldexpf(x0, -e), __builtin_ldexpf(x1, -e));  // rint(x * 32767)
+  const s16x2 b = __builtin_amdgcn_cvt_pknorm_i16(__builtin_ldexpf(x2, -e), __builtin_ldexpf(x3, -e));
+  m01 = __builtin_bit_cast(uint32_t, a);
+  m23 = __builtin_bit_cast(uint32_t, b);
+  eb = (uint32_t)(e + kT16ExpBias);
+}
+// scale of a block from its exponent byte
+__device__ __forceinline__ float t16_scale(uint32_t eb) { return __builtin_ldexpf(1.0f / 32767.0f, (int)eb - kT16ExpBias); }
+// one word of two mantissas -> the packed pair of hi parts / of lo parts of the two values (the MFMA operand halves)
+__device__ __forceinline__ void t16_unpack2(uint32_t w, float sc, uint32_t& hi_pair, uint32_t& lo_pair) {
+  const float x0 = (float)(int)(int16_t)(w & 0xffffu) * sc, x1 = (float)((int)w >> 16) * sc;
+  hi_pair = cvt_pk_bf16(x0, x1);
+  lo_pair = cvt_pk_bf16(x0 - __uint_as_float(hi_pair << 16), x1 - __uint_as_float(hi_pair & 0xffff0000u));
+}
+
 // ds_read_b64_tr_b16: every group of 16 lanes reads a block of 4 rows x 16 columns of 16-bit values and gets it back
 // column-major -- lane i of the group receives column i, rows 0..3 packed as two words (row0 | row1 << 16, row2 |
 // row3 << 16).  Lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3 (8-byte aligned).  That is

@@ -434,6 +434,7 @@ int gemm_tn_splits(int64_t m, int ka, int n) {
   if (m > reach_rows) s *= (4 * m + 3 * reach_rows - 1) / (3 * reach_rows);
   const int64_t max_s = (m + 255) / 256;
   if (s > max_s) s = max_s;
+  if (s < 1) s = 1;  // (m = 0)
   // a launch of the buffer-load TN kernels must reach at least one range plus the rows it prefetches past it:
   // 2 * chunk * widest < 2^32 (launch_gemm_tn_bf16's `reach`), chunk = ceil(m / s) rounded up to a 32-row stage --
   // applied last, so that neither the 512-workgroup target nor the 256-row floor can leave a range out of reach

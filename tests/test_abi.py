@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(built_library):
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
     for name in syms:
         assert hasattr(lib, name), f"{name} declared in se3conv.h but not exported"
-    assert _lib.load().se3_abi_version() == _lib.ABI_VERSION == 2   # the binding refuses a library of another version
+    header_version = int(re.search(r"#define SE3_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert _lib.load().se3_abi_version() == _lib.ABI_VERSION == header_version   # the binding refuses a library of another version
 
 
 def test_host_side_argument_checks(built_library):
@@ -75,6 +76,25 @@ def test_intermediate_format_query(built_library):
     between = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 48, 48, 32, _lib.PRECISIONS["bf16x3"])  # two channels per lane: packed words
     assert [q(between, w) for w in range(3)] == [4, 4, 4]
     assert q(headline, 3) < 0 and q(_lib.Se3Shape(10, 10, 10, 0, 1, 8, 8, 32, 1), 0) < 0
+
+
+def test_workspace_queries_of_degenerate_and_wide_shapes(built_library):
+    """Host-only arithmetic behind the workspace queries (row-range counts of the weight-gradient GEMM): zero rows (a
+    division by the range count once took the process down with SIGFPE) and wide layers on many rows, whose ranges must
+    stay within reach of one launch's 32-bit operand offsets (512 -> 256 channels beyond ~32 k rows)."""
+    from se3conv3d_amd import _lib
+
+    lib = _lib.load()
+    assert lib.se3_linear_wgrad_workspace_bytes(0, 8, 16) == 8 * 16 * 4          # one (empty) range
+    assert lib.se3_linear_wgrad_workspace_bytes(1, 5, 32) >= 5 * 32 * 4
+    for prec in ("bf16x3", "fp32"):
+        empty = _lib.Se3Shape(0, 0, 0, 2, 2, 64, 64, 32, _lib.PRECISIONS[prec])
+        assert lib.se3conv_bwd_workspace_bytes(C.byref(empty), 1, 1, 0) > 0
+        wide = _lib.Se3Shape(21000, 21000, 250_000, 2, 2, 512, 256, 32, _lib.PRECISIONS[prec])
+        small = _lib.Se3Shape(2000, 2000, 25_000, 2, 2, 512, 256, 32, _lib.PRECISIONS[prec])
+        # 42 000 rows of 16 384 values: at least 2 row ranges (one range = 32 703 rows at most), so > 1x the weight count more
+        w_bytes = 512 * 32 * 256 * 4
+        assert lib.se3conv_bwd_workspace_bytes(C.byref(wide), 0, 1, 1) - lib.se3conv_bwd_workspace_bytes(C.byref(small), 0, 1, 1) >= w_bytes
 
 
 def test_header_lists_every_environment_switch():
