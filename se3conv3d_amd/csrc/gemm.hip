@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void reduce_partials_grouped_kernel(const floa
 int gemm_nn_splits(int64_t m, int n, int k) {
   const int64_t tiles = ((m + BM - 1) / BM) * ((n + BN - 1) / BN);
   const int nk = k / FK;
-  if (tiles >= 256 || k % FK != 0 || n % 4 != 0 || nk < 16) return 1;
+  if (tiles < 1 || tiles >= 256 || k % FK != 0 || n % 4 != 0 || nk < 16) return 1;  // (tiles = 0: an empty cloud)
   int64_t s = 1024 / tiles;
   if (s > nk / 8) s = nk / 8;
   return (int)(s < 1 ? 1 : s);

@@ -776,7 +776,7 @@ int gemm_nn_bf16_splits(int64_t m, int n, int k) {
   const int64_t tiles = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
   const int nkt = (k + BK - 1) / BK;
   constexpr int target = 512;  // workgroups aimed at (two per CU); 1024 and 256 measured slower on the 9 k-point level
-  if (tiles >= target / 2 || nkt < 8) return 1;
+  if (tiles < 1 || tiles >= target / 2 || nkt < 8) return 1;  // (tiles = 0: an empty cloud)
   // at most `target` workgroups (one more split than fits starts a second, nearly empty round: 144 tiles x 4 splits =
   // 576 on 512 slots took as long as two full rounds), at least 4 k-tiles per split
   int64_t s_max = target / tiles;
