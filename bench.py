@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 METRIC = "Mpoints/sec fwd+bwd PNEConvLayerRotEquiv (N=64k,k=32,F=2)"
 # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate; bf16 dense MFMA ~2.5 PF.
 # In "bf16x3" every multiply costs 3 bf16 MFMA products, so mfma_frac <= 1/3 by construction there.
-PEAK_MFMA_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
+PEAK_MFMA_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_t16": 2500.0}
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
@@ -380,7 +380,9 @@ def run_rank(args):
     dt_stack = timed(run_stack, args.steps, args.warmup)
     ms_step = dt_stack / args.steps * 1e3
     mpts = lambda ms: round(n0 * world / (ms * 1e-3) / 1e6, 3)
-    dtype = "f32" if args.precision == "fp32" else "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate)"
+    dtype = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate)",
+             "bf16x3_t16": "bf16x3 arithmetic, row-sized intermediates T / U in 2.25-byte block floating point (16-bit mantissas, "
+                           "one exponent per 4 channels)"}[args.precision]
     result = {
         "metric": METRIC, "value": mpts(ms_step), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
@@ -441,14 +443,14 @@ def run_rank(args):
         # what the library says it moves through memory for this shape (3-byte rows / 4-byte words / nothing)
         shp = _lib.Se3Shape(lv0["n"], lv0["n"], lv0["e"], frames, frames, lv0["c"], lv0["c"], W.NUM_BASIS,
                             _lib.PRECISIONS[args.precision])
-        per_el = tuple(int(lib.se3conv_intermediate_bytes_per_element(C.byref(shp), w)) for w in range(3))
+        per_el = tuple(int(lib.se3conv_intermediate_row_bytes(C.byref(shp), w)) / (lv0["c"] * W.NUM_BASIS) for w in range(3))
         moved = W.stage_moved_bytes(lv0["n"], lv0["e"], frames, lv0["c"], per_el)
         lb = W.layer_bytes(lv0["n"], lv0["e"], frames, lv0["c"])
         sb = sum(W.layer_bytes(lv["n"], lv["e"], frames, lv["c"]) for lv in levels)
         result["roofline"] = roofline
         result["single_layer"] = {"ms_per_step": round(ms_layer, 4), "value": mpts(ms_layer), "unit": "Mpoints/s",
                                   "hip_events": ev_layer, "algorithmic_bytes": lb,
-                                  "intermediate_bytes_per_element": dict(zip(("T", "U", "grad_T"), per_el)),
+                                  "intermediate_bytes_per_element": dict(zip(("T", "U", "grad_T"), (round(b, 3) for b in per_el))),
                                   "least_bytes_with_intermediates": sum(moved.values())}
         # Yardsticks of the decomposition as built.  Every launch moves its owned bytes plus the row-sized intermediates
         # (T, U, grad_T) once each way -- the edge phase and its contraction cannot share a CU (the contraction's weight
@@ -463,7 +465,7 @@ def run_rank(args):
         for lv in levels:
             shp_l = _lib.Se3Shape(lv["n"], lv["n"], lv["e"], frames, frames, lv["c"], lv["c"], W.NUM_BASIS,
                                   _lib.PRECISIONS[args.precision])
-            pe = tuple(int(lib.se3conv_intermediate_bytes_per_element(C.byref(shp_l), w)) for w in range(3))
+            pe = tuple(int(lib.se3conv_intermediate_row_bytes(C.byref(shp_l), w)) / (lv["c"] * W.NUM_BASIS) for w in range(3))
             least_stack += sum(W.stage_moved_bytes(lv["n"], lv["e"], frames, lv["c"], pe).values())
             hbm_stack += sum(W.stage_hbm_bytes(lv["n"], lv["e"], frames, lv["c"], pe).values())
         ms_at = lambda nbytes, gbps: nbytes / (gbps * 1e9) * 1e3
@@ -629,6 +631,52 @@ def run_rank(args):
             result["fp32_mode"] = {"ms_per_step": round(ms32, 4), "value": mpts(ms32), "unit": "Mpoints/s",
                                    "note": "same stack with every contraction on v_mfma_f32_32x32x2_f32 (exact fp32 products)"}
 
+        # The third arithmetic mode: bf16x3 products with T / U in the 2.25-byte block format.  Timed
+        # like the headline (same stack, graph replay) with its error measured at FULL size: every output and gradient of
+        # the level-0 layer against the exact-fp32 mode's (itself within 1.5e-6 of the fp64 oracle), next to the default
+        # mode's own distance -- the measured cost in accuracy of the bytes it saves.  Opt-in: not part of `value`.
+        if args.precision == "bf16x3" and not args.no_t16:
+            def layer_results(prec):
+                amd.set_precision(prec)
+                lv = levels[0]
+                lv["x"].grad = None
+                for p in lv["conv"].parameters():
+                    p.grad = None
+                out = lv["conv"](p_pc_in=lv["pc"], p_pc_out=lv["pc"], p_in_features=lv["x"], p_neighborhood=lv["nbh"])
+                out.backward(lv["g"])
+                return [out.detach().double()] + [t.grad.detach().double().clone() for t in
+                                                  (lv["x"], lv["conv"].proj_axes_, lv["conv"].proj_biases_, lv["conv"].conv_weights_)]
+
+            try:
+                ref32 = layer_results("fp32")
+                rel = lambda got: [float((a - b).norm() / b.norm()) for a, b in zip(got, ref32)]
+                err_t16, err_def = rel(layer_results("bf16x3_t16")), rel(layer_results("bf16x3"))
+                del ref32
+                amd.set_precision("bf16x3_t16")
+                run16 = (lambda: step(levels)) if args.no_graph else GraphedStep(levels)
+                ms16 = timed(run16, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
+                run16l = (lambda: step(levels[:1])) if args.no_graph else GraphedStep(levels[:1])
+                ms16l = timed(run16l, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
+                st16 = profile_level(lib, levels[0], reps=5)
+                shp16 = _lib.Se3Shape(lv0["n"], lv0["n"], lv0["e"], frames, frames, lv0["c"], lv0["c"], W.NUM_BASIS,
+                                      _lib.PRECISIONS["bf16x3_t16"])
+                names = ("out", "dX", "dA", "dbeta", "dW")
+                result["t16_mode"] = {
+                    "ms_per_step": round(ms16, 4), "value": mpts(ms16), "unit": "Mpoints/s",
+                    "single_layer_ms": round(ms16l, 4),
+                    "row_bytes": {k: int(lib.se3conv_intermediate_row_bytes(C.byref(shp16), w)) for w, k in enumerate(("T", "U", "grad_T"))},
+                    "rel_err_vs_fp32_mode": dict(zip(names, (float(f"{e:.3g}") for e in err_t16))),
+                    "default_mode_rel_err_vs_fp32_mode": dict(zip(names, (float(f"{e:.3g}") for e in err_def))),
+                    "worst_rel_err": float(f"{max(err_t16):.3g}"),
+                    "stages_ms": {t: round(v[0], 4) for t, v in sorted(st16.items())},
+                    "note": "same stack, bf16x3 products, T / U rows as 16-bit mantissas with one exponent per 4 channels (2.25 B per "
+                            "element instead of 3); errors = ||x - x_fp32mode|| / ||x_fp32mode|| of the full-size level-0 layer"}
+            except RuntimeError as exc:
+                result["t16_mode"] = {"error": str(exc)[:200]}
+                torch.cuda.synchronize()
+            finally:
+                amd.set_precision(args.precision)
+
     # the "trivial result gather": one checksum of the level-0 output per scene.  A fixed-size record per rank, so it
     # travels as one tensor all-gather (RCCL over xGMI; gloo in the rehearsal) rather than through pickled objects.
     with torch.no_grad():
@@ -664,11 +712,12 @@ def main(argv=None):
                     help="row order of the synthetic points: as drawn, or sorted along a Z-order curve per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 leg")
+    ap.add_argument("--no-t16", action="store_true", help="skip the leg of the third arithmetic mode (T / U in the 2.25-byte block format)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the N-rank protocol (no GPU work)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: ranks may share a GPU (rank %% device count), gloo instead of RCCL")
-    ap.add_argument("--precision", default=os.environ.get("SE3CONV_PRECISION", "bf16x3"), choices=["bf16x3", "fp32"])
+    ap.add_argument("--precision", default=os.environ.get("SE3CONV_PRECISION", "bf16x3"), choices=["bf16x3", "fp32", "bf16x3_t16"])
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

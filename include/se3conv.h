@@ -85,15 +85,24 @@ typedef struct se3conv_shape {
  *            3 products).  `t_save` is then an opaque buffer of the same size (packed hi/lo words, or
  *            3-byte rows -- the library picks per shape) and must be passed back to se3conv_bwd
  *            with the same precision, shape and process environment. */
+/*   BF16X3_T16 (opt-in, round 4): the arithmetic of BF16X3 with the row-sized intermediates T and U (the tensors
+ *            [rows, C, K] between an edge kernel and its contraction) kept in a 2.25-byte block floating-point format
+ *            instead of 3-byte rows: 4 consecutive channels of one basis function share an 8-bit power-of-two exponent
+ *            and keep 16-bit mantissas.  A quarter fewer bytes through HBM for those tensors; the rounding of T / U
+ *            alone puts ~2e-5 into every output and gradient (BF16X3: ~6e-6), i.e. ~2.5e-5 in all against the
+ *            north-star tolerance of 1e-4.  Shapes the format is not implemented for (rows that are not a multiple of
+ *            64 channels, odd frame counts at 64 channels) run exactly as in BF16X3. */
 #define SE3_PRECISION_FP32 0
 #define SE3_PRECISION_BF16X3 1
+#define SE3_PRECISION_BF16X3_T16 2
 
 /* Library / build identification.  SE3_ABI_VERSION changes whenever an entry point's signature does: 2 = round 3
  * (se3_skip_fwd / se3_skip_bwd take gate_keep, se3_bn_fwd takes num_batches_tracked; entry points added since 1:
  * se3_knn_query_pair, se3_grid_pick, se3_rows_gather / _scatter, se3_rot_tensors_rel, se3_csr_transpose_bounded,
  * se3_side_stream_stats, se3_linear_wgrad).  A binding should compare se3_abi_version() with the header it was written
  * against (se3conv3d_amd/_lib.py does). */
-/* 3 = round 4: se3_side_stream_stats fills FIVE counters (was three). */
+/* 3 = round 4: se3_side_stream_stats fills FIVE counters (was three); SE3_PRECISION_BF16X3_T16 and
+ * se3conv_intermediate_row_bytes added. */
 #define SE3_ABI_VERSION 3
 int se3_abi_version(void);
 const char* se3_error_string(int code);
@@ -102,6 +111,10 @@ const char* se3_error_string(int code);
  * hi|lo words, 3 = 3-byte rows (the library picks per shape: rows of <= 32 or >= 64 channels, even); negative = SE3_ERR_*.
  * For traffic models (bench.py), so that they need not hard-code what the library picked. */
 int se3conv_intermediate_bytes_per_element(const se3conv_shape* s, int which);
+/* The same as exact bytes per ROW of that tensor (rows x this = what one pass over it moves): 4 / 3 bytes per element, or
+ * 72 bytes per channel (2.25 per element) in the T16 block format of SE3_PRECISION_BF16X3_T16, which the call above
+ * reports as 2.  Negative = SE3_ERR_*. */
+int64_t se3conv_intermediate_row_bytes(const se3conv_shape* s, int which);
 
 /* ---------------------------------------------------------------------------------------------
  * compute_keys  <-  point_cloud_lib_ops.compute_keys

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "lib", f"libse3conv_hip{os.environ.get('SE3_LIB_SU
 
 SE3_OK = 0
 ABI_VERSION = 3  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
-PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x3_t16": 2}
 REL_ROT = {"6D": (0, 9), "matrix": (1, 12), "quaternion": (2, 7)}  # p_rel_rot -> (SE3_REL_ROT_*, descriptor dims)
 
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "se3_abi_version": (C.c_int, []),
     "se3_error_string": (C.c_char_p, [C.c_int]),
     "se3conv_intermediate_bytes_per_element": (C.c_int, [_SHP, C.c_int]),
+    "se3conv_intermediate_row_bytes": (C.c_int64, [_SHP, C.c_int]),
     "se3_compute_keys": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "se3_batch_aabb": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
     "se3_grid_subsample_workspace_bytes": (_SZ, [_I64, _I32]),

@@ -220,7 +220,8 @@ inline unsigned grid_for(int64_t n) {
 bool shape_ok(const se3conv_shape* s) {
   return s && s->n_in >= 0 && s->n_out >= 0 && s->n_edges >= 0 && s->f_in >= 1 && s->f_out >= 1 && s->c_in >= 1 &&
          s->c_out >= 1 && s->num_basis >= 1 &&
-         (s->precision == SE3_PRECISION_FP32 || s->precision == SE3_PRECISION_BF16X3);
+         (s->precision == SE3_PRECISION_FP32 || s->precision == SE3_PRECISION_BF16X3 ||
+          s->precision == SE3_PRECISION_BF16X3_T16);
 }
 int shape_supported(const se3conv_shape* s) {
   if (s->num_basis != kBasis) return SE3_ERR_UNSUPPORTED;  // every shipped config uses K = 32
@@ -241,7 +242,7 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
   const size_t kb = s->num_basis;
   l.axes_ext = take(kDescExt * kBasis * 4);
   l.t = save_t ? 0 : take((size_t)s->n_out * s->f_out * s->c_in * kb * 4);
-  if (s->precision == SE3_PRECISION_BF16X3) {
+  if (s->precision != SE3_PRECISION_FP32) {
     l.featpk = take((size_t)s->n_in * s->f_in * s->c_in * 4);
     const size_t plane = (size_t)s->c_out * align_up((size_t)s->c_in * kb, 32) * 2;
     l.bt_hi = take(plane);
@@ -268,7 +269,7 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   const size_t kb = s->num_basis;
   const size_t rows_out = (size_t)s->n_out * s->f_out, rows_in = (size_t)s->n_in * s->f_in;
   const size_t wsz = (size_t)s->c_in * kb * s->c_out * 4;
-  const bool fast = s->precision == SE3_PRECISION_BF16X3;
+  const bool fast = s->precision != SE3_PRECISION_FP32;
   l.axes_ext = take(kDescExt * kBasis * 4);
   if (!fast) {
     l.wt = want_params ? take(wsz) : 0;
@@ -656,25 +657,40 @@ extern "C" int se3_feat_basis_proj_grad(const float* basis, const float* feat, c
   return check_launch();
 }
 
-// The row-sized intermediates (T, and U of the feature gradient) are kept in the 3-byte row format of common.h when
-// the edge kernel can produce them (edge_t_bf16_t24_rows) and the buffer-load GEMMs consume them (SE3_NO_T24=1: packed words
-// everywhere).  tn_cols = the column count of the TN product that also reads the rows (0: none).
-static bool t24_rows(const EdgeGeom& g, int channels, int64_t rows, int tn_cols) {
+// Format of the row-sized intermediates (T, and U of the feature gradient): 0 packed hi|lo words (4 bytes per element), 1
+// the 3-byte rows of common.h when the edge kernel can produce them (edge_t_bf16_t24_rows) and the buffer-load GEMMs consume
+// them (SE3_NO_T24=1: packed words everywhere), 2 the 2.25-byte block format T16 -- only in SE3_PRECISION_BF16X3_T16, where
+// the wave-pair edge kernel produces it (rows of a multiple of 64 channels); other shapes of that mode fall back to 1 / 0.
+// tn_cols = the column count of the TN product that also reads the rows (0: none).
+static int row_format(const se3conv_shape* s, const EdgeGeom& g, int channels, int64_t rows, int tn_cols) {
   static const bool on = getenv("SE3_NO_T24") == nullptr;
   (void)rows;  // any row count: the GEMMs that read the rows walk them in blocks their 32-bit offsets reach (gemm_bf16.hip)
-  return on && kBasis == 32 && channels % 2 == 0 && edge_t_bf16_t24_rows(g, channels) && tn_cols % 4 == 0;
+  if (s->precision == SE3_PRECISION_BF16X3_T16 && kBasis == 32 && edge_t_bf16_t16_rows(g, channels) && tn_cols % 4 == 0)
+    return 2;
+  return on && kBasis == 32 && channels % 2 == 0 && edge_t_bf16_t24_rows(g, channels) && tn_cols % 4 == 0 ? 1 : 0;
 }
 
 // Bytes per element of the row-sized intermediates this shape would move (what a traffic model has to assume):
 // which = 0: T (forward, read again by the weight gradient), 1: U (feature gradient), 2: grad_T.  < 0: bad shape.
-extern "C" int se3conv_intermediate_bytes_per_element(const se3conv_shape* s, int which) {
-  if (!shape_ok(s) || which < 0 || which > 2) return SE3_ERR_INVALID_ARGUMENT;
-  if (s->precision == SE3_PRECISION_FP32 || which == 2) return 4;
+// The T16 format's 2.25 bytes are reported as 2 here (an integer interface); se3conv_intermediate_row_bytes is exact.
+static int64_t intermediate_row_bytes(const se3conv_shape* s, int which) {
+  const int64_t ck = (int64_t)(which == 1 ? s->c_out : s->c_in) * s->num_basis;
+  if (s->precision == SE3_PRECISION_FP32 || which == 2 || s->num_basis != kBasis) return ck * 4;
   EdgeGeom g = forward_geom(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
   EdgeGeom gt{};
   gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.n_nb = s->n_out, gt.transposed = 1;
-  if (which == 0) return t24_rows(g, s->c_in, s->n_out * s->f_out, s->c_out) ? 3 : 4;
-  return t24_rows(gt, s->c_out, s->n_in * s->f_in, 0) ? 3 : 4;
+  const int fmt = which == 0 ? row_format(s, g, s->c_in, s->n_out * s->f_out, s->c_out)
+                             : row_format(s, gt, s->c_out, s->n_in * s->f_in, 0);
+  return fmt == 2 ? t16_row_bytes(which == 0 ? s->c_in : s->c_out) : ck * (fmt == 1 ? 3 : 4);
+}
+extern "C" int64_t se3conv_intermediate_row_bytes(const se3conv_shape* s, int which) {
+  if (!shape_ok(s) || which < 0 || which > 2) return SE3_ERR_INVALID_ARGUMENT;
+  return intermediate_row_bytes(s, which);
+}
+extern "C" int se3conv_intermediate_bytes_per_element(const se3conv_shape* s, int which) {
+  if (!shape_ok(s) || which < 0 || which > 2) return SE3_ERR_INVALID_ARGUMENT;
+  const int64_t ck = (int64_t)(which == 1 ? s->c_out : s->c_in) * s->num_basis;
+  return (int)(intermediate_row_bytes(s, which) / ck);
 }
 
 extern "C" size_t se3conv_fwd_workspace_bytes(const se3conv_shape* s, int save_t) {
@@ -752,7 +768,7 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   const float inv_phi = inv_fin / kGeluOut;  // the bf16 edge kernels produce kGeluOut * phi (gelu_scaled)
-  const bool t24 = t24_rows(g, s->c_in, rows_out, s->c_out);  // se3conv_bwd decides the same way
+  const int t24 = row_format(s, g, s->c_in, rows_out, s->c_out);  // 0 / 1 / 2 (row_format); se3conv_bwd decides the same way
   {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
     PrepBatch pb;
     pb.axes(proj_axes, proj_biases, axes_ext);
@@ -916,8 +932,8 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   uint32_t* bigw = (uint32_t*)big;
   const float inv_phi = inv_fin / kGeluOut;  // T and U hold kGeluOut * (the reference's values), see gelu_scaled
   const bool feat_branch = want_feat && rows_in > 0;
-  const bool t24_t = t24_rows(g, s->c_in, rows_out, s->c_out);  // as se3conv_fwd
-  const bool t24_u = feat_branch && t24_rows(gt, s->c_out, rows_in, 0);
+  const int t24_t = row_format(s, g, s->c_in, rows_out, s->c_out);  // as se3conv_fwd
+  const int t24_u = feat_branch ? row_format(s, gt, s->c_out, rows_in, 0) : 0;
   const bool strip_t = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);            // grad_T = g W^T
   {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
     float* geom_in = (float*)(ws + l.geom_in);

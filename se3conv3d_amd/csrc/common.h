@@ -134,6 +134,17 @@ __device__ __forceinline__ void t16_unpack2(uint32_t w, float sc, uint32_t& hi_p
   lo_pair = cvt_pk_bf16(x0 - __uint_as_float(hi_pair << 16), x1 - __uint_as_float(hi_pair & 0xffff0000u));
 }
 
+// a 16-byte piece (8 mantissas = two blocks with the exponent bytes e2 & 0xff, e2 >> 8) -> its hi / lo fragment words
+__device__ __forceinline__ void t16_unpack8(u32x4 mw, uint32_t e2, u32x4& vh, u32x4& vl) {
+  const float sc0 = t16_scale(e2 & 0xffu), sc1 = t16_scale((e2 >> 8) & 0xffu);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t hw, lw;
+    t16_unpack2(mw[i], i < 2 ? sc0 : sc1, hw, lw);
+    vh[i] = hw, vl[i] = lw;
+  }
+}
+
 // ds_read_b64_tr_b16: every group of 16 lanes reads a block of 4 rows x 16 columns of 16-bit values and gets it back
 // column-major -- lane i of the group receives column i, rows 0..3 packed as two words (row0 | row1 << 16, row2 |
 // row3 << 16).  Lane 4q + p of the group supplies the address of row q, columns 4p .. 4p+3 (8-byte aligned).  That is
@@ -358,9 +369,10 @@ struct ReduceBatch {
 int launch_split_pack(const float* src, uint32_t* dst, int64_t n, hipStream_t stream);
 bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels);
 bool edge_t_bf16_t24_rows(const EdgeGeom& g, int channels);
+bool edge_t_bf16_t16_rows(const EdgeGeom& g, int channels);
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream,
-                       int64_t row_lo = -1, int64_t row_hi = -1, bool t24 = false);
+                       int64_t row_lo = -1, int64_t row_hi = -1, int rowfmt = 0);  // rowfmt: 0 packed words, 1 3-byte rows, 2 T16
 int edge_param_grad_bf16_channel_blocks(int channels);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
@@ -444,7 +456,7 @@ struct PrepBatch {
   void geometry(const float* pts, const float* frames, int64_t n, int f, float* records);
   void split(const float* src, uint32_t* dst, int64_t n);
   void weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
-               const float* scale_num = nullptr, float scale = 1.0f, bool frag_layout = false, bool perm24 = false);
+               const float* scale_num = nullptr, float scale = 1.0f, bool frag_layout = false, int a_rowfmt = 0);  // a_rowfmt: k order of the A rows (0 natural, 1 3-byte rows, 2 T16)
   int launch(hipStream_t stream);
 };
 
@@ -454,10 +466,10 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
                            int64_t m, int n, int k, hipStream_t stream);
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
-                        float alpha_scale, hipStream_t stream, bool a24 = false, ReduceBatch* defer = nullptr);
+                        float alpha_scale, hipStream_t stream, int afmt = 0, ReduceBatch* defer = nullptr);  // afmt: A rows 0 packed, 1 3-byte, 2 T16
 size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k);
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
-                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24 = false,
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, int afmt = 0,
                         ReduceBatch* defer = nullptr);  // defer (both GEMMs): the reduction joins the caller's ReduceBatch
 
 }  // namespace se3

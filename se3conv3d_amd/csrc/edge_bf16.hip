@@ -335,6 +335,21 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int ch0 = cbase + 32 * (CT * wv + t);
+        if (t24 == 2) {  // 2.25-byte rows (common.h, T16): registers 4j .. 4j+3 of this lane = 4 consecutive channels = one block
+          char* row = reinterpret_cast<char*>(t_out) + (item * NF + a) * t16_row_bytes(C);
+          uint8_t* expo = reinterpret_cast<uint8_t*>(row) + (int64_t)C * kBasis * 2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cq = (ch0 >> 2) + 2 * j + h;  // channel quad of registers 4j .. 4j+3 (acc_row(4j + i, h) = 8j + 4h + i)
+            uint32_t m01, m23, eb;
+            t16_pack4(acc[a][t][4 * j], acc[a][t][4 * j + 1], acc[a][t][4 * j + 2], acc[a][t][4 * j + 3], m01, m23, eb);
+            typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+            // one instruction = 64 lanes x 8 bytes = 512 consecutive bytes of the row (quads cq, cq + 1 over all 32 k)
+            __builtin_nontemporal_store(u32x2s{m01, m23}, reinterpret_cast<u32x2s*>(row) + cq * kBasis + kcol);
+            __builtin_nontemporal_store((uint8_t)eb, expo + t16_exp_pos(cq * kBasis + kcol));
+          }
+          continue;
+        }
         if (t24) {  // 3-byte rows (common.h): channels c, c+1 of this lane = one hi word + one lo half-word
           char* row = reinterpret_cast<char*>(t_out) + (item * NF + a) * t24_row_bytes(C);
 #pragma unroll
@@ -898,16 +913,23 @@ bool edge_t_bf16_t24_rows(const EdgeGeom& g, int channels) {
   return channels <= 32 || channels == 64;
 }
 
+// 2.25-byte rows (T16): the wave-pair kernel on full 64-channel passes (a lane's four consecutive registers are a block)
+bool edge_t_bf16_t16_rows(const EdgeGeom& g, int channels) {
+  return channels % 64 == 0 && edge_t_bf16_uses_pair(g, channels);
+}
+
 // row_lo / row_hi (multiples of 2 for even F; < 0: everything): only the rows in that range are produced -- the
 // wave-pair kernel supports it (edge_t_bf16_row_ranges), which lets the caller interleave producer and consumer
 // launches over slices of the rows
 int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels, int64_t feat_rows,
                        const float* axes_ext, const float* rho, uint32_t* t_out, hipStream_t stream, int64_t row_lo,
-                       int64_t row_hi, bool t24) {
+                       int64_t row_hi, int rowfmt) {
+  const bool t24 = rowfmt == 1;
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (rows == 0) return SE3_OK;
   if (row_lo >= 0 && !edge_t_bf16_row_ranges(g, channels)) return SE3_ERR_UNSUPPORTED;
   if (t24 && !edge_t_bf16_t24_rows(g, channels)) return SE3_ERR_UNSUPPORTED;
+  if (rowfmt == 2 && !edge_t_bf16_t16_rows(g, channels)) return SE3_ERR_UNSUPPORTED;
   // 32-bit byte offsets into the gathered operand; kOobOffset must lie beyond it
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
@@ -936,7 +958,7 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     const dim3 pgrid((unsigned)pblocks), pblock(128);
 #define SE3_PAIR_T(CT, FULL, NF, P2, TR)                                                                                \
   hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                     axes_ext, rho, t_out, item_lo, item_hi, shift, t24 ? 1 : 0)
+                     axes_ext, rho, t_out, item_lo, item_hi, shift, rowfmt)
 #define SE3_PAIR_L(CT, FULL, NF, P2)                 \
   do {                                               \
     if (!(P2)) SE3_PAIR_T(CT, FULL, NF, P2, -1);     \

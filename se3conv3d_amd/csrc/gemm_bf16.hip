@@ -376,6 +376,180 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
   }
 }
 
+// NN GEMM over A rows in the 2.25-byte block format (common.h, T16; k a multiple of 256 = one mega tile of the exponent
+// plane).  Same skeleton as the 3-byte kernel above -- super tiles of 64 k, the two 32-k halves of a super tile are the
+// two LDS buffers -- with these differences: the row stream is the mantissa plane (128 B per row and super tile, as the
+// 3-byte format's hi plane) plus ONE 8-byte exponent load per thread and mega tile (4 super tiles; the 8 threads of a
+// row read one 64-byte line); a piece (8 mantissas = 2 blocks) is decoded to its hi / lo bf16 planes on the way into
+// LDS (t16_unpack2: 5.5 VALU per element, once per element of A -- the MFMA stage then reads both fragments as they
+// lie, no rebuild); no per-block phase stagger (4608-byte rows do not alias onto a few channels as 8192-byte rows do).
+template <int OUT_MODE, int NB>
+__global__ __launch_bounds__(256) void gemm_nn_t16_kernel(const uint8_t* __restrict__ a,
+                                                          const uint16_t* __restrict__ bt_hi,
+                                                          const uint16_t* __restrict__ bt_lo, void* __restrict__ c,
+                                                          int64_t m, int n, int k, int st_per_split,
+                                                          const float* __restrict__ alpha_num, float alpha_scale) {
+  constexpr int BNW = BN * NB;
+  constexpr int RB = BM;           // rows per workgroup
+  constexpr int RP = 32;           // rows one load pass covers (8 threads per row): 4 passes = RB rows
+  constexpr int CP = 32;           // weight columns one load pass covers: 2 * NB passes per plane
+  constexpr int NBP = 2 * NB;
+  __shared__ __attribute__((aligned(16))) uint16_t ash[2][RB][BK + 8];   // 80-byte pitch
+  __shared__ __attribute__((aligned(16))) uint16_t asl[2][RB][BK + 8];
+  __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BNW][B_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rl = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * RB;
+  const int n0 = blockIdx.y * BNW;
+  const int st_begin = blockIdx.z * st_per_split;          // a multiple of 4 (host)
+  const int ns = min(k / 64 - st_begin, st_per_split);     // super tiles of this block (> 0, a multiple of 4)
+
+  struct Super { u32x4 am[4], bh[NBP], bl[NBP]; };
+  const uint32_t rb = (uint32_t)k / 32u * 72u;             // row bytes: 2 k of mantissas + k / 4 exponent bytes
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(a), (short)0, (int)(uint32_t)(m * rb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bh_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_hi), (short)0, (int)(uint32_t)((int64_t)n * k * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_lo), (short)0, (int)(uint32_t)((int64_t)n * k * 2), 0x00020000);
+  const int hsel = (tid >> 2) & 1;
+  // lane l of load pass p reads 16-byte column (l & 7) ^ (4 * (p & 1)) of its row (see gemm_nn_t24_kernel)
+  auto load_super = [&](Super& t, int st) {
+    const uint32_t k0 = (uint32_t)(st_begin + st) * 64u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t off = (uint32_t)(m0 + p * RP + (tid >> 3)) * rb + k0 * 2u + (uint32_t)((tid & 7) ^ ((p & 1) << 2)) * 16u;
+      t.am[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < NBP; ++j) {
+      const uint32_t off = ((uint32_t)(n0 + CP * j + (tid >> 3)) * (uint32_t)k + k0 + (uint32_t)((tid & 7) ^ ((j & 1) << 2)) * 8u) * 2u;
+      t.bh[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, off, 0, 0));
+      t.bl[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, off, 0, 0));
+    }
+  };
+  // exponents of this thread's pieces for the 4 super tiles of mega tile `mg` (relative to st_begin): pass p, piece
+  // (tid & 7) ^ (4 (p & 1)) -> 8 bytes = [super tile s][block of the piece]
+  auto load_exps = [&](u32x2 (&e)[4], int mg) {
+    const uint32_t e0 = (uint32_t)k * 2u + (uint32_t)(st_begin / 4 + mg) * 64u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t off = (uint32_t)(m0 + p * RP + (tid >> 3)) * rb + e0 + (uint32_t)((tid & 7) ^ ((p & 1) << 2)) * 8u;
+      e[p] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, off, 0, 0));
+    }
+  };
+  // the 32-k half `hf` of super tile number s (0..3) of its mega tile -> LDS buffer `buf`
+  auto store_half = [&](const Super& t, const u32x2 (&e)[4], int s, int hf, int buf) {
+    const bool q = (hf ^ hsel) != 0;
+    const int r8 = tid >> 3, c4 = (tid & 3) * 8;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {  // the two passes whose piece lies in this half: p = 2 g + q
+      const u32x4 mw = q ? t.am[2 * g + 1] : t.am[2 * g];
+      const u32x2 ev = q ? e[2 * g + 1] : e[2 * g];
+      const uint32_t e2 = (s < 2 ? ev[0] : ev[1]) >> (16 * (s & 1));  // bytes 2 s, 2 s + 1 of the 8
+      u32x4 vh, vl;
+      t16_unpack8(mw, e2, vh, vl);
+      const int row = (2 * g + (q ? 1 : 0)) * RP + r8;
+      *reinterpret_cast<u32x4*>(&ash[buf][row][c4]) = vh;
+      *reinterpret_cast<u32x4*>(&asl[buf][row][c4]) = vl;
+    }
+#pragma unroll
+    for (int g = 0; g < NBP / 2; ++g) {
+      *reinterpret_cast<u32x4*>(&bsh[buf][CP * (2 * g) + (q ? CP : 0) + r8][c4]) = q ? t.bh[2 * g + 1] : t.bh[2 * g];
+      *reinterpret_cast<u32x4*>(&bsl[buf][CP * (2 * g) + (q ? CP : 0) + r8][c4]) = q ? t.bl[2 * g + 1] : t.bl[2 * g];
+    }
+  };
+  f32x16 acc[2 * NB];
+#pragma unroll
+  for (int ct = 0; ct < 2 * NB; ++ct) acc[ct] = zero16();
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kk = 16 * s + 8 * h;
+      const u32x4 a_hi = *reinterpret_cast<const u32x4*>(&ash[buf][wave * 32 + rl][kk]);
+      const u32x4 a_lo = *reinterpret_cast<const u32x4*>(&asl[buf][wave * 32 + rl][kk]);
+#pragma unroll
+      for (int ct = 0; ct < 2 * NB; ++ct) {
+        const u32x4 bh = *reinterpret_cast<const u32x4*>(&bsh[buf][32 * ct + rl][kk]);
+        const u32x4 bl = *reinterpret_cast<const u32x4*>(&bsl[buf][32 * ct + rl][kk]);
+        acc[ct] = mfma_bf16x3(a_hi, a_lo, bh, bl, acc[ct]);
+      }
+    }
+  };
+  // Mega tile = 4 super tiles, fully unrolled (the exponent bytes of super tile s sit at a compile-time position of the
+  // thread's 8).  Two super tiles in registers; the next mega tile's exponents are requested during super tile 1 and are
+  // first needed when super tile 3 hands over to the next mega tile's super tile 0.
+  Super t0, t1;
+  u32x2 ex[4], ex_next[4];
+  load_exps(ex, 0);
+  load_super(t0, 0);
+  load_super(t1, 1);
+  store_half(t0, ex, 0, 0, 0);
+  __syncthreads();
+  const int n_mega = ns / 4;
+  for (int mg = 0; mg < n_mega; ++mg) {
+    const int st = 4 * mg;
+    const bool more = mg + 1 < n_mega;
+    // super tile 0 (in t0)
+    compute(0);
+    store_half(t0, ex, 0, 1, 1);
+    __syncthreads();
+    load_super(t0, st + 2);
+    compute(1);
+    store_half(t1, ex, 1, 0, 0);
+    __syncthreads();
+    // super tile 1 (in t1)
+    compute(0);
+    store_half(t1, ex, 1, 1, 1);
+    __syncthreads();
+    load_super(t1, st + 3);
+    if (more) load_exps(ex_next, mg + 1);
+    compute(1);
+    store_half(t0, ex, 2, 0, 0);
+    __syncthreads();
+    // super tile 2 (in t0)
+    compute(0);
+    store_half(t0, ex, 2, 1, 1);
+    __syncthreads();
+    if (more) load_super(t0, st + 4);
+    compute(1);
+    store_half(t1, ex, 3, 0, 0);
+    __syncthreads();
+    // super tile 3 (in t1)
+    compute(0);
+    store_half(t1, ex, 3, 1, 1);
+    __syncthreads();
+    if (more) load_super(t1, st + 5);
+    compute(1);
+    if (more) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) ex[p] = ex_next[p];
+      store_half(t0, ex, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const float alpha = OUT_MODE == 2 ? 1.0f : (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t gr = m0 + wave * 32 + acc_row(r, h);
+    if (gr < m) {
+#pragma unroll
+      for (int ct = 0; ct < 2 * NB; ++ct) {
+        const int gc = n0 + 32 * ct + rl;
+        if (gc >= n) continue;
+        if constexpr (OUT_MODE == 1) {
+          static_cast<uint32_t*>(c)[gr * n + gc] = split_pack(alpha * acc[ct][r]);
+        } else {
+          float* out = static_cast<float*>(c) + (OUT_MODE == 2 ? (int64_t)blockIdx.z * m * n : 0);
+          out[gr * n + gc] = alpha * acc[ct][r];
+        }
+      }
+    }
+  }
+}
+
 // Row-strip GEMM for the wide, write-dominated products with a short k (grad_T = g W^T, H = f W''):
 //   C[m, n] (packed words) = A[m, k] (packed words) * Bt[n, k]^T,   k <= 64, n large (C_in*K or C_out*K = 2048)
 // A wavefront keeps its 32 rows of A as MFMA fragments for the whole kernel and walks the n range 32 columns
@@ -525,13 +699,18 @@ __global__ void reduce_splits_kernel(const float* __restrict__ partials, void* _
 // One block: 128 (ka) x 64 (n) outputs over rows [split*chunk, (split+1)*chunk) in stages of 32 rows.
 // FAST (n % 4 == 0, operands < 4 GB): unconditional raw buffer loads bounded at the split's last row (rows
 // past it and columns past ka / n read as 0), stages prefetched 3 deep in registers like gemm_nn.
-// A24: A rows in the 3-byte format (common.h, T24; ka a multiple of 64); the partial rows are written at t24_k_of().
-template <bool FAST, bool A24>
+// AFMT 1: A rows in the 3-byte format (common.h, T24; ka a multiple of 64); the partial rows are written at t24_k_of().
+// AFMT 2: A rows in the 2.25-byte block format (T16; ka a multiple of 128): a stage reads 256 B of mantissas per row
+// and the two exponent bytes of every thread's piece, decodes to the same hi / lo 16-bit images (the lo plane is then
+// the bf16 lo operand itself: no rebuild in the MFMA stage); partial rows at t16_k_of().
+template <bool FAST, int AFMT>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __restrict__ a,
                                                            const uint32_t* __restrict__ b,
                                                            float* __restrict__ partials, int64_t m, int ka, int n,
                                                            int64_t chunk) {
-  static_assert(!A24 || FAST, "the 3-byte A format is only read through buffer loads");
+  constexpr bool A16 = AFMT == 2;
+  constexpr bool A24 = AFMT != 0;  // "the A operand comes as two 16-bit planes": everything below that is not format-specific
+  static_assert(!A24 || FAST, "the 3-byte / T16 A formats are only read through buffer loads");
   // A24: hi / lo planes of A (lo bytes widened to 16 bits) and of B as 16-bit images whose rows are the K index of
   // the MFMAs; the fragments come out of ds_read_b64_tr_b16 (common.h) ready-made: 12 LDS reads and no v_perm per
   // k-step where gathering them with scalar reads took 32 reads + 24 v_perm.  Row pitches of 16 (mod 64) dwords
@@ -554,14 +733,31 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
 
   struct Stage { u32x4 a0, a1, a2, a3, b0, b1; };
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint32_t*>(a), (short)0, FAST ? (int)(uint32_t)(me * ka * (A24 ? 3 : 4)) : 0, 0x00020000);
+      const_cast<uint32_t*>(a), (short)0, FAST ? (int)(uint32_t)(A16 ? me * (ka / 32 * 72) : me * ka * (A24 ? 3 : 4)) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint32_t*>(b), (short)0, FAST ? (int)(uint32_t)(me * n * 4) : 0, 0x00020000);
   const int arow = tid >> 5, acq = (tid & 31) * 4, brow = tid >> 4, bcq = (tid & 15) * 4;
   const bool a_ok = ka0 + acq < ka, b_ok = n0 + bcq < n;
   auto load_stage = [&](Stage& t, int64_t st) {
     const int64_t mm = mb + st * BK;
-    if constexpr (A24) {
+    if constexpr (A16) {
+      const uint32_t oob = 0xfffffff0u;
+      const uint32_t rb = (uint32_t)ka / 32u * 72u;
+      constexpr int kNtLoad = 2;
+      // mantissas: 32 rows x 256 B = 2 pieces of 16 B per thread (rows tid >> 4 and + 16, piece tid & 15 = 8 mantissas =
+      // blocks 2 pc, 2 pc + 1 of the 128 columns); their exponent bytes are adjacent in the plane (t16_exp_pos: bit 0)
+      const bool h_ok = ka0 + (tid & 15) * 8 < ka;
+      const uint32_t ho = (uint32_t)(mm + (tid >> 4)) * rb + (uint32_t)(ka0 + (tid & 15) * 8) * 2u;
+      const uint32_t eo = (uint32_t)(mm + (tid >> 4)) * rb + (uint32_t)ka * 2u + (uint32_t)t16_exp_pos((ka0 + (tid & 15) * 8) >> 2);
+      const uint32_t bo = b_ok ? (uint32_t)(((mm + brow) * n + n0 + bcq) * 4) : oob;
+      const uint32_t bs16 = (uint32_t)n * 64u;
+      t.a0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, h_ok ? ho : oob, 0, kNtLoad));
+      t.a1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, h_ok ? ho + 16u * rb : oob, 0, kNtLoad));
+      t.a2[0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(a_rs, h_ok ? eo : oob, 0, kNtLoad);
+      t.a2[1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(a_rs, h_ok ? eo + 16u * rb : oob, 0, kNtLoad);
+      t.b0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, bo, 0, 0));
+      t.b1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_ok ? bo + bs16 : oob, 0, 0));
+    } else if constexpr (A24) {
       const uint32_t oob = 0xfffffff0u;
       const uint32_t rb = (uint32_t)ka * 3u;
       // hi: 32 rows x 256 B = 2 pieces of 16 B per thread; lo: 32 rows x 128 B = 1 piece per thread.  The rows are
@@ -605,7 +801,21 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
     }
   };
   auto store_stage = [&](const Stage& t, int buf) {
-    if constexpr (A24) {
+    if constexpr (A16) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const u32x4 mw = p ? t.a1 : t.a0;
+        const uint32_t e2 = t.a2[p];
+        u32x4 vh, vl;
+        t16_unpack8(mw, e2, vh, vl);
+        *reinterpret_cast<u32x4*>(&ath[buf][16 * p + (tid >> 4)][(tid & 15) * 8]) = vh;
+        *reinterpret_cast<u32x4*>(&atl[buf][16 * p + (tid >> 4)][(tid & 15) * 8]) = vl;
+      }
+      *reinterpret_cast<u32x2*>(&bth[buf][brow][bcq]) = u32x2{pair_hi(t.b0[0], t.b0[1]), pair_hi(t.b0[2], t.b0[3])};
+      *reinterpret_cast<u32x2*>(&btl[buf][brow][bcq]) = u32x2{pair_lo(t.b0[0], t.b0[1]), pair_lo(t.b0[2], t.b0[3])};
+      *reinterpret_cast<u32x2*>(&bth[buf][brow + 16][bcq]) = u32x2{pair_hi(t.b1[0], t.b1[1]), pair_hi(t.b1[2], t.b1[3])};
+      *reinterpret_cast<u32x2*>(&btl[buf][brow + 16][bcq]) = u32x2{pair_lo(t.b1[0], t.b1[1]), pair_lo(t.b1[2], t.b1[3])};
+    } else if constexpr (A24) {
       *reinterpret_cast<u32x4*>(&ath[buf][tid >> 4][(tid & 15) * 8]) = t.a0;
       *reinterpret_cast<u32x4*>(&ath[buf][16 + (tid >> 4)][(tid & 15) * 8]) = t.a1;
       u32x4 e0, e1;  // 16 lo bytes -> 16 half-words
@@ -643,8 +853,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
         const int r0 = 16 * s + 8 * (grp >> 1) + q;
         const u32x4 a_hi = lds_frag_tr16(&ath[buf][r0][wave * 32 + col], &ath[buf][r0 + 4][wave * 32 + col]);
         const u32x4 lw = lds_frag_tr16(&atl[buf][r0][wave * 32 + col], &atl[buf][r0 + 4][wave * 32 + col]);
-        const u32x4 a_lo = {t24_lo_word<0, 2>(a_hi[0], lw[0]), t24_lo_word<0, 2>(a_hi[1], lw[1]),
-                            t24_lo_word<0, 2>(a_hi[2], lw[2]), t24_lo_word<0, 2>(a_hi[3], lw[3])};
+        u32x4 a_lo = lw;  // T16: the lo plane holds the bf16 lo operand itself
+        if constexpr (!A16)
+          a_lo = u32x4{t24_lo_word<0, 2>(a_hi[0], lw[0]), t24_lo_word<0, 2>(a_hi[1], lw[1]),
+                       t24_lo_word<0, 2>(a_hi[2], lw[2]), t24_lo_word<0, 2>(a_hi[3], lw[3])};
         u32x4 b_hi = lds_frag_tr16(&bth[buf][r0][col], &bth[buf][r0 + 4][col]);
         u32x4 b_lo = lds_frag_tr16(&btl[buf][r0][col], &btl[buf][r0 + 4][col]);
         acc0 = mfma_bf16x3(a_hi, a_lo, b_hi, b_lo, acc0);
@@ -710,7 +922,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
   for (int r = 0; r < 16; ++r) {
     const int kq = ka0 + wave * 32 + acc_row(r, h);
     if (kq < ka) {
-      const int row = A24 ? t24_k_of(kq) : kq;
+      const int row = A16 ? t16_k_of(kq) : (A24 ? t24_k_of(kq) : kq);
       if (n0 + rl < n) out[(int64_t)row * n + n0 + rl] = acc0[r];
       if (n0 + 32 + rl < n) out[(int64_t)row * n + n0 + 32 + rl] = acc1[r];
     }
@@ -839,7 +1051,8 @@ int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* b
 
 static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c, bool out_packed,
                              int64_t m, int n, int k, float* split_ws, const float* alpha_num, float alpha_scale,
-                             hipStream_t stream, bool a24, ReduceBatch* defer) {
+                             hipStream_t stream, int afmt, ReduceBatch* defer) {
+  const bool a24 = afmt == 1, a16 = afmt == 2;  // A rows: 0 packed words, 1 3-byte rows, 2 T16 (common.h)
   const int kp = (k + 31) / 32 * 32;
   const int nkt = kp / BK;
   int splits = split_ws ? gemm_nn_bf16_splits(m, n, k) : 1;
@@ -850,8 +1063,12 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
   const bool fast = (k % 32 == 0) && (m * (int64_t)k * 4 < (1ll << 32)) && ((int64_t)n * kp * 2 < (1ll << 32)) &&
                     ((m + BM) * (int64_t)k * 4 < (1ll << 32)) && ((int64_t)(n + 128) * kp * 2 < (1ll << 32));
   if (a24 && (!fast || k % 64 != 0)) return SE3_ERR_UNSUPPORTED;
-  const int st_per = (per + 1) / 2;  // 3-byte rows: the kernel walks super tiles of 64 k
-  if (a24) splits = (k / 64 + st_per - 1) / st_per;
+  // T16: mega tiles of 256 k; its rows are 2.25 bytes per element, addressed with 32-bit byte offsets like the others
+  if (a16 && (k % 256 != 0 || (m + BM) * ((int64_t)k / 32 * 72) >= (1ll << 32) || (int64_t)(n + 128) * kp * 2 >= (1ll << 32)))
+    return SE3_ERR_UNSUPPORTED;
+  int st_per = (per + 1) / 2;  // 3-byte / T16 rows: the kernels walk super tiles of 64 k
+  if (a16) st_per = (st_per + 3) / 4 * 4;  // whole mega tiles per split
+  if (a24 || a16) splits = (k / 64 + st_per - 1) / st_per;
   const dim3 grid24((unsigned)((m + BM - 1) / BM), grid.y, (unsigned)splits);
 #define SE3_NN_LAUNCH(MODE, F, NBV, OUT)                                                                              \
   hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, F, NBV>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), m, n, \
@@ -859,9 +1076,14 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
 #define SE3_NN_LAUNCH24(MODE, NBV, OUT)                                                                               \
   hipLaunchKernelGGL((gemm_nn_t24_kernel<MODE, NBV>), grid24, dim3(256), 0, stream, (const uint8_t*)a, bt_hi, bt_lo,   \
                      (void*)(OUT), m, n, k, st_per, alpha_num, alpha_scale)
+#define SE3_NN_LAUNCH16(MODE, NBV, OUT)                                                                               \
+  hipLaunchKernelGGL((gemm_nn_t16_kernel<MODE, NBV>), grid24, dim3(256), 0, stream, (const uint8_t*)a, bt_hi, bt_lo,   \
+                     (void*)(OUT), m, n, k, st_per, alpha_num, alpha_scale)
 #define SE3_NN(MODE, OUT)                                    \
   do {                                                       \
-    if (a24 && nbw == 2) SE3_NN_LAUNCH24(MODE, 2, OUT);      \
+    if (a16 && nbw == 2) SE3_NN_LAUNCH16(MODE, 2, OUT);      \
+    else if (a16) SE3_NN_LAUNCH16(MODE, 1, OUT);             \
+    else if (a24 && nbw == 2) SE3_NN_LAUNCH24(MODE, 2, OUT); \
     else if (a24) SE3_NN_LAUNCH24(MODE, 1, OUT);             \
     else if (fast && nbw == 2) SE3_NN_LAUNCH(MODE, true, 2, OUT); \
     else if (fast) SE3_NN_LAUNCH(MODE, true, 1, OUT);        \
@@ -888,6 +1110,7 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
 #undef SE3_NN
 #undef SE3_NN_LAUNCH
 #undef SE3_NN_LAUNCH24
+#undef SE3_NN_LAUNCH16
   return check_launch();
 }
 
@@ -896,18 +1119,18 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
 // of k at that size, so the blocks share nothing but the weights).
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
-                        float alpha_scale, hipStream_t stream, bool a24, ReduceBatch* defer) {
+                        float alpha_scale, hipStream_t stream, int afmt, ReduceBatch* defer) {
   if (m == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   const int64_t max_rows = (((1ll << 32) - 64) / ((int64_t)k * 4) - 2 * BM) / BM * BM;
   if (m <= max_rows || max_rows < BM || k % 32 != 0)
-    return gemm_nn_bf16_rows(a, bt_hi, bt_lo, c, out_packed, m, n, k, split_ws, alpha_num, alpha_scale, stream, a24, defer);
-  const int64_t a_row_bytes = (int64_t)k * (a24 ? 3 : 4);
+    return gemm_nn_bf16_rows(a, bt_hi, bt_lo, c, out_packed, m, n, k, split_ws, alpha_num, alpha_scale, stream, afmt, defer);
+  const int64_t a_row_bytes = afmt == 2 ? (int64_t)k / 32 * 72 : (int64_t)k * (afmt == 1 ? 3 : 4);
   for (int64_t m0 = 0; m0 < m; m0 += max_rows) {
     const int64_t mb = m - m0 < max_rows ? m - m0 : max_rows;
     if (int rc = gemm_nn_bf16_rows(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a) + m0 * a_row_bytes), bt_hi,
                                    bt_lo, static_cast<char*>(c) + m0 * (int64_t)n * 4, out_packed, mb, n, k, nullptr, alpha_num,
-                                   alpha_scale, stream, a24, nullptr))
+                                   alpha_scale, stream, afmt, nullptr))
       return rc;
   }
   return SE3_OK;
@@ -919,8 +1142,9 @@ size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k) {
 }
 
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
-                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, bool a24,
+                        int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, int afmt,
                         ReduceBatch* defer) {
+  const bool a24 = afmt == 1, a16 = afmt == 2;
   if (ka == 0 || n == 0) return SE3_OK;
   ProfScope prof(tag, stream);
   int64_t chunk = (m + splits - 1) / splits;
@@ -935,6 +1159,7 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
   if (zs > splits) zs = splits;
   const bool vec = n % 4 == 0, reach = (zs + 1) * chunk * widest < (1ll << 32) - 64;
   if (a24 && (!vec || !reach || ka % 64 != 0)) return SE3_ERR_UNSUPPORTED;
+  if (a16 && (!vec || !reach || ka % 256 != 0)) return SE3_ERR_UNSUPPORTED;
   for (int64_t z0 = 0; z0 < splits; z0 += zs) {
     const int64_t zn = splits - z0 < zs ? splits - z0 : zs, r0 = z0 * chunk;
     if (r0 >= m) {  // ranges past the last row (rounding of chunk): their partials are zeros
@@ -943,15 +1168,18 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
     }
     const int64_t mb = m - r0 < zn * chunk ? m - r0 : zn * chunk;
     const dim3 grid((unsigned)((ka + 127) / 128), (unsigned)((n + BN - 1) / BN), (unsigned)zn);
-    const uint32_t* ab = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a) + r0 * (int64_t)ka * (a24 ? 3 : 4));
+    const int64_t a_row_bytes = a16 ? (int64_t)ka / 32 * 72 : (int64_t)ka * (a24 ? 3 : 4);
+    const uint32_t* ab = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a) + r0 * a_row_bytes);
     const uint32_t* bb = b + r0 * n;
     float* pb = partials + z0 * ka * n;
-    if (a24)
-      hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
+    if (a16)
+      hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, 2>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
+    else if (a24)
+      hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, 1>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
     else if (vec && reach)
-      hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
+      hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, 0>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
     else
-      hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
+      hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, 0>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
   }
   if (defer) {
     defer->sum(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, false);

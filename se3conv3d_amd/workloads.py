@@ -187,7 +187,7 @@ def stage_moved_bytes(n: int, e: int, f: int, c: int, bytes_per_el=(3, 3, 4), kb
     intermediates it writes or reads.  ``bytes_per_el`` = bytes per element of (T, U, grad_T) as the library reports
     them for the shape (``se3conv_intermediate_bytes_per_element``: 3-byte rows, 4-byte words, 0 = never written)."""
     rows = n * f
-    t_bytes, u_bytes, g_bytes = (b * rows * c * kb for b in bytes_per_el)
+    t_bytes, u_bytes, g_bytes = (int(b * rows * c * kb) for b in bytes_per_el)  # (2.25 for the T16 block format)
     own = stage_owned_bytes(n, e, f, c, kb)
     act = 4 * rows * c
     return {"edge_t_fwd": own["edge_t_fwd"] + t_bytes, "gemm_out": own["gemm_out"] + t_bytes,

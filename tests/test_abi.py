@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "se3conv.h")
 def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(se3\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t|size_t|const char\*)\s+(se3\w+)\s*\(", text, flags=re.M)))
 
 
 def test_header_declares_the_expected_surface():
@@ -76,6 +76,17 @@ def test_intermediate_format_query(built_library):
     between = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 48, 48, 32, _lib.PRECISIONS["bf16x3"])  # two channels per lane: packed words
     assert [q(between, w) for w in range(3)] == [4, 4, 4]
     assert q(headline, 3) < 0 and q(_lib.Se3Shape(10, 10, 10, 0, 1, 8, 8, 32, 1), 0) < 0
+    # exact bytes per row; the third arithmetic mode keeps T / U of 64-channel rows (even frame count) in the 2.25-byte block format
+    rb = lambda shp, which: lib.se3conv_intermediate_row_bytes(C.byref(shp), which)
+    assert [rb(headline, w) for w in range(3)] == [64 * 32 * 3, 64 * 32 * 3, 64 * 32 * 4]
+    t16 = _lib.Se3Shape(65536, 65536, 2_000_000, 2, 2, 64, 64, 32, _lib.PRECISIONS["bf16x3_t16"])
+    assert [rb(t16, w) for w in range(3)] == [64 * 72, 64 * 72, 64 * 32 * 4] and [q(t16, w) for w in range(3)] == [2, 2, 4]
+    wide16 = _lib.Se3Shape(4096, 4096, 60_000, 2, 2, 128, 256, 32, _lib.PRECISIONS["bf16x3_t16"])
+    assert [rb(wide16, w) for w in range(3)] == [128 * 72, 256 * 72, 128 * 32 * 4]
+    narrow16 = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 32, 32, 32, _lib.PRECISIONS["bf16x3_t16"])   # not implemented there: as bf16x3
+    assert [rb(narrow16, w) for w in range(3)] == [32 * 32 * 3, 32 * 32 * 3, 32 * 32 * 4]
+    odd16 = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 64, 64, 32, _lib.PRECISIONS["bf16x3_t16"])      # F = 1 at 64 channels: single-wavefront kernel
+    assert [rb(odd16, w) for w in range(3)] == [64 * 32 * 3, 64 * 32 * 3, 64 * 32 * 4]
 
 
 def test_workspace_queries_of_degenerate_and_wide_shapes(built_library):

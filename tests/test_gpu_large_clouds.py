@@ -32,7 +32,7 @@ def _run(amd, pts, batch, frames_t, conv, x, g, radius):
     return out.detach(), x.grad.detach(), [p.grad.detach().clone() for p in conv.parameters()]
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])   # fp32: beyond the reach of its buffer-load forms too
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "bf16x3_t16"])   # fp32: beyond the reach of its buffer-load forms too
 @pytest.mark.parametrize("n,frames", [(140_000, 2)])         # 2 x 280 000 = 560 000 rows: above both row limits
 def test_two_copies_of_a_body_equal_the_body_alone(n, frames, precision):
     import se3conv3d_amd as amd

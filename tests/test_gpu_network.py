@@ -112,7 +112,7 @@ def test_reference_resnetformer_block_runs_unchanged(built_library):
     t = lambda k: torch.from_numpy(np.asarray(d[k])).to(DEV)
     pc = amd.pc.PointcloudRotEquiv.from_frames(t("pts"), t("batch"), t("frames"))
     nbh = amd.pc.BQNeighborhood(pc, pc, float(d["radius"]))
-    for precision, tol in (("fp32", 5e-6), ("bf16x3", 5e-5)):
+    for precision, tol in (("fp32", 5e-6), ("bf16x3", 5e-5), ("bf16x3_t16", 5e-5)):
         amd.set_precision(precision)
         blk = amd.ResNetFormer(32, 48, amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu"), amd.BatchNormPC, 0.0).to(DEV)
         state = {k[len("state/"):]: t(k) for k in d.files if k.startswith("state/")}

@@ -23,7 +23,7 @@ for i in range(n_cases):
     if n_out is None and f_in != f_out and rng.random() < 0.5:
         f_out = f_in
     c = T.random_case(100 + i, n_in, n_out, f_in, f_out, c_in, c_out, k_deg, batches)
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("bf16x3", "fp32", "bf16x3_t16"):
         amd.set_precision(prec)
         errs, _, _ = T.run_case_against_oracle(c, f_in, f_out, amd)
         m = max(errs.values())
@@ -40,7 +40,7 @@ for i in range(max(2, n_cases // 8)):
     if n_in > 3000 and c_in * c_out > 1024:
         c_in = c_out = 32
     c = T.random_case(500 + i, n_in, rng.choice([None, None, 1200]), f, f, c_in, c_out, rng.choice([6, 9]), rng.choice([1, 2]))
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("bf16x3", "fp32", "bf16x3_t16"):
         amd.set_precision(prec)
         errs, _, _ = T.run_case_against_oracle(c, f, f, amd)
         m = max(errs.values())

@@ -39,7 +39,7 @@ def main():
         ref = O.conv_forward_backward(d["pts_in"], d["pts_out"], d["frames_in"], d["frames_out"], d["neighbors"].long(),
                                       d["x"], d["proj_axes"], d["proj_biases"], d["conv_weights"], d["rho"], d["nu"],
                                       d["grad_out"], dtype=torch.float64)
-        for mode in ("fp32", "bf16x3"):
+        for mode in ("fp32", "bf16x3", "bf16x3_t16"):
             got = run(d, mode)
             print(f"{os.path.basename(f)[6:-4]:28s} {mode:7s} " + " ".join(f"{rel(u, v):9.2e}" for u, v in zip(got, ref)))
         gold = (d["out"], d["dx"], d["dA"], d["dbeta"], d["dW"])
