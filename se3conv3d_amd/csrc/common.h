@@ -376,7 +376,8 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
 int edge_param_grad_bf16_channel_blocks(int channels);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
-                                float* partials, int n_partials, int* n_used, hipStream_t stream);
+                                float* partials, int n_partials, int* n_used, hipStream_t stream, bool gt16 = false);  // gt16: grad_t rows in the T16 block format
+bool edge_param_grad_bf16_t16_rows(const EdgeGeom& g, int channels);
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream, const float* scale_num = nullptr, float scale = 1.0f,
                         bool frag_layout = false);
@@ -456,14 +457,16 @@ struct PrepBatch {
   void geometry(const float* pts, const float* frames, int64_t n, int f, float* records);
   void split(const float* src, uint32_t* dst, int64_t n);
   void weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
-               const float* scale_num = nullptr, float scale = 1.0f, bool frag_layout = false, int a_rowfmt = 0);  // a_rowfmt: k order of the A rows (0 natural, 1 3-byte rows, 2 T16)
+               const float* scale_num = nullptr, float scale = 1.0f, bool frag_layout = false, int a_rowfmt = 0,
+               bool out_t16 = false);  // a_rowfmt: k order of the A rows (0 natural, 1 3-byte rows, 2 T16); out_t16: mode 1's output columns in T16 order
   int launch(hipStream_t stream);
 };
 
 int launch_pack_geometry(const float* pts, const float* frames, int64_t n, int f, float* records, hipStream_t stream);
 bool gemm_strip_bf16_applicable(int64_t m, int n, int k);
 int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, uint32_t* c,
-                           int64_t m, int n, int k, hipStream_t stream);
+                           int64_t m, int n, int k, hipStream_t stream, bool out_t16 = false);  // out_t16: C rows in the T16 block format
+bool gemm_strip_t16_applicable(int64_t m, int n, int k);
 int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, void* c,
                         bool out_packed, int64_t m, int n, int k, float* split_ws, const float* alpha_num,
                         float alpha_scale, hipStream_t stream, int afmt = 0, ReduceBatch* defer = nullptr);  // afmt: A rows 0 packed, 1 3-byte, 2 T16

@@ -336,6 +336,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       for (int t = 0; t < CT; ++t) {
         const int ch0 = cbase + 32 * (CT * wv + t);
         if (t24 == 2) {  // 2.25-byte rows (common.h, T16): registers 4j .. 4j+3 of this lane = 4 consecutive channels = one block
+          if (!FULL && ch0 >= C) continue;  // C is a multiple of 64 (host): a 32-channel tile is inside the row or past it
           char* row = reinterpret_cast<char*>(t_out) + (item * NF + a) * t16_row_bytes(C);
           uint8_t* expo = reinterpret_cast<uint8_t*>(row) + (int64_t)C * kBasis * 2;
 #pragma unroll

@@ -682,6 +682,130 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void gemm_strip_bf16_kernel(c
 #undef SE3_WAIT_B
 }
 
+// The row-strip GEMM writing C (= grad_T) in the T16 block format (common.h): 2.25 instead of 4 bytes per element leave
+// the kernel, which is bound by its stores.  Column n of C is position n of the T16 row (the weights are prepared in that
+// order), so a 32-column tile = one channel quad x 8 basis functions x 4 channels: a block (4 channels of one basis
+// function) is four ADJACENT LANES of one accumulator register -- its maximum takes two DPP steps.  Mantissas and exponent
+// bytes go through wave-private LDS staging so that every store instruction writes 16 bytes per lane: a tile's 32 rows x
+// 64 B of mantissas as two stores, the 64 exponent bytes per row of a mega tile (8 column tiles) as two stores per mega tile
+// (2 + 1/4 store instructions per tile; the packed-word kernel issues 16).
+template <int KS>
+__global__ __launch_bounds__(256, 4) void gemm_strip_t16_kernel(const uint32_t* __restrict__ a,
+                                                                const uint16_t* __restrict__ bt_hi,
+                                                                const uint16_t* __restrict__ bt_lo,
+                                                                uint8_t* __restrict__ c, int64_t m, int n, int k) {
+  constexpr int KP = KS * 16;
+  __shared__ __attribute__((aligned(16))) uint16_t st_m[4][32][32 + 8];  // [wave][row][column], 80-byte pitch
+  __shared__ __attribute__((aligned(16))) uint8_t st_e[4][32][64 + 16];  // [wave][row][byte of the mega tile's exponent line]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rl = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  if (row0 >= m) return;
+  const __amdgpu_buffer_rsrc_t a_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a), (short)0, (int)(uint32_t)(m * k * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bh_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_hi), (short)0, (int)(uint32_t)((int64_t)n * KP * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bl_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(bt_lo), (short)0, (int)(uint32_t)((int64_t)n * KP * 2), 0x00020000);
+  u32x4 a_hi[KS], a_lo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int kk = 16 * ks + 8 * h;
+    uint32_t w[8];
+    const uint32_t off = kk < k ? (uint32_t)(((row0 + rl) * k + kk) * 4) : 0xfffffff0u;  // k % 8 == 0 (host)
+    const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, off, 0, 0);
+    const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(a_rs, kk < k ? off + 16 : 0xfffffff0u, 0, 0);
+    w[0] = v0[0], w[1] = v0[1], w[2] = v0[2], w[3] = v0[3], w[4] = v1[0], w[5] = v1[1], w[6] = v1[2], w[7] = v1[3];
+    frags_from_words(w, a_hi[ks], a_lo[ks]);
+  }
+  // weight fragments of the next tile through inline asm + counted waits, as in gemm_strip_bf16_kernel: vmcnt retires
+  // loads and stores in order, so "at most S outstanding" behind the S stores of a tile means the older loads have landed
+  static_assert(KS == 2 || KS == 4, "operand lists of SE3_WAIT_B16");
+  u32x4 bh[KS], bl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) bh[ks] = bl[ks] = u32x4{0u, 0u, 0u, 0u};
+  auto load_b = [&](int tile) {
+    const uint32_t off = (uint32_t)((tile * KS * 64 + lane) * 16);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "+v"(bh[ks]) : "v"(off), "s"(bh_rs), "n"(1024 * ks) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "+v"(bl[ks]) : "v"(off), "s"(bl_rs), "n"(1024 * ks) : "memory");
+    }
+  };
+#define SE3_WAIT_B16(CNT)                                                                                          \
+  do {                                                                                                             \
+    if constexpr (KS == 2)                                                                                         \
+      asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(bh[0]), "+v"(bh[1]), "+v"(bl[0]), "+v"(bl[1])::"memory");    \
+    else                                                                                                           \
+      asm volatile("s_waitcnt vmcnt(" #CNT ")"                                                                     \
+                   : "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[KS - 2]), "+v"(bh[KS - 1]), "+v"(bl[0]), "+v"(bl[1]),       \
+                     "+v"(bl[KS - 2]), "+v"(bl[KS - 1])::"memory");                                                \
+  } while (0)
+  // rows of C: 72 bytes per channel (n = channels * 32 columns); rows >= m fall outside the buffer and are dropped
+  const int64_t rb = (int64_t)n / 32 * 72;
+  const int64_t c_bytes = (m - row0) * rb;
+  const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(
+      c + row0 * rb, (short)0, (int)(uint32_t)(c_bytes > 0xffffffffll ? 0xffffffffll : c_bytes), 0x00020000);
+  // blockIdx.y selects a contiguous range of mega tiles; the mega tiles of a strip are walked from a rotated start
+  const int n_mega_all = n / 256;
+  const int per = (n_mega_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int mega_lo = (int)blockIdx.y * per;
+  const int n_mega = min(per, n_mega_all - mega_lo);
+  if (n_mega <= 0) return;
+  int mg = mega_lo + (int)(((blockIdx.x * 4 + wave) * 5u) % (unsigned)n_mega);
+  // store-side lane roles: lane l writes 16 bytes of row (l >> 2) + 16 i, piece l & 3
+  const int s_row = lane >> 2, s_pc = lane & 3;
+  load_b(mg * 8);
+  SE3_WAIT_B16(0);
+  for (int it = 0; it < n_mega; ++it) {
+    const int mg_next = mg + 1 < mega_lo + n_mega ? mg + 1 : mega_lo;
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+      const int tile = mg * 8 + tl;
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma_bf16x3(a_hi[ks], a_lo[ks], bh[ks], bl[ks], acc);
+      load_b(tl < 7 ? tile + 1 : mg_next * 8);  // in flight during the epilogue (after the last tile: one unused fetch)
+      // block = 4 adjacent lanes of one register: maximum by two DPP steps, exponent, mantissa
+      const int blk = (tile & 7) * 8 + (rl >> 2);  // block index inside the mega tile: (channel quad & 1) * 32 + basis function
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float mx = fabsf(acc[r]);
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx), 0xb1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx), 0x4e, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
+        int e = __builtin_amdgcn_frexp_expf(mx);
+        e = e < -kT16ExpBias ? -kT16ExpBias : (e > 127 ? 127 : e);
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const s16x2 q = __builtin_amdgcn_cvt_pknorm_i16(__builtin_ldexpf(acc[r], -e), 0.f);
+        st_m[wave][acc_row(r, h)][rl] = (uint16_t)q[0];
+        if ((rl & 3) == 0) st_e[wave][acc_row(r, h)][t16_exp_pos(blk) & 63] = (uint8_t)(e + kT16ExpBias);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&st_m[wave][s_row + 16 * i][s_pc * 8]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, c_rs, (int)((s_row + 16 * i) * rb + s_pc * 16), tile * 64, 0);
+      }
+      if (tl == 7) {  // the mega tile's exponent line of every row: 64 bytes
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(&st_e[wave][s_row + 16 * i][s_pc * 16]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, c_rs, (int)((s_row + 16 * i) * rb + s_pc * 16), n * 2 + mg * 64, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the staging rows are free for the next tile
+      if (tl == 7) SE3_WAIT_B16(4);     // the loads are older than this tile's 2 (+ 2 exponent) stores
+      else SE3_WAIT_B16(2);
+    }
+    mg = mg_next;
+  }
+#undef SE3_WAIT_B16
+}
+
 // out = alpha * sum_z partials[z]  (fp32 or packed words)
 template <bool OUT_PACKED>
 __global__ void reduce_splits_kernel(const float* __restrict__ partials, void* __restrict__ out, int64_t count,
@@ -1029,11 +1153,31 @@ bool gemm_strip_bf16_applicable(int64_t m, int n, int k) {
          (m + 128) * (int64_t)k * 4 < (1ll << 32) - 64 && (int64_t)(n + 64) * kp * 2 < (1ll << 32) - 64;
 }
 
+// T16 output: whole mega tiles of 256 columns, k of one or two 32-steps, rows addressed with 32-bit byte offsets
+bool gemm_strip_t16_applicable(int64_t m, int n, int k) {
+  const int kp = (k + 31) / 32 * 32;
+  return gemm_strip_bf16_applicable(m, n, k) && (kp == 32 || kp == 64) && k % 8 == 0 && n % 256 == 0 &&
+         (m + 128) * ((int64_t)n / 32 * 72) < (1ll << 32) - 64;
+}
+
 int launch_gemm_strip_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_hi, const uint16_t* bt_lo, uint32_t* c,
-                           int64_t m, int n, int k, hipStream_t stream) {
+                           int64_t m, int n, int k, hipStream_t stream, bool out_t16) {
   if (m == 0 || n == 0) return SE3_OK;
   if (!gemm_strip_bf16_applicable(m, n, k)) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
+  if (out_t16) {
+    if (!gemm_strip_t16_applicable(m, n, k)) return SE3_ERR_UNSUPPORTED;
+    const int64_t rbk = (m + 127) / 128;
+    int split = rbk >= 1024 ? 1 : (int)(1024 / rbk);  // <= 1024 workgroups = one resident round
+    const int n_mega = n / 256;
+    if (split > n_mega) split = n_mega;
+    const dim3 g16((unsigned)rbk, (unsigned)split);
+    if ((k + 31) / 32 * 32 == 32)
+      hipLaunchKernelGGL(gemm_strip_t16_kernel<2>, g16, dim3(256), 0, stream, a, bt_hi, bt_lo, (uint8_t*)c, m, n, k);
+    else
+      hipLaunchKernelGGL(gemm_strip_t16_kernel<4>, g16, dim3(256), 0, stream, a, bt_hi, bt_lo, (uint8_t*)c, m, n, k);
+    return check_launch();
+  }
   const int64_t row_blocks = (m + 127) / 128;
   int n_split = row_blocks >= 1024 ? 1 : (int)(1024 / row_blocks);  // <= 1024 workgroups = one resident round (4 per CU)
   const int n_tiles = n / 32;

@@ -67,7 +67,7 @@ __device__ void job_weights(const PrepJob& j, int block, int blocks) {
       // the A operand is in the 3-byte (2) or the T16 (4) row format: its k order
       const int ks = (frag & 2) ? t24_k_of(kk) : ((frag & 4) ? t16_k_of(kk) : kk);
       if (mode == 0) v = w[(int64_t)ks * c_out + nn];
-      else if (mode == 1) v = w[(int64_t)nn * c_out + kk];
+      else if (mode == 1) v = w[(int64_t)((frag & 8) ? t16_k_of(nn) : nn) * c_out + kk];  // 8: output columns in T16 order
       else if (mode == 2) v = w[((int64_t)nn * kb + (ks % kb)) * c_out + ks / kb];
       else v = w[((int64_t)kk * kb + (nn % kb)) * c_out + nn / kb];
     }
@@ -120,7 +120,7 @@ void PrepBatch::split(const float* src, uint32_t* dst, int64_t n) {
 }
 
 void PrepBatch::weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
-                        const float* scale_num, float scale, bool frag_layout, int a_rowfmt) {
+                        const float* scale_num, float scale, bool frag_layout, int a_rowfmt, bool out_t16) {
   int n, k;
   if (mode == 0) n = c_out, k = c_in * kb;
   else if (mode == 1) n = c_in * kb, k = c_out;
@@ -130,7 +130,7 @@ void PrepBatch::weights(const float* w, int c_in, int kb, int c_out, int mode, u
   PrepJob& j = jobs.job[jobs.count++];
   j = PrepJob{};
   j.type = kJobWeights, j.blocks = blocks_for((int64_t)n * kp, 2048), j.a = w, j.b = scale_num, j.o0 = bt_hi, j.o1 = bt_lo;
-  j.p[0] = c_in, j.p[1] = kb, j.p[2] = c_out, j.p[3] = mode, j.p[4] = n, j.p[5] = k, j.p[6] = kp, j.p[7] = (frag_layout ? 1 : 0) | (a_rowfmt == 1 ? 2 : 0) | (a_rowfmt == 2 ? 4 : 0);
+  j.p[0] = c_in, j.p[1] = kb, j.p[2] = c_out, j.p[3] = mode, j.p[4] = n, j.p[5] = k, j.p[6] = kp, j.p[7] = (frag_layout ? 1 : 0) | (a_rowfmt == 1 ? 2 : 0) | (a_rowfmt == 2 ? 4 : 0) | (out_t16 ? 8 : 0);
   j.scale = scale;
 }
 
