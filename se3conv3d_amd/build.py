@@ -81,7 +81,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
+        # --no-undefined: a declaration that ran ahead of its definition must fail HERE, not as an undefined symbol when
+        # the GPU box loads the library
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,--no-undefined", *objs, "-o", LIB])
     with open(stamp, "w") as fh:
         fh.write(fp + "\n")
     return LIB

@@ -670,13 +670,22 @@ static int row_format(const se3conv_shape* s, const EdgeGeom& g, int channels, i
   return on && kBasis == 32 && channels % 2 == 0 && edge_t_bf16_t24_rows(g, channels) && tn_cols % 4 == 0 ? 1 : 0;
 }
 
+// grad_T in the T16 block format (SE3_PRECISION_BF16X3_T16): when the row-strip GEMM can write it (rows of whole mega tiles,
+// c_out <= 64) and the pair form of the parameter-gradient kernel reads it (two frames per point, 64-channel blocks)
+static bool grad_t_t16(const se3conv_shape* s, const EdgeGeom& g) {
+  const int64_t rows_out = s->n_out * s->f_out;
+  return s->precision == SE3_PRECISION_BF16X3_T16 && s->num_basis == kBasis &&
+         gemm_strip_t16_applicable(rows_out, s->c_in * kBasis, s->c_out) && edge_param_grad_bf16_t16_rows(g, s->c_in);
+}
+
 // Bytes per element of the row-sized intermediates this shape would move (what a traffic model has to assume):
 // which = 0: T (forward, read again by the weight gradient), 1: U (feature gradient), 2: grad_T.  < 0: bad shape.
 // The T16 format's 2.25 bytes are reported as 2 here (an integer interface); se3conv_intermediate_row_bytes is exact.
 static int64_t intermediate_row_bytes(const se3conv_shape* s, int which) {
   const int64_t ck = (int64_t)(which == 1 ? s->c_out : s->c_in) * s->num_basis;
-  if (s->precision == SE3_PRECISION_FP32 || which == 2 || s->num_basis != kBasis) return ck * 4;
+  if (s->precision == SE3_PRECISION_FP32 || s->num_basis != kBasis) return ck * 4;
   EdgeGeom g = forward_geom(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+  if (which == 2) return grad_t_t16(s, g) ? t16_row_bytes(s->c_in) : ck * 4;
   EdgeGeom gt{};
   gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.n_nb = s->n_out, gt.transposed = 1;
   const int fmt = which == 0 ? row_format(s, g, s->c_in, s->n_out * s->f_out, s->c_out)
@@ -935,6 +944,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   const int t24_t = row_format(s, g, s->c_in, rows_out, s->c_out);  // as se3conv_fwd
   const int t24_u = feat_branch ? row_format(s, gt, s->c_out, rows_in, 0) : 0;
   const bool strip_t = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);            // grad_T = g W^T
+  const bool gt16 = strip_t && grad_t_t16(s, g);                                      // ... written as T16 rows
   {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
@@ -949,7 +959,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (want_params) {
       pb.split(feat, featpk, rows_in * s->c_in);
       // alpha = nu/F_in is folded into these weights (one multiply per weight instead of one per grad_T element)
-      pb.weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, nu, inv_fin, strip_t);
+      pb.weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, nu, inv_fin, strip_t, 0, gt16);
     }
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
@@ -976,7 +986,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (!grad_axes && !grad_biases) return SE3_OK;
     int n_part = 0;
     if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw, partials,
-                                             l.n_param_partials, &n_part, st))
+                                             l.n_param_partials, &n_part, st, gt16))
       return rc;
     final_sums.params(partials, n_part, grad_axes, grad_biases, 0.5f);
     return SE3_OK;
@@ -1016,7 +1026,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs, -1, -1, t24_u))
         return rc;
       if (strip_t) {
-        if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream)) return rc;
+        if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream, gt16)) return rc;
       } else if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
                                               (float*)(ws + l.split), nullptr, 1.0f, stream)) {
         return rc;
@@ -1036,7 +1046,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   }
   if (want_params) {
     if (strip_t) {
-      if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream)) return rc;
+      if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream, gt16)) return rc;
     } else if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
                                             (float*)(ws + l.split), nullptr, 1.0f, stream)) {
       return rc;

@@ -528,7 +528,10 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 // wavefront v builds the image of frame v (32 of the 64 row loads) and takes the chunks v, v + 2, ... of the item for
 // both frames; two workgroup barriers per item (image built / image free), partial sums folded per workgroup.
 // POW2: the neighbour cloud's frame count is a power of two (fnb_shift >= 0) -- no division path, no branch on it
-template <int CH16, int NFR, bool PAIR = false, bool POW2 = false>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
+// GT16: grad_T rows come in the T16 block format (common.h; pair form, 64-channel blocks): a lane's 8 channels of a k-step
+// are two blocks of its basis function -- two 8-byte mantissa loads + the exponent line's 8-byte group per k-step instead
+// of eight dword loads, decoded to the same fragment image (t16_unpack2).
+template <int CH16, int NFR, bool PAIR = false, bool POW2 = false, bool GT16 = false>  // NFR = frames per wavefront: 2 (even F) or 1 (odd F: both lane halves hold the frame)
 __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_PAIR_WAVES : (NFR == 2 ? 2 : (CH16 == 3 ? 3 : SE3_PG_SINGLE_WAVES))) void edge_param_grad_bf16_v2_kernel(EdgeGeom g, const uint32_t* __restrict__ feat,
                                                                          int row_ch, int64_t feat_rows,
                                                                          const float* __restrict__ axes_ext,
@@ -541,6 +544,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
   // row recomputes the descriptors and GELU').  row_ch = channels per row (a multiple of 16).
   // wavefronts per block: the gT images (8 KB per frame and wavefront) bound the occupancy
   static_assert(!PAIR || NFR == 2, "the pair form shares the two frames of a point");
+  static_assert(!GT16 || (PAIR && CH16 == 4), "T16 grad_T rows: pair form on whole 64-channel blocks");
   constexpr bool LEAN = PAIR && SE3_PG_PAIR_LEAN;
   constexpr int NW = PAIR ? 2 : (NFR == 2 ? 8 : 4);
   constexpr int NIMG = PAIR ? 1 : NW;        // grad_T images per workgroup
@@ -610,6 +614,26 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     // (pair form: this wavefront fetches and builds the image of frame `wave` only)
     constexpr int NBUILD = PAIR ? 1 : NFR;
     uint32_t gw[NBUILD][CH16][8];
+    if constexpr (GT16) {
+      // row `wave` of the item: mantissas of channel quad cq = c_off / 4 + 4 st + 2 h + jj at (cq * 32 + kcol) * 8; the
+      // exponents of both jj sit in one 8-byte group of the row's exponent plane (t16_exp_pos: mega tile = cq >> 1, piece
+      // = (kcol >> 1) & 7; byte (2 jj + (kcol >> 4)) * 2 + (kcol & 1))
+      const int64_t rbytes = t16_row_bytes(row_ch);
+      const uint64_t gt_addr = reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(grad_t) + (item * NFR + wave) * rbytes);
+      const uint64_t gt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gt_addr >> 32)) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gt_addr);
+      const __amdgpu_buffer_rsrc_t gt_rs = buffer_of(reinterpret_cast<const void*>(gt_base), rbytes);
+      const int cq0 = (c_off >> 2) + 2 * h;
+      const int e_off = row_ch * 64 + ((kcol >> 1) & 7) * 8, e_sh = 8 * ((kcol >> 4) * 2 + (kcol & 1));
+#pragma unroll
+      for (int st = 0; st < CH16; ++st) {
+        const auto m0 = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, ((cq0 + 4 * st) * kBasis + kcol) * 8, 0, 0);
+        const auto m1 = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, ((cq0 + 4 * st + 1) * kBasis + kcol) * 8, 0, 0);
+        const auto eg = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, e_off + ((cq0 + 4 * st) >> 1) * 64, 0, 0);
+        gw[0][st][0] = m0[0], gw[0][st][1] = m0[1], gw[0][st][2] = m1[0], gw[0][st][3] = m1[1];
+        gw[0][st][4] = (eg[0] >> e_sh) & 0xffu, gw[0][st][5] = (eg[1] >> e_sh) & 0xffu;
+      }
+    } else
 #pragma unroll
     for (int ab = 0; ab < NBUILD; ++ab) {
       const int a = PAIR ? wave : ab;
@@ -638,6 +662,14 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       for (int st = 0; st < CH16; ++st) {
         const int a = PAIR ? wave : ab;
         u32x4 f_hi, f_lo;
+        if constexpr (GT16) {
+          const float sc0 = t16_scale(gw[ab][st][4]), sc1 = t16_scale(gw[ab][st][5]);
+          uint32_t hw, lw;
+          t16_unpack2(gw[ab][st][0], sc0, hw, lw), f_hi[0] = hw, f_lo[0] = lw;
+          t16_unpack2(gw[ab][st][1], sc0, hw, lw), f_hi[1] = hw, f_lo[1] = lw;
+          t16_unpack2(gw[ab][st][2], sc1, hw, lw), f_hi[2] = hw, f_lo[2] = lw;
+          t16_unpack2(gw[ab][st][3], sc1, hw, lw), f_hi[3] = hw, f_lo[3] = lw;
+        } else
         frags_from_words(gw[ab][st], f_hi, f_lo);
         *reinterpret_cast<u32x4*>(&lds_gt[img][a][st][0][lane][0]) = f_hi;
         *reinterpret_cast<u32x4*>(&lds_gt[img][a][st][1][lane][0]) = f_lo;
@@ -1004,14 +1036,24 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   return check_launch();
 }
 
+// grad_T rows in the T16 block format: the pair form (two frames per point) on whole 64-channel blocks
+bool edge_param_grad_bf16_t16_rows(const EdgeGeom& g, int channels) {
+  static const bool pair_on = [] {
+    const char* e = getenv("SE3_PG_PAIR");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return pair_on && getenv("SE3_PG_SINGLE") == nullptr && g.f_ctr % 2 == 0 && channels % 64 == 0 && channels >= 64;
+}
+
 // partials: room for n_partials x edge_param_grad_bf16_channel_blocks(channels) slots of 320 floats; *n_used = slots written
 int edge_param_grad_bf16_channel_blocks(int channels) { return channels > 64 && channels % 16 == 0 ? (channels + 63) / 64 : 1; }
 
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
-                                float* partials, int n_partials, int* n_used, hipStream_t stream) {
+                                float* partials, int n_partials, int* n_used, hipStream_t stream, bool gt16) {
   const int64_t rows = g.n_ctr * g.f_ctr;
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
+  if (gt16 && !edge_param_grad_bf16_t16_rows(g, channels)) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
   *n_used = n_partials;
   if (channels % 16 == 0 && channels > 0) {
@@ -1060,6 +1102,12 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
                            feat_rows, axes_ext, rho, grad_t, partials, items, shift);
       else if (channels == 32)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<2, 2, true, false>), pgrid, dim3(128), 0, stream, g, feat, channels,
+                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+      else if (gt16 && shift >= 0)
+        hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
+                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+      else if (gt16)
+        hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, false, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
                            feat_rows, axes_ext, rho, grad_t, partials, items, shift);
       else if (shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
