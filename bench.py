@@ -504,6 +504,8 @@ def run_rank(args):
                     lv["conv"](p_pc_in=lv["pc"], p_pc_out=lv["pc"], p_in_features=lv["x"], p_neighborhood=lv["nbh"])
 
         try:
+            if args.no_extra:
+                raise RuntimeError("skipped (--no-extra)")
             for lv in levels:
                 lv["conv"].eval()
             run_fwd = (lambda: forward_only(levels)) if args.no_graph else GraphedStep(levels, fn=forward_only)
@@ -527,6 +529,7 @@ def run_rank(args):
         # replays as ONE captured graph; the overflow flags are read once after the timed region.
         caps = [int(lv["e"] * 1.25) + 64 for lv in levels]
         flags = []
+        extra = not args.no_extra
 
         def e2e_step(lvls):
             flags.clear()
@@ -560,21 +563,22 @@ def run_rank(args):
             assert all(int(f[1]) == 0 for f in flags), "ball query overflowed its edge buffer"
             assert [int(f[0]) for f in flags] == [lv["e"] for lv in levels], "bounded ball query found a different edge count"
 
-        run_e2e = (lambda: e2e_step(levels)) if args.no_graph else GraphedStep(levels, fn=e2e_step)
-        ms_e2e = timed(run_e2e, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
-        check_flags()
-        run_e2e_ov = (lambda: e2e_step_overlapped(levels)) if args.no_graph else GraphedStep(levels, fn=e2e_step_overlapped)
-        ms_e2e_ov = timed(run_e2e_ov, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
-        check_flags()
-        ms_e2e_eager = timed(lambda: e2e_step(levels), max(5, args.steps // 4), 2) / max(5, args.steps // 4) * 1e3
-        result["end_to_end"] = {"ms_per_step": round(ms_e2e, 4), "value": mpts(ms_e2e), "unit": "Mpoints/s",
-                                "neighbourhood_ms": round(ms_e2e - ms_step, 4), "eager_ms_per_step": round(ms_e2e_eager, 4),
-                                "overlapped": {"ms_per_step": round(ms_e2e_ov, 4), "value": mpts(ms_e2e_ov),
-                                               "neighbourhood_ms": round(ms_e2e_ov - ms_step, 4),
-                                               "note": "levels 1-3 build their neighbourhoods on a second stream under level 0's "
-                                                       "convolution (they depend on the points only); same graph, same results"},
-                                "note": "ball query of every level (capacity-bounded edge buffers, no host sync) + the conv step, "
-                                        "one captured graph, level by level on one stream; eager_ms_per_step = the same launched from Python"}
+        if extra:
+            run_e2e = (lambda: e2e_step(levels)) if args.no_graph else GraphedStep(levels, fn=e2e_step)
+            ms_e2e = timed(run_e2e, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
+            check_flags()
+            run_e2e_ov = (lambda: e2e_step_overlapped(levels)) if args.no_graph else GraphedStep(levels, fn=e2e_step_overlapped)
+            ms_e2e_ov = timed(run_e2e_ov, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
+            check_flags()
+            ms_e2e_eager = timed(lambda: e2e_step(levels), max(5, args.steps // 4), 2) / max(5, args.steps // 4) * 1e3
+            result["end_to_end"] = {"ms_per_step": round(ms_e2e, 4), "value": mpts(ms_e2e), "unit": "Mpoints/s",
+                                    "neighbourhood_ms": round(ms_e2e - ms_step, 4), "eager_ms_per_step": round(ms_e2e_eager, 4),
+                                    "overlapped": {"ms_per_step": round(ms_e2e_ov, 4), "value": mpts(ms_e2e_ov),
+                                                   "neighbourhood_ms": round(ms_e2e_ov - ms_step, 4),
+                                                   "note": "levels 1-3 build their neighbourhoods on a second stream under level 0's "
+                                                           "convolution (they depend on the points only); same graph, same results"},
+                                    "note": "ball query of every level (capacity-bounded edge buffers, no host sync) + the conv step, "
+                                            "one captured graph, level by level on one stream; eager_ms_per_step = the same launched from Python"}
 
         # The convolutions BETWEEN two levels: the encoder's first down-convolution (level 0 -> 1) and
         # the decoder's last up-convolution (level 1 -> 0) of this workload's hierarchy (and of dfaust_f2's, the
@@ -616,6 +620,8 @@ def run_rank(args):
             return leg
 
         try:
+            if not extra:
+                raise RuntimeError("skipped (--no-extra)")
             result["down_up"] = {w: down_up_leg(w) for w in dict.fromkeys([args.workload, "dfaust_f2"])}
             result["down_up"]["note"] = ("level 0 -> 1 down-convolution (radius of level 0) and level 1 -> 0 up-convolution (radius of "
                                          "level 1) of the workload's hierarchy, fwd+bwd; layer_frac on SURVEY 8d's bytes for N_in != N_out")
@@ -623,7 +629,7 @@ def run_rank(args):
             result["down_up"] = {"error": str(exc)[:200]}
             torch.cuda.synchronize()
 
-        if not args.no_fp32 and args.precision != "fp32":
+        if not args.no_fp32 and not args.no_extra and args.precision != "fp32":
             amd.set_precision("fp32")
             run32 = (lambda: step(levels)) if args.no_graph else GraphedStep(levels)
             ms32 = timed(run32, max(3, args.steps // 2), 2) / max(3, args.steps // 2) * 1e3
@@ -635,7 +641,7 @@ def run_rank(args):
         # like the headline (same stack, graph replay) with its error measured at FULL size: every output and gradient of
         # the level-0 layer against the exact-fp32 mode's (itself within 1.5e-6 of the fp64 oracle), next to the default
         # mode's own distance -- the measured cost in accuracy of the bytes it saves.  Opt-in: not part of `value`.
-        if args.precision == "bf16x3" and not args.no_t16:
+        if args.precision == "bf16x3" and not args.no_t16 and not args.no_extra:
             def layer_results(prec):
                 amd.set_precision(prec)
                 lv = levels[0]
@@ -712,6 +718,8 @@ def main(argv=None):
                     help="row order of the synthetic points: as drawn, or sorted along a Z-order curve per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 leg")
+    ap.add_argument("--no-extra", action="store_true", help="A/B runs: only the stack, the single layer and its stage times (no forward_only / "
+                    "end_to_end / down_up / t16 / fp32 legs)")
     ap.add_argument("--no-t16", action="store_true", help="skip the leg of the third arithmetic mode (T / U in the 2.25-byte block format)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the N-rank protocol (no GPU work)")

@@ -28,7 +28,7 @@
  *     a stream per request does not grow the table; (3) kernel-variant switches read ONCE from the environment at first
  *     use (A/B knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP, SE3_OVERLAP_ROWS,
  *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32),
- *     SE3_NN_SPLITS.
+ *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower), SE3_PAIR_DYNAMIC.
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - return value: SE3_OK (0) or a negative SE3_ERR_* code; no exceptions cross the boundary.
  *
@@ -190,6 +190,11 @@ int se3_frame_unpool(const float* grad_out, const int32_t* arg, int64_t n_points
  * int(((max - 1e-6) - aabb_min) / radius) + 1.  aabb_max_scratch: [n_batches,3] floats of scratch. */
 int se3_ball_query_grid(const float* pts_src, const int32_t* batch_src, int64_t n_src, int32_t n_batches, float radius,
                         float* aabb_min, float* aabb_max_scratch, int32_t* num_cells, void* stream);
+/* The same from bounding boxes that are already known (se3_batch_aabb's box_min / box_max [n_batches,3] of the SOURCE
+ * cloud): a cloud is the source of three or four queries per step in the reference's networks (same-level, down, up) and
+ * its boxes do not depend on the radius -- one small launch instead of a pass over the points. */
+int se3_ball_query_grid_from_box(const float* box_min, const float* box_max, int32_t n_batches, float radius,
+                                 float* aabb_min, int32_t* num_cells, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ball query  <-  point_cloud_lib_ops.ball_query

@@ -52,6 +52,7 @@ SIGNATURES = {
     "se3_frame_pool": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "se3_frame_unpool": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "se3_ball_query_grid": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P, _P, _P]),
+    "se3_ball_query_grid_from_box": (C.c_int, [_P, _P, _I32, _F, _P, _P, _P]),
     "se3_ball_query_needs_grid": (C.c_int, [_I64]),
     "se3_ball_query_workspace_bytes": (_SZ, [_I64, _I64]),
     "se3_ball_query_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _SZ, _P, _P]),

@@ -672,9 +672,16 @@ static int row_format(const se3conv_shape* s, const EdgeGeom& g, int channels, i
 
 // grad_T in the T16 block format (SE3_PRECISION_BF16X3_T16): when the row-strip GEMM can write it (rows of whole mega tiles,
 // c_out <= 64) and the pair form of the parameter-gradient kernel reads it (two frames per point, 64-channel blocks)
+// OPT-IN (SE3_T16_GT=1): measured a net loss at the headline shape -- the strip GEMM gains 0.015 ms on 44 % fewer bytes
+// (its epilogue, not its stores, now sets its time) and the parameter-gradient kernel loses 0.04 ms to the decode in
+// front of every item's first chunk (profiles/r04_t16_ab.txt); T and U alone are the mode's default.
 static bool grad_t_t16(const se3conv_shape* s, const EdgeGeom& g) {
+  static const bool on = [] {
+    const char* e = getenv("SE3_T16_GT");
+    return e != nullptr && atoi(e) != 0;
+  }();
   const int64_t rows_out = s->n_out * s->f_out;
-  return s->precision == SE3_PRECISION_BF16X3_T16 && s->num_basis == kBasis &&
+  return on && s->precision == SE3_PRECISION_BF16X3_T16 && s->num_basis == kBasis &&
          gemm_strip_t16_applicable(rows_out, s->c_in * kBasis, s->c_out) && edge_param_grad_bf16_t16_rows(g, s->c_in);
 }
 

@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
                          // 16 no geometry gathers / descriptor / descriptor split (upper bound of what a descriptor stash written by the forward could save)
 #endif
 #ifndef SE3_PAIR_ABLATE
-#define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi, 64 no barrier between the partner wavefronts
+#define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi, 64 no barrier between the partner wavefronts,
+                           // 128 the chunk's feature rows fetched as FOUR 16-byte loads per lane (8 rows x 128 B per instruction: the access
+                           // shape of an LDS-staged gather) instead of sixteen dword gathers -- same bytes, a quarter of the VMEM and
+                           // ds_bpermute instructions, without the LDS round trip a real version needs: the upper bound of that variant
 #endif
 #ifndef SE3_PAIR_PIN
 #define SE3_PAIR_PIN 1  // centre record passed through an empty asm at the top of every chunk: nothing derived from it is hoisted out
@@ -171,11 +174,16 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
 #endif
 // POW2: fnb_shift >= 0 is known (no division path, no branch on it).  TR: 0 forward, 1 transposed pass, -1 decided by
 // g.transposed at run time (both descriptor paths in the loop)
+// SE3_PAIR_DYNAMIC=1 (with SE3_PAIR_PERSIST=n; an A/B switch, one launch at a time per device): persistent workgroups CLAIM
+// their next item from a device counter instead of striding -- what static striding loses to imbalance (-5 %) against
+// what the prologue paid once per workgroup returns.  The last workgroup to finish re-arms the counter.
+__device__ int g_pair_claim[2];  // [0] next item, [1] workgroups done
 template <int CT, bool FULL, int NF, bool POW2 = false, int TR = -1>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift,
-    int t24) {
+    int t24, int dynamic) {
+  __shared__ int lds_next_item;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
   __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   int buf = 0;
   // Persistent workgroups (SE3_PAIR_PERSIST): the block walks items blockIdx.x, blockIdx.x + gridDim.x, ... so that
   // the kernel prologue (arguments, descriptors, MLP weights into LDS) is paid once per block, not once per item.
-  for (int64_t item = item_lo + blockIdx.x; item < n_items; item += gridDim.x) {  // items item_lo .. n_items-1
+  for (int64_t item = item_lo + blockIdx.x; item < n_items;) {  // items item_lo .. n_items-1
   // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
   const int64_t ctr = (uint32_t)item / (uint32_t)groups;
   const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NF;
@@ -262,6 +270,18 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       // gathered feature words for this wavefront's channels (shared by both frames): all loads go out now and are
       // only turned into MFMA fragments after the barrier below
       uint32_t fw[CT][2][8];
+      if (SE3_PAIR_ABLATE & 128) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int src_off = __builtin_amdgcn_ds_bpermute(4 * (8 * i + (lane >> 3)), qoff);
+#pragma unroll
+          for (int t = 0; t < CT; ++t) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, src_off + cbase * 4 + 128 * (CT * wv + t) + (lane & 7) * 16, 0, 0);
+            fw[t][i >> 1][4 * (i & 1)] = v[0], fw[t][i >> 1][4 * (i & 1) + 1] = v[1];
+            fw[t][i >> 1][4 * (i & 1) + 2] = v[2], fw[t][i >> 1][4 * (i & 1) + 3] = v[3];
+          }
+        }
+      } else
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -387,6 +407,19 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       }
     if (cbase + 64 * CT < C) __syncthreads();  // the next pass reuses the phi buffers from their start
   }
+  if (!dynamic) {
+    item += gridDim.x;
+  } else {
+    __syncthreads();
+    if (threadIdx.x == 0) lds_next_item = atomicAdd(&g_pair_claim[0], 1);
+    __syncthreads();
+    item = item_lo + gridDim.x + lds_next_item;
+  }
+  }
+  if (dynamic && threadIdx.x == 0 && atomicAdd(&g_pair_claim[1], 1) == (int)gridDim.x - 1) {
+    g_pair_claim[0] = 0;
+    g_pair_claim[1] = 0;
+    __threadfence();
   }
 }
 
@@ -982,16 +1015,21 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
       const char* e = getenv("SE3_PAIR_PERSIST");
       return e ? atoi(e) : 0;
     }();
+    static const int dynamic_env = [] {
+      const char* e = getenv("SE3_PAIR_DYNAMIC");
+      return e ? atoi(e) : 0;
+    }();
     const int per = two ? 2 : 1;
     const int64_t item_lo = row_lo >= 0 ? row_lo / per : 0;
     const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
     const int64_t n_range = item_hi - item_lo;
     if (n_range <= 0) return SE3_OK;
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
+    const int dynamic = dynamic_env != 0 && pblocks < n_range ? 1 : 0;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
 #define SE3_PAIR_T(CT, FULL, NF, P2, TR)                                                                                \
   hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                     axes_ext, rho, t_out, item_lo, item_hi, shift, rowfmt)
+                     axes_ext, rho, t_out, item_lo, item_hi, shift, rowfmt, dynamic)
 #define SE3_PAIR_L(CT, FULL, NF, P2)                 \
   do {                                               \
     if (!(P2)) SE3_PAIR_T(CT, FULL, NF, P2, -1);     \

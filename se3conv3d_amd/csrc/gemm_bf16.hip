@@ -20,6 +20,9 @@ namespace {
 #ifndef SE3_GEMM_ABLATE
 #define SE3_GEMM_ABLATE 0  // diagnostic builds: 1 no MFMA stage, 2 no LDS staging, 4 no barriers
 #endif
+#ifndef SE3_T16_ABLATE
+#define SE3_T16_ABLATE 0  // diagnostic builds of gemm_nn_t16_kernel (wrong results): 1 no decode, 2 no weight loads, 4 no MFMA stage
+#endif
 #ifndef SE3_GEMM_DEPTH
 #define SE3_GEMM_DEPTH 4
 #endif
@@ -424,6 +427,10 @@ __global__ __launch_bounds__(256) void gemm_nn_t16_kernel(const uint8_t* __restr
     }
 #pragma unroll
     for (int j = 0; j < NBP; ++j) {
+#if SE3_T16_ABLATE & 2
+      t.bh[j] = t.bl[j] = u32x4{k0, k0, k0, k0};
+      continue;
+#endif
       const uint32_t off = ((uint32_t)(n0 + CP * j + (tid >> 3)) * (uint32_t)k + k0 + (uint32_t)((tid & 7) ^ ((j & 1) << 2)) * 8u) * 2u;
       t.bh[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bh_rs, off, 0, 0));
       t.bl[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bl_rs, off, 0, 0));
@@ -449,7 +456,11 @@ __global__ __launch_bounds__(256) void gemm_nn_t16_kernel(const uint8_t* __restr
       const u32x2 ev = q ? e[2 * g + 1] : e[2 * g];
       const uint32_t e2 = (s < 2 ? ev[0] : ev[1]) >> (16 * (s & 1));  // bytes 2 s, 2 s + 1 of the 8
       u32x4 vh, vl;
+#if SE3_T16_ABLATE & 1
+      vh = mw, vl = mw ^ u32x4{e2, e2, e2, e2};
+#else
       t16_unpack8(mw, e2, vh, vl);
+#endif
       const int row = (2 * g + (q ? 1 : 0)) * RP + r8;
       *reinterpret_cast<u32x4*>(&ash[buf][row][c4]) = vh;
       *reinterpret_cast<u32x4*>(&asl[buf][row][c4]) = vl;
@@ -464,6 +475,9 @@ __global__ __launch_bounds__(256) void gemm_nn_t16_kernel(const uint8_t* __restr
 #pragma unroll
   for (int ct = 0; ct < 2 * NB; ++ct) acc[ct] = zero16();
   auto compute = [&](int buf) {
+#if SE3_T16_ABLATE & 4
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int kk = 16 * s + 8 * h;

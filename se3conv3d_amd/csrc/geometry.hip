@@ -587,7 +587,31 @@ __global__ void grid_params_kernel(float* __restrict__ mn, const float* __restri
   if (lo <= hi) atomicMax(&num_cells[i % 3], (int)__fdiv_rn(__fsub_rn(hi_s, lo_s), cell) + 1);
   mn[i] = lo_s;
 }
+// the same in one launch from boxes that are already known (one block: n_batches * 3 values)
+__global__ __launch_bounds__(256) void grid_params_from_box_kernel(const float* __restrict__ mn_raw, const float* __restrict__ mx_raw,
+                                                                   int n_batches, float cell, float max_shift,
+                                                                   float* __restrict__ mn_out, int32_t* __restrict__ num_cells) {
+  __shared__ int cells[3];
+  if (threadIdx.x < 3) cells[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_batches * 3; i += blockDim.x) {
+    const float lo = mn_raw[i], hi = mx_raw[i];
+    const float lo_s = __fsub_rn(lo, 1e-6f), hi_s = __fadd_rn(hi, max_shift);
+    if (lo <= hi) atomicMax(&cells[i % 3], (int)__fdiv_rn(__fsub_rn(hi_s, lo_s), cell) + 1);
+    mn_out[i] = lo_s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) num_cells[threadIdx.x] = cells[threadIdx.x];
+}
 }  // namespace
+
+extern "C" int se3_ball_query_grid_from_box(const float* box_min, const float* box_max, int32_t n_batches, float radius,
+                                            float* aabb_min, int32_t* num_cells, void* stream_) {
+  if (n_batches < 1 || !(radius > 0.f) || !box_min || !box_max || !aabb_min || !num_cells) return SE3_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(grid_params_from_box_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, box_min, box_max, n_batches,
+                     radius, -1e-6f, aabb_min, num_cells);
+  return check_launch();
+}
 
 extern "C" int se3_ball_query_grid(const float* pts_src, const int32_t* batch_src, int64_t n_src, int32_t n_batches,
                                    float radius, float* aabb_min, float* aabb_max_scratch, int32_t* num_cells,

@@ -131,13 +131,28 @@ def batch_aabb(pts, batch_ids, n_batches: Optional[int] = None) -> Tuple[torch.T
     return mn, mx
 
 
-def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float, n_batches: Optional[int] = None):
-    """Grid parameters exactly as BallQuery.forward builds them (BallQuery.py:34-38), on device, one library call."""
+def ball_query_needs_grid(n_src: int) -> bool:
+    """Whether a query against ``n_src`` source points uses the cell grid (small source sets are scanned whole)."""
+    return bool(_lib.load().se3_ball_query_needs_grid(int(n_src)))
+
+
+def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float, n_batches: Optional[int] = None, box=None):
+    """Grid parameters exactly as BallQuery.forward builds them (BallQuery.py:34-38), on device, one library call.
+    ``box`` = the source cloud's ``batch_aabb`` result when the caller has it (``Pointcloud.aabb()``: computed once per
+    cloud, a cloud is the source of several queries per step): one tiny launch instead of a pass over the points."""
     lib = _lib.load()
     if n_batches is None:
         # one tiny sync, the same one the reference pays with `torch::amax(...).item()` (ball_query.cu:46)
         n_batches = int(batch_src.max().item()) + 1 if batch_src.numel() else 1
     dev = pts_src.device
+    if box is not None and box[0].shape == (n_batches, 3) and box[0].device == dev:
+        mn = torch.empty((n_batches, 3), dtype=torch.float32, device=dev)
+        num_cells = torch.empty(3, dtype=torch.int32, device=dev)
+        _lib.check(lib.se3_ball_query_grid_from_box(_ptr(box[0], torch.float32, "box_min", dev), _ptr(box[1], torch.float32, "box_max", dev),
+                                                    n_batches, float(radius), _ptr(mn, torch.float32, "aabb_min"),
+                                                    _ptr(num_cells, torch.int32, "num_cells"), _stream(dev)),
+                   "se3_ball_query_grid_from_box")
+        return mn, num_cells
     box = torch.empty((2, n_batches, 3), dtype=torch.float32, device=dev)  # [0] = shifted minimum, [1] = scratch
     num_cells = torch.empty(3, dtype=torch.int32, device=dev)
     _lib.check(lib.se3_ball_query_grid(
@@ -148,7 +163,7 @@ def _batch_aabb_min_and_cells(pts_src, batch_src, radius: float, n_batches: Opti
 
 
 def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
-               n_batches: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+               n_batches: Optional[int] = None, src_box=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Radius neighbours: ``neighbors [E,2] int32`` (col0 sample, col1 source; grouped by sample)
     and ``ends [M] int32`` (inclusive end offsets).  Two-phase C ABI, one host sync for E."""
     lib = _lib.load()
@@ -166,7 +181,7 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
         return torch.zeros((0, 2), dtype=torch.int32, device=dev), torch.zeros(n_dst, dtype=torch.int32, device=dev)
     ends = torch.empty(n_dst, dtype=torch.int32, device=dev)  # every entry is written by the count phase
     # small source sets are searched all-pairs by the library: no boxes / cell grid to prepare
-    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
+    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches, src_box) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
     nbytes = lib.se3_ball_query_workspace_bytes(n_src, n_dst)
     ws = _workspace(nbytes, dev)
     f32, i32 = torch.float32, torch.int32
@@ -186,7 +201,7 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
 
 def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, capacity: int,
                        n_batches: Optional[int] = None, want_sources: bool = False,
-                       neighbors_out: Optional[torch.Tensor] = None):
+                       neighbors_out: Optional[torch.Tensor] = None, src_box=None):
     """The same query without the host round trip for the edge count (``se3_ball_query_bounded``): the caller sizes the
     edge buffer (``capacity`` rows, e.g. 1.25 x the previous step's count).  Returns ``(neighbors [capacity,2] int32,
     ends [M] int32, info [2] int32 on the device)`` with ``info[0]`` = true edge count and ``info[1]`` = 1 when it did
@@ -217,7 +232,7 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
         info = torch.zeros(2, dtype=i32, device=dev)
         return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)
     info = torch.empty(2, dtype=i32, device=dev)  # both words are written by the store pass
-    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
+    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches, src_box) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
     ws = _workspace(lib.se3_ball_query_workspace_bytes(n_src, n_dst), dev)
     _lib.check(lib.se3_ball_query_bounded(
         _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),

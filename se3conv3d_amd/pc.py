@@ -92,6 +92,16 @@ class Pointcloud(object):
             self._num_batches = int(self.batch_size_)
         return self._num_batches
 
+    def aabb(self):
+        """Per-batch bounding boxes ``(min, max) [B,3]`` of the points, computed once per cloud (the reference recomputes
+        them in every ball query, BallQuery.py:35-36; a cloud is the source of three or four queries per step)."""
+        box = getattr(self, "_se3_aabb", None)
+        if box is None or box[2] != self.pts_.data_ptr():
+            mn, mx = ops.batch_aabb(self.pts_, self.batch_ids_, self.num_batches())
+            box = (mn, mx, self.pts_.data_ptr())
+            self._se3_aabb = box
+        return box[0], box[1]
+
 
 class PointcloudRotEquiv(Pointcloud):
     """Point cloud with ``n_frames`` SO(3) reference frames per point."""
@@ -243,16 +253,19 @@ class BQNeighborhood(Neighborhood):
         # the edge list carries no gradient.  The kernels read the int32 list (``neighbors_i32_``); the int64
         # ``neighbors_`` the reference exposes is materialised on first access only (33 MB at the headline shape).
         self.sources_i32_ = None
+        # the source cloud's boxes: computed once per cloud (Pointcloud.aabb), not once per query
+        src_box = self.pc_src_.aabb() if hasattr(self.pc_src_, "aabb") and ops.ball_query_needs_grid(self.pc_src_.pts_.shape[0]) else None
         if self.capacity_ is not None:
             res = ops.ball_query_bounded(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
                                          self.samples_.batch_ids_, self.radius_, int(self.capacity_),
-                                         self.pc_src_.num_batches(), want_sources=self.symmetric_)
+                                         self.pc_src_.num_batches(), want_sources=self.symmetric_, src_box=src_box)
             nb, self.start_ids_, self.edge_info_ = res[:3]
             if self.symmetric_:
                 self.sources_i32_ = res[3]
         else:
             nb, self.start_ids_ = ops.ball_query(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
-                                                 self.samples_.batch_ids_, self.radius_, self.pc_src_.num_batches())
+                                                 self.samples_.batch_ids_, self.radius_, self.pc_src_.num_batches(),
+                                                 src_box=src_box)
         self.neighbors_i32_ = nb
         self._neighbors64 = None
 

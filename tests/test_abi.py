@@ -80,11 +80,11 @@ def test_intermediate_format_query(built_library):
     rb = lambda shp, which: lib.se3conv_intermediate_row_bytes(C.byref(shp), which)
     assert [rb(headline, w) for w in range(3)] == [64 * 32 * 3, 64 * 32 * 3, 64 * 32 * 4]
     t16 = _lib.Se3Shape(65536, 65536, 2_000_000, 2, 2, 64, 64, 32, _lib.PRECISIONS["bf16x3_t16"])
-    assert [rb(t16, w) for w in range(3)] == [64 * 72, 64 * 72, 64 * 72] and [q(t16, w) for w in range(3)] == [2, 2, 2]
+    assert [rb(t16, w) for w in range(3)] == [64 * 72, 64 * 72, 64 * 32 * 4] and [q(t16, w) for w in range(3)] == [2, 2, 4]   # grad_T: opt-in (SE3_T16_GT)
     wide16 = _lib.Se3Shape(4096, 4096, 60_000, 2, 2, 128, 256, 32, _lib.PRECISIONS["bf16x3_t16"])   # c_out = 256: grad_T by the tiled GEMM, packed words
     assert [rb(wide16, w) for w in range(3)] == [128 * 72, 256 * 72, 128 * 32 * 4]
-    wide16b = _lib.Se3Shape(4096, 4096, 60_000, 2, 2, 128, 64, 32, _lib.PRECISIONS["bf16x3_t16"])   # c_out = 64: the strip GEMM writes T16 rows
-    assert [rb(wide16b, w) for w in range(3)] == [128 * 72, 64 * 72, 128 * 72]
+    wide16b = _lib.Se3Shape(4096, 4096, 60_000, 2, 2, 128, 64, 32, _lib.PRECISIONS["bf16x3_t16"])
+    assert [rb(wide16b, w) for w in range(3)] == [128 * 72, 64 * 72, 128 * 32 * 4]
     narrow16 = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 32, 32, 32, _lib.PRECISIONS["bf16x3_t16"])   # not implemented there: as bf16x3
     assert [rb(narrow16, w) for w in range(3)] == [32 * 32 * 3, 32 * 32 * 3, 32 * 32 * 4]
     odd16 = _lib.Se3Shape(4096, 4096, 60_000, 1, 1, 64, 64, 32, _lib.PRECISIONS["bf16x3_t16"])      # F = 1 at 64 channels: single-wavefront kernel

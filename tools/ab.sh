@@ -12,7 +12,7 @@
 # layer; with --levels the graph-replay time of every level of the stack instead (tools/profile_levels.py).
 set -u
 out=gpurun_out/$1; shift
-reps=3; levels=0; bargs="--no-cpu-baseline --no-fp32 --steps 30"
+reps=3; levels=0; bargs="--no-cpu-baseline --no-extra --steps 30"
 while [ $# -gt 0 ]; do
   case "$1" in
     --reps) reps=$2; shift 2;;
