@@ -174,16 +174,11 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
 #endif
 // POW2: fnb_shift >= 0 is known (no division path, no branch on it).  TR: 0 forward, 1 transposed pass, -1 decided by
 // g.transposed at run time (both descriptor paths in the loop)
-// SE3_PAIR_DYNAMIC=1 (with SE3_PAIR_PERSIST=n; an A/B switch, one launch at a time per device): persistent workgroups CLAIM
-// their next item from a device counter instead of striding -- what static striding loses to imbalance (-5 %) against
-// what the prologue paid once per workgroup returns.  The last workgroup to finish re-arms the counter.
-__device__ int g_pair_claim[2];  // [0] next item, [1] workgroups done
 template <int CT, bool FULL, int NF, bool POW2 = false, int TR = -1>
 __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift,
-    int t24, int dynamic) {
-  __shared__ int lds_next_item;
+    int t24) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
   __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -202,7 +197,10 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
   int buf = 0;
   // Persistent workgroups (SE3_PAIR_PERSIST): the block walks items blockIdx.x, blockIdx.x + gridDim.x, ... so that
   // the kernel prologue (arguments, descriptors, MLP weights into LDS) is paid once per block, not once per item.
-  for (int64_t item = item_lo + blockIdx.x; item < n_items;) {  // items item_lo .. n_items-1
+  // (claiming the next item from a device counter instead of striding was measured in round 4: 65 536 returning atomics on
+  // one word take 0.74 ms by themselves, profiles/r04_vmem_diet_ab.txt; one item per workgroup lets the hardware dispatcher
+  // do the balancing)
+  for (int64_t item = item_lo + blockIdx.x; item < n_items; item += gridDim.x) {  // items item_lo .. n_items-1
   // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
   const int64_t ctr = (uint32_t)item / (uint32_t)groups;
   const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NF;
@@ -407,19 +405,6 @@ __global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) voi
       }
     if (cbase + 64 * CT < C) __syncthreads();  // the next pass reuses the phi buffers from their start
   }
-  if (!dynamic) {
-    item += gridDim.x;
-  } else {
-    __syncthreads();
-    if (threadIdx.x == 0) lds_next_item = atomicAdd(&g_pair_claim[0], 1);
-    __syncthreads();
-    item = item_lo + gridDim.x + lds_next_item;
-  }
-  }
-  if (dynamic && threadIdx.x == 0 && atomicAdd(&g_pair_claim[1], 1) == (int)gridDim.x - 1) {
-    g_pair_claim[0] = 0;
-    g_pair_claim[1] = 0;
-    __threadfence();
   }
 }
 
@@ -1015,21 +1000,16 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
       const char* e = getenv("SE3_PAIR_PERSIST");
       return e ? atoi(e) : 0;
     }();
-    static const int dynamic_env = [] {
-      const char* e = getenv("SE3_PAIR_DYNAMIC");
-      return e ? atoi(e) : 0;
-    }();
     const int per = two ? 2 : 1;
     const int64_t item_lo = row_lo >= 0 ? row_lo / per : 0;
     const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
     const int64_t n_range = item_hi - item_lo;
     if (n_range <= 0) return SE3_OK;
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
-    const int dynamic = dynamic_env != 0 && pblocks < n_range ? 1 : 0;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
 #define SE3_PAIR_T(CT, FULL, NF, P2, TR)                                                                                \
   hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
-                     axes_ext, rho, t_out, item_lo, item_hi, shift, rowfmt, dynamic)
+                     axes_ext, rho, t_out, item_lo, item_hi, shift, rowfmt)
 #define SE3_PAIR_L(CT, FULL, NF, P2)                 \
   do {                                               \
     if (!(P2)) SE3_PAIR_T(CT, FULL, NF, P2, -1);     \
