@@ -28,7 +28,7 @@
  *     a stream per request does not grow the table; (3) kernel-variant switches read ONCE from the environment at first
  *     use (A/B knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP, SE3_OVERLAP_ROWS,
  *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32),
- *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower), SE3_BQ_TWO_PASS.
+ *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower).
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - return value: SE3_OK (0) or a negative SE3_ERR_* code; no exceptions cross the boundary.
  *

@@ -227,180 +227,6 @@ __global__ __launch_bounds__(256) void scan_candidates_kernel(const float* __res
   if (!STORE && lane == 0) counts[s] = found;
 }
 
-// One-pass form of the capacity-bounded query (round 4): count, prefix and store in ONE launch instead of the count
-// kernel + two scan launches + the store kernel.  A workgroup owns 64 consecutive samples (16 per wavefront, in index
-// order: the offsets are a prefix over the sample index).  Phase 1 tests the candidates as above and keeps the 64-bit
-// hit masks of every group of 64 candidates in LDS (kOpGroups per sample; a sample with more candidates than that is
-// simply tested again in phase 3).  The workgroup's total then joins a decoupled look-back over the workgroups in front
-// of it: one 8-byte {state, value} word per workgroup, written by ONE agent-scope store and polled with agent-scope
-// loads (the granule hand-off of MI355X_MICROARCH.md -- nothing else crosses workgroups), 64 predecessors per poll.
-// Workgroups take their index from a ticket counter, so every predecessor of a running workgroup is running too: the
-// wait always ends (and is bounded anyway: a workgroup that gives up raises the overflow flag instead of hanging the GPU).
-// Phase 3 walks the masks again: a hit's slot = base of its sample + its rank, its source id is re-read from the sorted
-// records (no distance arithmetic the second time).  Same edge order as the two-kernel form (candidate order per sample).
-constexpr int kOpSamples = 64, kOpGroups = 6;
-constexpr uint64_t kOpAggregate = 1ull << 32, kOpPrefix = 2ull << 32;
-__global__ __launch_bounds__(256) void scan_candidates_onepass_kernel(const float* __restrict__ pts_dst, float inv_r,
-                                                                      const float4* __restrict__ spts,
-                                                                      const int2* __restrict__ ranges, int64_t n_dst,
-                                                                      unsigned long long* __restrict__ state,  // [blocks] + ticket
-                                                                      int32_t* __restrict__ ends, int32_t* __restrict__ neighbors,
-                                                                      int limit, int32_t* __restrict__ sources,
-                                                                      int32_t* __restrict__ info) {
-  __shared__ unsigned long long masks[kOpSamples][kOpGroups];
-  __shared__ int cnt[kOpSamples];
-  __shared__ int bid_s, base_s;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_blocks = (int)gridDim.x;
-  if (threadIdx.x == 0) bid_s = (int)atomicAdd(reinterpret_cast<unsigned int*>(state + n_blocks), 1u);
-  __syncthreads();
-  const int bid = bid_s;
-  const int64_t s0 = (int64_t)bid * kOpSamples;
-  // candidate `c` of the sample whose windows are (lo, pre): its position in the sorted records
-  auto position = [](const int (&lo)[9], const int (&pre)[10], int c) {
-    int o = 0;
-#pragma unroll
-    for (int t = 1; t < 9; ++t) o += (c >= pre[t]) ? 1 : 0;
-    int pos = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-      if (t == o) pos = lo[t] + (c - pre[t]);
-    return pos;
-  };
-  auto windows = [&](int64_t s, int (&lo)[9], int (&pre)[10]) {
-    pre[0] = 0;
-#pragma unroll
-    for (int o = 0; o < 9; ++o) {
-      const int2 r = ranges[s * 9 + o];
-      lo[o] = r.x;
-      pre[o + 1] = pre[o] + (r.y - r.x);
-    }
-  };
-  auto test = [&](const float4 p, float sx, float sy, float sz) {
-    // length((s - p) * invR) < 1, un-fused so that it is bit-identical to the CPU oracle
-    const float dx = __fmul_rn(__fsub_rn(sx, p.x), inv_r);
-    const float dy = __fmul_rn(__fsub_rn(sy, p.y), inv_r);
-    const float dz = __fmul_rn(__fsub_rn(sz, p.z), inv_r);
-    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-    return __fsqrt_rn(d2) < 1.0f;
-  };
-  // ---- phase 1: hit masks and counts
-  for (int i = 0; i < kOpSamples / 4; ++i) {
-    const int sl = wave * (kOpSamples / 4) + i;
-    const int64_t s = s0 + sl;
-    int found = 0;
-    if (s < n_dst) {
-      const float sx = pts_dst[s * 3], sy = pts_dst[s * 3 + 1], sz = pts_dst[s * 3 + 2];
-      int lo[9], pre[10];
-      windows(s, lo, pre);
-      const int total = pre[9];
-      for (int c0 = 0, g = 0; c0 < total; c0 += 64, ++g) {
-        const int c = c0 + lane;
-        bool hit = false;
-        if (c < total) hit = test(spts[position(lo, pre, c)], sx, sy, sz);
-        const unsigned long long mask = __ballot(hit);
-        if (g < kOpGroups && lane == 0) masks[sl][g] = mask;
-        found += __popcll(mask);
-      }
-    }
-    if (lane == 0) cnt[sl] = found;
-  }
-  __syncthreads();
-  // ---- phase 2: exclusive prefix inside the workgroup (wavefront 0), look-back over the workgroups in front
-  if (wave == 0) {
-    const int mine = cnt[lane];
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off);
-      if (lane >= off) incl += v;
-    }
-    const int total = __shfl(incl, 63);
-    if (bid > 0 && lane == 0)
-      __hip_atomic_store(state + bid, kOpAggregate | (unsigned int)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    long long prefix = 0;
-    bool failed = false;
-    if (bid > 0) {
-      int j = bid - 1;  // nearest predecessor of lane 0
-      for (int spins = 0;;) {
-        const int idx = j - lane;
-        unsigned long long w = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kOpPrefix;
-        const unsigned int st = (unsigned int)(w >> 32);
-        const unsigned long long ready = __ballot(st != 0), pref = __ballot(st == 2);
-        // usable run: lanes 0 .. first prefix lane (or all 64), provided every lane of the run has published something
-        const int first_p = pref ? __builtin_ctzll(pref) : 64;
-        const unsigned long long need = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull);
-        if ((ready & need) != need) {
-          if (++spins > (1 << 22)) { failed = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        int v = (need >> lane) & 1ull ? (int)(unsigned int)w : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        prefix += v;
-        if (pref) break;
-        j -= 64;
-      }
-    }
-    if (lane == 0) {
-      __hip_atomic_store(state + bid, kOpPrefix | (unsigned int)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      base_s = (int)prefix;
-      if (failed) info[1] = 1;  // never seen: the predecessors of a ticketed workgroup are running
-    }
-    // the samples' own offsets, clamped to the buffer like scan_candidates_kernel<2>
-    const int64_t s = s0 + lane;
-    const long long e = prefix + incl;
-    if (s < n_dst) {
-      ends[s] = (int)(e > limit ? limit : e);
-      if (s == n_dst - 1) info[0] = (int)e, info[1] = e > limit ? 1 : (failed ? 1 : 0);
-    }
-    cnt[lane] = incl - mine;  // exclusive offset inside the workgroup
-  }
-  __syncthreads();
-  // ---- phase 3: store
-  const int wg_base = base_s;
-  for (int i = 0; i < kOpSamples / 4; ++i) {
-    const int sl = wave * (kOpSamples / 4) + i;
-    const int64_t s = s0 + sl;
-    if (s >= n_dst) break;
-    const long long base = (long long)wg_base + cnt[sl];
-    if (base >= limit) continue;
-    int lo[9], pre[10];
-    windows(s, lo, pre);
-    const int total = pre[9];
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    if (total > 64 * kOpGroups) sx = pts_dst[s * 3], sy = pts_dst[s * 3 + 1], sz = pts_dst[s * 3 + 2];
-    int found = 0;
-    for (int c0 = 0, g = 0; c0 < total; c0 += 64, ++g) {
-      const int c = c0 + lane;
-      unsigned long long mask;
-      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < kOpGroups) {
-        mask = masks[sl][g];
-        if ((mask >> lane) & 1ull) p = spts[position(lo, pre, c)];
-      } else {  // beyond the masks that were kept: test again
-        bool hit = false;
-        if (c < total) {
-          p = spts[position(lo, pre, c)];
-          hit = test(p, sx, sy, sz);
-        }
-        mask = __ballot(hit);
-      }
-      if ((mask >> lane) & 1ull) {
-        const long long slot = base + found + __popcll(mask & ((1ull << lane) - 1ull));
-        if (slot < limit) {
-          const int id = __float_as_int(p.w);
-          neighbors[slot * 2] = (int32_t)s;
-          neighbors[slot * 2 + 1] = id;
-          if (sources) sources[slot] = id;
-        }
-      }
-      found += __popcll(mask);
-    }
-  }
-}
-
 // Small source sets (n_src <= kBqScanAllMax): one wavefront per sample tests every source, 64 at a time -- no boxes,
 // keys, sort or windows, i.e. 3 launches instead of 16 where the launches are all there is to the cost.  Same
 // predicate, same batch test; hits of a sample come out in ascending source id.
@@ -861,8 +687,7 @@ extern "C" size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst) {
 static int ball_query_count_impl(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
                                  const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
                                  float radius, int64_t n_src, int64_t n_dst, void* workspace,
-                                 size_t workspace_bytes, int32_t* ends, bool skip_scan, int key_bits, void* stream_,
-                                 bool ranges_only = false) {  // ranges_only: stop behind the window search (one-pass store follows)
+                                 size_t workspace_bytes, int32_t* ends, bool skip_scan, int key_bits, void* stream_) {
   if (n_src < 0 || n_dst < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_src >= (1ll << 31) || n_dst >= (1ll << 31) / 9) return SE3_ERR_UNSUPPORTED;
   if (n_dst == 0) return SE3_OK;
@@ -928,7 +753,6 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
     hipLaunchKernelGGL(find_ranges_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
                        aabb_min, num_cells, radius, skeys, (int)n_src, n_dst, ranges, order);
   }
-  if (ranges_only) return check_launch();
   hipLaunchKernelGGL(scan_candidates_kernel<0>, dim3((unsigned)((n_dst + 3) / 4)), dim3(256), 0, stream, pts_dst,
                      1.0f / radius, spts, ranges, n_dst, counts, (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr,
                      (int32_t*)nullptr, order);
@@ -1003,23 +827,8 @@ extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst
   // more: the 64-bit keys of the two-phase path
   int key_bits = 0;
   if (n_batches >= 1 && n_batches <= 2) key_bits = 30 + (n_batches > 1 ? 1 : 0);
-  // the grid path counts, scans and stores in one launch (scan_candidates_onepass_kernel); SE3_BQ_TWO_PASS=1: the count
-  // kernel + scan + store kernel of the two-phase entry points
-  static const bool two_pass = getenv("SE3_BQ_TWO_PASS") != nullptr;
-  if (n_src > kBqScanAllMax && !two_pass) {
-    if (int rc = ball_query_count_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
-                                       workspace, workspace_bytes, ends, false, key_bits, stream, true))
-      return rc;
-    const BqLayout l = bq_layout(n_src, n_dst);
-    char* ws = (char*)workspace;
-    const unsigned blocks = (unsigned)((n_dst + kOpSamples - 1) / kOpSamples);
-    unsigned long long* state = (unsigned long long*)(ws + l.counts);  // the count array's room: one word per workgroup + ticket
-    if (hipMemsetAsync(state, 0, ((size_t)blocks + 1) * 8, (hipStream_t)stream) != hipSuccess) return SE3_ERR_LAUNCH;
-    hipLaunchKernelGGL(scan_candidates_onepass_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pts_dst, 1.0f / radius,
-                       (const float4*)(ws + l.spts), (const int2*)(ws + l.ranges), n_dst, state, ends, neighbors, (int)capacity,
-                       sources, info);
-    return check_launch();
-  }
+  // (count + prefix + store as one launch with a decoupled look-back was measured in round 4: slower, removed --
+  // profiles/r04_ball_query_onepass_ab.txt)
   if (int rc = ball_query_count_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
                                      workspace, workspace_bytes, ends, inline_prefix, key_bits, stream))
     return rc;
