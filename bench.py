@@ -65,6 +65,12 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def mark(msg: str) -> None:
+    """Progress marks on stderr (SE3_BENCH_VERBOSE=1): which leg a run was in when it died."""
+    if os.environ.get("SE3_BENCH_VERBOSE"):
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def launch_ranks(args, argv) -> int:
     """Parent of an N-rank run: no GPU call has happened in this process (``import torch`` does not initialise
     HIP), the ranks are children of ``torch.distributed.run``.  Their stdout is relayed line by line."""
@@ -377,6 +383,7 @@ def run_rank(args):
                                  f"synchronised afterwards ({str(exc2)[:120]})")
             run_stack = lambda: step(levels)
             launch = f"eager on rank {rank} (graph capture failed: {str(exc)[:120]})"
+    mark("stack")
     dt_stack = timed(run_stack, args.steps, args.warmup)
     ms_step = dt_stack / args.steps * 1e3
     mpts = lambda ms: round(n0 * world / (ms * 1e-3) / 1e6, 3)
@@ -399,6 +406,7 @@ def run_rank(args):
 
     if world == 1:
         lv0 = levels[0]
+        mark("single layer / eager / stages")
         result["timing"]["hip_events"] = timed_events(run_stack, max(args.steps, 50))
         run_layer = (lambda: step(levels[:1])) if args.no_graph else GraphedStep(levels[:1])
         ms_layer = timed(run_layer, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
@@ -458,6 +466,7 @@ def run_rank(args):
         # (3 x 4*E*F*C) are NOT HBM traffic: the gathered table (33 MB at the headline shape) sits in the memory-side cache.
         # So the bound that matters is `hbm_bytes` (intermediates + every other tensor once) at the rate this chip streams;
         # `least_bytes_with_intermediates` (gathers priced as if they were HBM reads) is kept beside it for continuity.
+        mark("streaming rates")
         rate, fill_rate = streaming_rates_gbps()
         hbm_layer = sum(W.stage_hbm_bytes(lv0["n"], lv0["e"], frames, lv0["c"], per_el).values())
         gather_layer = sum(W.stage_gather_bytes(lv0["n"], lv0["e"], frames, lv0["c"]).values())
@@ -497,6 +506,7 @@ def run_rank(args):
         result["eager"] = {"ms_per_step": round(ms_eager, 4), "value": mpts(ms_eager),
                            "note": "same step launched from Python every iteration (no graph replay)"}
 
+        mark("forward_only")
         # inference: the forward pass of the same stack alone (eval mode, no autograd graph, T in the workspace)
         def forward_only(lvls):
             with torch.no_grad():
@@ -527,6 +537,7 @@ def run_rank(args):
         # Ball queries go into capacity-bounded edge buffers (1.25 x the known edge count; the edge count stays on the
         # device), so the whole thing -- 4 ball queries + 4 x (forward + backward) -- has no host synchronisation and
         # replays as ONE captured graph; the overflow flags are read once after the timed region.
+        mark("end_to_end")
         caps = [int(lv["e"] * 1.25) + 64 for lv in levels]
         flags = []
         extra = not args.no_extra
@@ -587,8 +598,16 @@ def run_rank(args):
         # its transposed copy prebuilt, like the headline), and `with_neighbourhood` -- the ball query (capacity-bounded, no
         # host sync) and se3_csr_transpose inside the step, as the task scripts pay them (they rebuild the hierarchy every
         # step, tasks/SemSeg/train_dfaust_rot.py:108-158).  Not part of `value`.
+        mark("down_up")
         def down_up_leg(wname):
             wspec = W.WORKLOADS[wname]
+            # Next to a live RCCL communicator (the one-rank rehearsal SE3_BENCH_FORCE_DIST=1; real N-rank runs never get
+            # here) the CAPTURED backward of the level 1 -> 0 convolution faulted on replay in round 4 (3 of 3 runs, a page
+            # outside every tensor of the step); the same step launched eagerly, and captured without a communicator, is clean
+            # under a non-caching allocator, serialized kernels and a poisoned edge-buffer tail.  Cause
+            # not found: with a process group this leg launches eagerly.
+            eager_leg = args.no_graph or dist is not None
+            mark(f"down_up {wname}: build")
             recs = W.build_down_up(wspec, device, seed=my_scenes[0], order=args.point_order)
             leg = {}
             reps_t = max(10, args.steps // 2)
@@ -602,16 +621,19 @@ def run_rank(args):
                     step_two_clouds(rec, nb)
 
                 conv_only = lambda _lv=None, rec=rec: step_two_clouds(rec)
-                run_c = conv_only if args.no_graph else GraphedStep(None, fn=conv_only)
+                mark(f"down_up {wname} {rec['name']}: conv_only")
+                run_c = conv_only if eager_leg else GraphedStep(None, fn=conv_only)
                 ms_c = timed(run_c, reps_t, 3) / reps_t * 1e3
-                run_n = with_nbh if args.no_graph else GraphedStep(None, fn=with_nbh)
+                mark(f"down_up {wname} {rec['name']}: with_neighbourhood")
+                run_n = with_nbh if eager_leg else GraphedStep(None, fn=with_nbh)
                 ms_n = timed(run_n, reps_t, 3) / reps_t * 1e3
                 assert int(held[0].edge_info_[1]) == 0 and int(held[0].edge_info_[0]) == rec["e"], "bounded two-cloud ball query"
+                mark(f"down_up {wname} {rec['name']}: stage times")
                 stages = profile_level(lib, None, 5, fn=lambda rec=rec: step_two_clouds(rec))
                 ab = W.layer_bytes_two_clouds(rec["n_in"], rec["n_out"], rec["e"], rec["f"], rec["f"], rec["c_in"], rec["c_out"])
                 leg[rec["name"]] = {
                     "n_in": rec["n_in"], "n_out": rec["n_out"], "edges": rec["e"], "c_in": rec["c_in"], "c_out": rec["c_out"],
-                    "frames": rec["f"], "radius": round(rec["r"], 5),
+                    "frames": rec["f"], "radius": round(rec["r"], 5), "launch": "eager" if eager_leg else "hipGraph replay",
                     "conv_only_ms": round(ms_c, 4), "with_neighbourhood_ms": round(ms_n, 4),
                     "neighbourhood_and_transpose_ms": round(ms_n - ms_c, 4),
                     "algorithmic_bytes": ab, "layer_frac": round(ab / (ms_c * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
@@ -629,6 +651,7 @@ def run_rank(args):
             result["down_up"] = {"error": str(exc)[:200]}
             torch.cuda.synchronize()
 
+        mark("fp32 leg")
         if not args.no_fp32 and not args.no_extra and args.precision != "fp32":
             amd.set_precision("fp32")
             run32 = (lambda: step(levels)) if args.no_graph else GraphedStep(levels)
@@ -641,6 +664,7 @@ def run_rank(args):
         # like the headline (same stack, graph replay) with its error measured at FULL size: every output and gradient of
         # the level-0 layer against the exact-fp32 mode's (itself within 1.5e-6 of the fp64 oracle), next to the default
         # mode's own distance -- the measured cost in accuracy of the bytes it saves.  Opt-in: not part of `value`.
+        mark("t16 leg")
         if args.precision == "bf16x3" and not args.no_t16 and not args.no_extra:
             def layer_results(prec):
                 amd.set_precision(prec)
@@ -683,6 +707,7 @@ def run_rank(args):
             finally:
                 amd.set_precision(args.precision)
 
+    mark("result gather")
     # the "trivial result gather": one checksum of the level-0 output per scene.  A fixed-size record per rank, so it
     # travels as one tensor all-gather (RCCL over xGMI; gloo in the rehearsal) rather than through pickled objects.
     with torch.no_grad():
