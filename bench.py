@@ -601,12 +601,10 @@ def run_rank(args):
         mark("down_up")
         def down_up_leg(wname):
             wspec = W.WORKLOADS[wname]
-            # Next to a live RCCL communicator (the one-rank rehearsal SE3_BENCH_FORCE_DIST=1; real N-rank runs never get
-            # here) the CAPTURED backward of the level 1 -> 0 convolution faulted on replay in round 4 (3 of 3 runs, a page
-            # outside every tensor of the step); the same step launched eagerly, and captured without a communicator, is clean
-            # under a non-caching allocator, serialized kernels and a poisoned edge-buffer tail.  Cause
-            # not found: with a process group this leg launches eagerly.
-            eager_leg = args.no_graph or dist is not None
+            # (Round 4: next to a live RCCL communicator the captured level 1 -> 0 step faulted on replay -- the memset nodes of
+            # rocPRIM's one-sweep radix sort inside the transposition, on the HIP runtime PyTorch ships; the library issues no
+            # hipMemsetAsync any more and the leg is captured whether or not a process group exists)
+            eager_leg = args.no_graph
             mark(f"down_up {wname}: build")
             recs = W.build_down_up(wspec, device, seed=my_scenes[0], order=args.point_order)
             leg = {}

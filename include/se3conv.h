@@ -28,8 +28,15 @@
  *     a stream per request does not grow the table; (3) kernel-variant switches read ONCE from the environment at first
  *     use (A/B knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP, SE3_OVERLAP_ROWS,
  *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32),
- *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower).
+ *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower),
+ *     SE3_TR_MERGE_SORT (se3_csr_transpose*: the merge-sort form for every graph, same result).
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
+ *   - graph capture: every entry point that takes a stream can be captured into a HIP graph (no host synchronisation,
+ *     nothing allocated) except the two-phase se3_ball_query_count / _store pair.  The library issues NO hipMemsetAsync
+ *     (buffers are zeroed by kernels) and its sorts stay on rocPRIM's merge sort at every size: on the HIP runtime
+ *     PyTorch 2.10 ships (7.0.51831, RCCL 2.26.6) a captured graph with memset nodes -- rocPRIM's one-sweep radix sort
+ *     issues three per pass -- faults on replay once an RCCL collective has run between two replays (round 4,
+ *     tools/debug_up_graph.py).
  *   - return value: SE3_OK (0) or a negative SE3_ERR_* code; no exceptions cross the boundary.
  *
  * Layouts: points [N,3]; frames [N,F,9] = row-major 3x3 per (point,frame)

@@ -646,7 +646,7 @@ extern "C" int se3_feat_basis_proj_grad(const float* basis, const float* feat, c
   hipStream_t stream = (hipStream_t)stream_;
   if (n_feat > 0) {
     if (!g_feat) return SE3_ERR_INVALID_ARGUMENT;
-    if (hipMemsetAsync(g_feat, 0, (size_t)n_feat * channels * 4, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+    if (int rc = launch_fill_words(g_feat, 0u, n_feat * channels, stream)) return rc;
   }
   if (n_edges == 0) return SE3_OK;
   if (!basis || !feat || !neighbors || !ends || !grad_out || !g_basis) return SE3_ERR_INVALID_ARGUMENT;

@@ -298,6 +298,11 @@ inline int check_launch() {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Fill `n_words` 32-bit words with `value` by a kernel (prep.hip).  Used wherever hipMemsetAsync would do: a memset NODE of
+// a captured graph faults on replay once an RCCL collective has run between two replays on the HIP runtime PyTorch 2.10
+// ships (7.0.51831) -- round 4, tools/debug_up_graph.py; kernel nodes and device-to-device copy nodes are fine.
+int launch_fill_words(void* dst, uint32_t value, int64_t n_words, hipStream_t stream);
+
 // Optional per-kernel timing (se3_profile_* in se3conv.h): when enabled every launcher brackets its
 // kernel with hipEvents on the launch stream.  Off by default; the only process-wide state.
 void prof_begin(const char* tag, hipStream_t stream);

@@ -158,6 +158,11 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
 #ifndef SE3_PAIR_WAVES
 #define SE3_PAIR_WAVES 4
 #endif
+#ifndef SE3_PAIR2_WAVES
+#define SE3_PAIR2_WAVES 2  // wavefronts per SIMD of the two-tile form (rows of 128 channels and up).  At 3 (168 VGPRs) it spilled
+                           // 48 - 64 bytes per lane to scratch and was 1 % slower (dfaust_f2 stack 2.02 vs 2.00 ms, a 128-channel
+                           // layer 4.67 vs 4.63 ms, profiles/r04_pair2_waves_ab.txt); no kernel the shipped configurations launch uses scratch now
+#endif
 #ifndef SE3_PG_ABLATE
 #define SE3_PG_ABLATE 0  // diagnostic builds of edge_param_grad_bf16_v2 (wrong results): 1 no GELU', 2 no feature gather, 4 no grad_T loads, 8 no d[A;beta] product,
                          // 16 no geometry gathers / descriptor / descriptor split (upper bound of what a descriptor stash written by the forward could save)
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
 // POW2: fnb_shift >= 0 is known (no division path, no branch on it).  TR: 0 forward, 1 transposed pass, -1 decided by
 // g.transposed at run time (both descriptor paths in the loop)
 template <int CT, bool FULL, int NF, bool POW2 = false, int TR = -1>
-__global__ __launch_bounds__(128, CT == 1 ? SE3_PAIR_WAVES : (FULL ? 3 : 2)) void edge_t_pair_bf16_kernel(
+__global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL ? SE3_PAIR2_WAVES : 2)) void edge_t_pair_bf16_kernel(
     EdgeGeom g, const uint32_t* __restrict__ feat, int C, int64_t feat_rows, const float* __restrict__ axes_ext,
     const float* __restrict__ rho_p, uint32_t* __restrict__ t_out, int64_t item_lo, int64_t n_items, int fnb_shift,
     int t24) {

@@ -340,7 +340,7 @@ extern "C" int se3_knn_query_pair(const float* src_pts, const int32_t* src_batch
   if (k > 64 || n_src >= (1ll << 31) || n_q >= (1ll << 31)) return SE3_ERR_UNSUPPORTED;
   if (n_q == 0) return SE3_OK;
   if (!q_pts || !q_batch || !out) return SE3_ERR_INVALID_ARGUMENT;
-  if (n_src == 0) return hipMemsetAsync(out, 0xff, (size_t)n_q * k * 4, (hipStream_t)stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  if (n_src == 0) return se3::launch_fill_words(out, 0xffffffffu, n_q * k, (hipStream_t)stream);
   if (!src_pts || !src_batch) return SE3_ERR_INVALID_ARGUMENT;
   return launch_knn_bruteforce(src_pts, src_batch, n_src, q_pts, q_batch, n_q, (int)k, out, (hipStream_t)stream);
 }

@@ -1321,7 +1321,7 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
   for (int64_t z0 = 0; z0 < splits; z0 += zs) {
     const int64_t zn = splits - z0 < zs ? splits - z0 : zs, r0 = z0 * chunk;
     if (r0 >= m) {  // ranges past the last row (rounding of chunk): their partials are zeros
-      if (hipMemsetAsync(partials + z0 * ka * n, 0, (size_t)(splits - z0) * ka * n * 4, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+      if (int rc = launch_fill_words(partials + z0 * ka * n, 0u, (int64_t)(splits - z0) * ka * n, stream)) return rc;
       break;
     }
     const int64_t mb = m - r0 < zn * chunk ? m - r0 : zn * chunk;

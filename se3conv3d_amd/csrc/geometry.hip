@@ -484,6 +484,37 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4* __restrict_
   }
 }
 
+
+// hipcub::DeviceRadixSort::SortPairs for the capturable paths.  Up to rocPRIM's own limit of 1 M items that call is a merge
+// sort (kernels and device-to-device copies only); above it, it is the one-sweep radix sort, which issues hipMemsetAsync
+// per pass and whose kernels use scratch memory -- and a captured graph with memset nodes faults on replay next to a live
+// RCCL communicator on the HIP runtime PyTorch 2.10 ships (see the note above se3_csr_transpose_bounded).  Larger inputs
+// therefore take the stable merge sort explicitly (keys here are non-negative with zero bits above end_bit, so both
+// orders agree).
+constexpr int kRadixIsMergeLimit = 1 << 20;
+struct KeyLess {
+  template <class K>
+  __device__ __forceinline__ bool operator()(const K& a, const K& b) const { return a < b; }
+};
+template <class Key>
+hipError_t sort_pairs_no_scratch(void* temp, size_t& temp_bytes, const Key* kin, Key* kout, const int32_t* vin, int32_t* vout,
+                                 int n, int begin_bit = 0, int end_bit = (int)sizeof(Key) * 8, hipStream_t stream = nullptr) {
+  if (temp == nullptr) {  // size query: the larger of the two forms
+    size_t a = 0, b = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, kin, kout, vin, vout, n, begin_bit, end_bit, stream);
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceMergeSort::StableSortPairs(nullptr, b, kout, vout, n, KeyLess(), stream);
+    temp_bytes = a > b ? a : b;
+    return e;
+  }
+  if (n <= kRadixIsMergeLimit) return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, stream);
+  hipError_t e = hipMemcpyAsync(kout, kin, (size_t)n * sizeof(Key), hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(vout, vin, (size_t)n * 4, hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) return e;
+  return hipcub::DeviceMergeSort::StableSortPairs(temp, temp_bytes, kout, vout, n, KeyLess(), stream);
+}
+
 struct KnnLayout {
   size_t keys, skeys, ids, sids, spts, list, count, temp, temp_bytes, total;
 };
@@ -501,7 +532,7 @@ KnnLayout knn_layout(int64_t n) {
   l.list = take(ns * 4);
   l.count = take(4);
   size_t t_sort = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (const int64_t*)nullptr, (int64_t*)nullptr,
+  (void)sort_pairs_no_scratch(nullptr, t_sort, (const int64_t*)nullptr, (int64_t*)nullptr,
                                            (const int32_t*)nullptr, (int32_t*)nullptr, (int)ns);
   l.temp_bytes = t_sort;
   l.temp = take(l.temp_bytes);
@@ -526,11 +557,11 @@ BqLayout bq_layout(int64_t n_src, int64_t n_dst) {
   l.ranges = take(nd * 9 * 8);
   l.counts = take(nd * 4);
   size_t t_sort = 0, t_scan = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (const int64_t*)nullptr, (int64_t*)nullptr,
+  (void)sort_pairs_no_scratch(nullptr, t_sort, (const int64_t*)nullptr, (int64_t*)nullptr,
                                      (const int32_t*)nullptr, (int32_t*)nullptr, (int)ns);
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, t_scan, (const int32_t*)nullptr, (int32_t*)nullptr, (int)nd);
   size_t t_sort32 = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+  (void)sort_pairs_no_scratch(nullptr, t_sort32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                            (const int32_t*)nullptr, (int32_t*)nullptr, (int)ns);
   if (t_sort32 > t_sort) t_sort = t_sort32;
   l.temp_bytes = t_sort > t_scan ? t_sort : t_scan;
@@ -650,12 +681,12 @@ extern "C" int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, co
   int32_t* list = (int32_t*)(ws + l.list);
   int32_t* list_count = (int32_t*)(ws + l.count);
   size_t temp_bytes = l.temp_bytes;
-  if (hipMemsetAsync(list_count, 0, 4, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+  if (int rc = se3::launch_fill_words(list_count, 0u, 1, stream)) return rc;
   {
     ProfScope prof("knn_sort", stream);
     hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, pts, batch_ids, aabb_min, num_cells,
                        cell_size, 0.f, n, keys, ids);
-    if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n, 0, 64, stream) !=
+    if (sort_pairs_no_scratch(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n, 0, 64, stream) !=
         hipSuccess)
       return SE3_ERR_LAUNCH;
     hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, pts, sids, n, spts);
@@ -731,7 +762,7 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
     if (n_src > 0) {
       hipLaunchKernelGGL(compute_keys32_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src,
                          aabb_min, num_cells, radius, n_src, keys32, ids);
-      if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys32, skeys32, ids, sids, (int)n_src, 0, key_bits,
+      if (sort_pairs_no_scratch(ws + l.temp, temp_bytes, keys32, skeys32, ids, sids, (int)n_src, 0, key_bits,
                                              stream) != hipSuccess)
         return SE3_ERR_LAUNCH;
       hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, sids,
@@ -744,7 +775,7 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
       // cell size = radius in every dimension (BallQuery.py:39-40)
       hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src, aabb_min,
                          num_cells, (const float*)nullptr, radius, n_src, keys, ids);
-      if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n_src, 0, 64,
+      if (sort_pairs_no_scratch(ws + l.temp, temp_bytes, keys, skeys, ids, sids, (int)n_src, 0, 64,
                                              stream) != hipSuccess)
         return SE3_ERR_LAUNCH;
       hipLaunchKernelGGL(gather_sorted_points_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, sids, n_src,
@@ -820,7 +851,7 @@ extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst
                                       size_t workspace_bytes, int64_t capacity, int32_t* neighbors, int32_t* sources,
                                       int32_t* ends, int32_t* info, void* stream) {
   if (capacity < 0 || capacity >= (1ll << 31) || !info) return SE3_ERR_INVALID_ARGUMENT;
-  if (n_dst == 0) return hipMemsetAsync(info, 0, 2 * sizeof(int32_t), (hipStream_t)stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  if (n_dst == 0) return se3::launch_fill_words(info, 0u, 2, (hipStream_t)stream);
   if (capacity > 0 && !neighbors) return SE3_ERR_INVALID_ARGUMENT;
   const bool inline_prefix = n_src <= kBqScanAllMax && n_dst <= kBqInlinePrefixMax;
   // one or two batch elements: 30 + 1 key bits (key32_of; the window's upper bound base + 3 then cannot wrap);
@@ -838,24 +869,151 @@ extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst
                                pts_src == pts_dst && n_src == n_dst && batch_src == batch_dst, stream);
 }
 
+// ---- source-major copy of an edge list (se3_csr_transpose*) -----------------------------------------------------------
+// Nothing here may become a MEMSET NODE of a captured graph: on the HIP runtime PyTorch 2.10 ships (7.0.51831, RCCL 2.26.6)
+// a graph with hipMemsetAsync nodes faults on replay once an RCCL collective has run between two replays.  Found in round 4
+// with rocPRIM's one-sweep radix sort (hipcub::DeviceRadixSort above 1 M items: three hipMemsetAsync per pass), which this
+// transposition used until then -- the captured level 1 -> 0 convolution next to a live communicator faulted in 7 of 7
+// runs, at the first replay behind the first barrier; the same graph with a merge sort (no memset) was clean, a counting
+// form with two hipMemsetAsync faulted again, the same form zeroing its arrays by a kernel is clean
+// (tools/debug_up_graph.py, tools/r04_fault_bisect.sh).  The one-sweep kernels also use scratch
+// memory (80 bytes per lane), the only kernels of this file that do; sorts stay on scratch-free forms too.
+// The list arrives grouped by sample in ascending sample order and a sample lists a source at most once, so "stable sort
+// by source" = per source the ascending list of its samples: count per source (atomics), inclusive scan, scatter into
+// the source's segment in arrival order (atomic cursor), then every segment is put in ascending order by ranking its
+// entries against each other -- the result does not depend on the order the atomics were served in.
+// Cost (rocprofv3, 2 M edges): short segments (a down-convolution, ~4 per source) 70 us in all; few sources with long
+// segments (an up-convolution, 9 k sources x 220) 260 us -- scattered atomics onto a few hundred cache lines and the
+// ranking of long segments -- against 90 us for the radix sort it replaces.  A variant with per-wavefront counters in
+// LDS and atomic-free, stable slot hand-out was built and measured no faster (285 us: an [slices x sources] count matrix
+// larger than the list itself).  For ball-query neighbourhoods the host side therefore builds that case's source-major
+// list as a second ball query with the clouds' roles swapped (pc.BQNeighborhood.source_major: the predicate is symmetric
+// bit for bit), which costs what the forward query costs.
 namespace {
 struct TrLayout {
-  size_t src, smp, ssrc, temp, temp_bytes, total;
+  size_t tmp, cursor, temp, temp_bytes, total;       // counting form (n_src <= 2 * rows)
+  size_t src, smp, merge_temp, merge_bytes;           // merge-sort form (sparser graphs): keys / values sorted in place
+};
+struct TrLess {
+  __device__ __forceinline__ bool operator()(const int32_t& a, const int32_t& b) const { return a < b; }
 };
 TrLayout tr_layout(int64_t e) {
   TrLayout l{};
+  const size_t ne = (size_t)(e > 0 ? e : 1);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = se3::align_up(off + bytes, 256); return o; };
-  const size_t ne = (size_t)(e > 0 ? e : 1);
+  l.tmp = take(ne * 4);
+  l.cursor = take(2 * ne * 4);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, l.temp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(2 * ne));
+  l.temp = take(l.temp_bytes);
+  const size_t counting_total = off;
+  off = 0;
   l.src = take(ne * 4);
   l.smp = take(ne * 4);
-  l.ssrc = take(ne * 4);
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, l.temp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                     (const int32_t*)nullptr, (int32_t*)nullptr, (int)ne);
-  l.temp = take(l.temp_bytes);
-  l.total = off;
+  (void)hipcub::DeviceMergeSort::StableSortPairs(nullptr, l.merge_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)ne, TrLess());
+  l.merge_temp = take(l.merge_bytes);
+  l.total = off > counting_total ? off : counting_total;
   return l;
 }
+
+__device__ __forceinline__ int64_t valid_rows(const int32_t* n_valid, int64_t e) {
+  return n_valid ? (int64_t)max(min((int64_t)*n_valid, e), (int64_t)0) : e;
+}
+
+// (a kernel, not hipMemsetAsync: see the note on memset nodes above se3_csr_transpose_bounded)
+__global__ void tr_zero_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    a[i] = 0;
+    if (b) b[i] = 0;
+  }
+}
+
+// counts[p] += 1 for every edge into source p (ids outside [0, n_src) are not edges of this graph: skipped everywhere)
+__global__ void tr_count_kernel(const int32_t* __restrict__ neighbors, int64_t e, const int32_t* __restrict__ n_valid,
+                                int32_t n_src, int32_t* __restrict__ counts) {
+  const int64_t valid = valid_rows(n_valid, e);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < valid; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t p = neighbors[i * 2 + 1];
+    if ((uint32_t)p < (uint32_t)n_src) atomicAdd(&counts[p], 1);
+  }
+}
+
+// edge i goes to the next free slot of its source's segment; rows past the list (the unset tail of a bounded buffer) are zeroed
+__global__ void tr_scatter_kernel(const int32_t* __restrict__ neighbors, int64_t e, const int32_t* __restrict__ n_valid,
+                                  int32_t n_src, const int32_t* __restrict__ ends, int32_t* __restrict__ cursor,
+                                  int32_t* __restrict__ tmp, int32_t* __restrict__ t_samples) {
+  const int64_t valid = valid_rows(n_valid, e);
+  const int64_t total = n_src > 0 ? ends[n_src - 1] : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i >= total) t_samples[i] = 0;  // nothing of the result is left unset
+    if (i >= valid) continue;
+    const int32_t p = neighbors[i * 2 + 1];
+    if ((uint32_t)p >= (uint32_t)n_src) continue;
+    const int32_t base = p > 0 ? ends[p - 1] : 0;
+    tmp[base + atomicAdd(&cursor[p], 1)] = neighbors[i * 2];
+  }
+}
+
+// One wavefront per source: its segment of `tmp` in ascending order -> t_samples.  rank = number of entries that sort in
+// front of mine (ties, which a well-formed list does not have, by position).  Segments of up to 64 entries live in
+// registers and are compared through shuffles; up to kTrSegLds entries are staged in a wave-private piece of LDS and every
+// lane ranks its entries against broadcast reads, four at a time; longer ones are read back from memory (L^2 / 64 steps).
+constexpr int kTrSegLds = 2048;
+__global__ __launch_bounds__(256) void tr_segment_sort_kernel(const int32_t* __restrict__ tmp, const int32_t* __restrict__ ends,
+                                                              int64_t n_src, int32_t* __restrict__ t_samples) {
+  __shared__ __attribute__((aligned(16))) int32_t seg[4][kTrSegLds];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + wave; p < n_src; p += (int64_t)gridDim.x * 4) {
+    const int start = p > 0 ? ends[p - 1] : 0;
+    const int len = ends[p] - start;
+    if (len <= 1) {
+      if (len == 1 && lane == 0) t_samples[start] = tmp[start];
+      continue;
+    }
+    if (len <= 64) {
+      const int v = lane < len ? tmp[start + lane] : 0x7fffffff;
+      int rank = 0;
+      for (int j = 0; j < len; ++j) {
+        const int vj = __shfl(v, j);
+        rank += (vj < v || (vj == v && j < lane)) ? 1 : 0;
+      }
+      if (lane < len) t_samples[start + rank] = v;
+      continue;
+    }
+    if (len <= kTrSegLds) {
+      const int len4 = (len + 3) & ~3;
+      for (int i = lane; i < len4; i += 64) seg[wave][i] = i < len ? tmp[start + i] : 0x7fffffff;  // the pad sorts behind everything
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int i = lane; i < len; i += 64) {
+        const int v = seg[wave][i];
+        int rank = 0;
+        for (int j = 0; j < len4; j += 4) {
+          const int4 q = *reinterpret_cast<const int4*>(&seg[wave][j]);
+          rank += (q.x < v || (q.x == v && j < i)) ? 1 : 0;
+          rank += (q.y < v || (q.y == v && j + 1 < i)) ? 1 : 0;
+          rank += (q.z < v || (q.z == v && j + 2 < i)) ? 1 : 0;
+          rank += (q.w < v || (q.w == v && j + 3 < i)) ? 1 : 0;
+        }
+        t_samples[start + rank] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the next source of this wavefront reuses the piece
+      continue;
+    }
+    for (int i = lane; i < len; i += 64) {
+      const int v = tmp[start + i];
+      int rank = 0;
+      for (int j = 0; j < len; ++j) {
+        const int vj = tmp[start + j];
+        rank += (vj < v || (vj == v && j < i)) ? 1 : 0;
+      }
+      t_samples[start + rank] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t se3_csr_transpose_workspace_bytes(int64_t n_edges) { return tr_layout(n_edges).total; }
@@ -865,27 +1023,42 @@ extern "C" int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_row
                                          void* stream_) {
   const int64_t n_edges = n_rows;
   if (n_edges < 0 || n_src < 0) return SE3_ERR_INVALID_ARGUMENT;
-  if (n_edges >= (1ll << 31) || n_src >= (1ll << 31) - 1) return SE3_ERR_UNSUPPORTED;
+  if (n_edges >= (1ll << 30) || n_src >= (1ll << 31) - 1) return SE3_ERR_UNSUPPORTED;
   if (n_src == 0) return SE3_OK;
   if (!t_ends || (n_edges > 0 && (!neighbors || !workspace || !t_samples))) return SE3_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
   const TrLayout l = tr_layout(n_edges);
   if (n_edges > 0 && workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   char* ws = (char*)workspace;
-  int32_t* ssrc = nullptr;
-  if (n_edges > 0) {
-    int32_t* src = (int32_t*)(ws + l.src);
-    int32_t* smp = (int32_t*)(ws + l.smp);
-    ssrc = (int32_t*)(ws + l.ssrc);
-    hipLaunchKernelGGL(split_edges_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, n_valid,
-                       (int32_t)n_src, src, smp);
-    size_t temp_bytes = l.temp_bytes;
-    // stable LSD radix sort: inside one source the samples keep their ascending input order
-    if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, src, ssrc, smp, t_samples, (int)n_edges, 0, 32,
-                                           stream) != hipSuccess)
-      return SE3_ERR_LAUNCH;
+  if (n_edges == 0) {
+    hipLaunchKernelGGL(tr_zero_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, t_ends, (int32_t*)nullptr, n_src);
+    return check_launch();
   }
-  hipLaunchKernelGGL(group_ends_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, ssrc, n_edges, n_src, t_ends);
+  static const bool force_merge = getenv("SE3_TR_MERGE_SORT") != nullptr;  // A/B and test switch: the fallback form everywhere
+  if (n_src <= 2 * n_edges && !force_merge) {
+    int32_t* tmp = (int32_t*)(ws + l.tmp);
+    int32_t* cursor = (int32_t*)(ws + l.cursor);
+    hipLaunchKernelGGL(tr_zero_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, t_ends, cursor, n_src);
+    hipLaunchKernelGGL(tr_count_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, n_valid,
+                       (int32_t)n_src, t_ends);
+    size_t temp_bytes = l.temp_bytes;  // sized for 2 * rows >= n_src items
+    if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, t_ends, t_ends, (int)n_src, stream) != hipSuccess)
+      return SE3_ERR_LAUNCH;
+    hipLaunchKernelGGL(tr_scatter_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, n_valid,
+                       (int32_t)n_src, t_ends, cursor, tmp, t_samples);
+    hipLaunchKernelGGL(tr_segment_sort_kernel, dim3(blocks_for(n_src, 4)), dim3(256), 0, stream, tmp, t_ends, n_src, t_samples);
+    return check_launch();
+  }
+  // more than two sources per row of the list: stable merge sort of (source, sample) pairs, in place (no scratch either)
+  int32_t* src = (int32_t*)(ws + l.src);
+  int32_t* smp = (int32_t*)(ws + l.smp);
+  hipLaunchKernelGGL(split_edges_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, n_valid,
+                     (int32_t)n_src, src, smp);
+  size_t merge_bytes = l.merge_bytes;
+  if (hipcub::DeviceMergeSort::StableSortPairs(ws + l.merge_temp, merge_bytes, src, smp, (int)n_edges, TrLess(), stream) != hipSuccess)
+    return SE3_ERR_LAUNCH;
+  if (hipMemcpyAsync(t_samples, smp, (size_t)n_edges * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+  hipLaunchKernelGGL(group_ends_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, src, n_edges, n_src, t_ends);
   return check_launch();
 }
 
@@ -1026,7 +1199,7 @@ GsLayout gs_layout(int64_t n, int n_batches) {
   l.box_min = take(nb * 12), l.box_max = take(nb * 12), l.num_cells = take(16);
   l.keys = take(nn * 8), l.skeys = take(nn * 8), l.ids = take(nn * 4), l.flags = take(nn * 4), l.ranks = take(nn * 4);
   size_t sort_bytes = 0, scan_bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr,
+  (void)sort_pairs_no_scratch(nullptr, sort_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr,
                                            (int32_t*)nullptr, (int)nn);
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)nn);
   l.temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
@@ -1047,7 +1220,7 @@ extern "C" int se3_grid_subsample(const float* pts, const int32_t* batch_ids, in
   if (n >= (1ll << 31) / 3) return SE3_ERR_UNSUPPORTED;
   if (!n_cells) return SE3_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
-  if (n == 0) return hipMemsetAsync(n_cells, 0, sizeof(int32_t), stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  if (n == 0) return se3::launch_fill_words(n_cells, 0u, 1, stream);
   if (!pts || !batch_ids || !workspace || !cell_ids || !sorted_ids || !cell_ends || !cell_pts || !cell_batch_ids)
     return SE3_ERR_INVALID_ARGUMENT;
   const GsLayout l = gs_layout(n, n_batches);
@@ -1067,7 +1240,7 @@ extern "C" int se3_grid_subsample(const float* pts, const int32_t* batch_ids, in
   hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, pts, batch_ids, box_min, num_cells,
                      (const float*)nullptr, cell_size, n, keys, ids);
   size_t temp_bytes = l.temp_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(ws + l.temp, temp_bytes, keys, skeys, ids, sorted_ids, (int)n, 0, 64, stream) !=
+  if (sort_pairs_no_scratch(ws + l.temp, temp_bytes, keys, skeys, ids, sorted_ids, (int)n, 0, 64, stream) !=
       hipSuccess)
     return SE3_ERR_LAUNCH;
   hipLaunchKernelGGL(cell_heads_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, skeys, n, flags);

@@ -466,7 +466,7 @@ extern "C" int se3_linear_wgrad(const float* grad_y, const float* x, int64_t row
     return SE3_ERR_INVALID_ARGUMENT;
   if (workspace_bytes < se3_linear_wgrad_workspace_bytes(rows, n_out, n_in)) return SE3_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  if (rows == 0) return hipMemsetAsync(grad_w, 0, (size_t)n_out * n_in * 4, stream) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;
+  if (rows == 0) return launch_fill_words(grad_w, 0u, (int64_t)n_out * n_in, stream);
   return launch_gemm_tn("linear_wgrad", grad_y, x, grad_w, (float*)workspace, gemm_tn_splits(rows, n_out, n_in), rows, n_out,
                         n_in, nullptr, 1.0f, stream);
 }

@@ -210,4 +210,19 @@ int PrepBatch::launch(hipStream_t stream) {
   return check_launch();
 }
 
+
+namespace {
+__global__ void fill_words_kernel(uint32_t* __restrict__ dst, uint32_t value, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = value;
+}
+}  // namespace
+
+int launch_fill_words(void* dst, uint32_t value, int64_t n_words, hipStream_t stream) {
+  if (n_words <= 0) return SE3_OK;
+  int64_t blocks = (n_words + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t*)dst, value, n_words);
+  return check_launch();
+}
+
 }  // namespace se3

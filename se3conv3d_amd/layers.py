@@ -120,6 +120,7 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     geom.bounded = geom.edge_info is not None
     if geom.symmetric:
         geom.sources = getattr(p_neighborhood, "sources_i32_", None)
+    geom.source_major_fn = getattr(p_neighborhood, "source_major", None)
     try:
         p_neighborhood._se3_geom = (key, geom)
     except AttributeError:
@@ -290,6 +291,7 @@ class PNEConvLayer(IConvLayer):
             geom.bounded = geom.edge_info is not None
             if geom.symmetric:
                 geom.sources = getattr(p_neighborhood, "sources_i32_", None)
+            geom.source_major_fn = getattr(p_neighborhood, "source_major", None)
             try:
                 p_neighborhood._se3_geom_plain = (key, geom)
             except AttributeError:

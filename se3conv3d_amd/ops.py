@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, field
-from typing import Optional, Tuple
+from typing import Callable, Optional, Tuple
 
 import torch
 
@@ -270,7 +270,7 @@ def csr_transpose(neighbors_i32: torch.Tensor, n_src: int, n_valid: Optional[tor
     dev = neighbors_i32.device
     e = neighbors_i32.shape[0]
     t_samples = torch.empty(e, dtype=torch.int32, device=dev)
-    t_ends = torch.zeros(n_src, dtype=torch.int32, device=dev)
+    t_ends = torch.empty(n_src, dtype=torch.int32, device=dev)  # every entry is written by the library
     ws = _workspace(lib.se3_csr_transpose_workspace_bytes(e), dev)
     _lib.check(lib.se3_csr_transpose_bounded(_ptr(neighbors_i32, torch.int32, "neighbors"), e,
                                              _ptr(n_valid, torch.int32, "n_valid", dev), n_src, C.c_void_p(ws.data_ptr()),
@@ -610,6 +610,8 @@ class ConvGeometry:
     bounded: bool = False  # `neighbors` is a capacity-sized buffer whose rows past ends[-1] are unset
     sources: Optional[torch.Tensor] = None  # column 1 of `neighbors` as a dense array when the ball query wrote one
     edge_info: Optional[torch.Tensor] = None  # [2] int32 on the device (bounded only): true edge count, overflow flag
+    # the neighbourhood's own way to the source-major list (pc.BQNeighborhood.source_major), or None
+    source_major_fn: Optional[Callable[[], Optional[Tuple[torch.Tensor, torch.Tensor]]]] = field(default=None, repr=False)
 
     @staticmethod
     def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends, symmetric: bool = False) -> "ConvGeometry":
@@ -632,6 +634,8 @@ class ConvGeometry:
             if self.symmetric:  # samples of source p = sources of sample p
                 src = self.sources if self.sources is not None else self.neighbors[:, 1].contiguous()
                 self._transpose = (src, self.ends)
+            elif self.source_major_fn is not None and (own := self.source_major_fn()) is not None:
+                self._transpose = own
             else:
                 if self.bounded and self.edge_info is None:
                     raise ValueError("a capacity-bounded edge buffer between two clouds needs its device-side edge count "

@@ -298,6 +298,29 @@ class BQNeighborhood(Neighborhood):
         if value is not None:
             self.neighbors_i32_ = None
 
+    def source_major(self):
+        """The source-major copy of the edge list the operator's backward reads -- ``(t_samples [rows], t_ends [N_src])`` -- or
+        ``None`` when the library's transposition of the list is the better way to get it.  Fewer sources than samples (an
+        up-convolution: every source has hundreds of edges) is the case se3_csr_transpose is slow for; the list is then a
+        SECOND ball query with the clouds' roles swapped: ``||(s - p) / r|| < 1`` is bit for bit the same predicate both
+        ways, so it finds exactly the same edges, grouped by source, in an order that depends on the points only
+        (deterministic; not ascending in the sample id, which no consumer needs).  Capacity-bounded like the forward list
+        (same row count), no host synchronisation: capturable."""
+        if self.symmetric_ or self.max_neighbors_ != 0 or getattr(self, "neighbors_i32_", None) is None:
+            return None
+        n_src, n_smp = self.pc_src_.pts_.shape[0], self.samples_.pts_.shape[0]
+        if n_src >= n_smp or n_src == 0:
+            return None
+        cached = getattr(self, "_source_major", None)
+        if cached is None:
+            rows = int(self.neighbors_i32_.shape[0])
+            box = self.samples_.aabb() if hasattr(self.samples_, "aabb") and ops.ball_query_needs_grid(n_smp) else None
+            _, t_ends, info, t_samples = ops.ball_query_bounded(
+                self.samples_.pts_, self.pc_src_.pts_, self.samples_.batch_ids_, self.pc_src_.batch_ids_, self.radius_, rows,
+                self.samples_.num_batches(), want_sources=True, src_box=box)
+            cached = self._source_major = (t_samples, t_ends, info)
+        return cached[0], cached[1]
+
     def num_edges(self) -> int:
         """Number of edges as a host integer (one device read-back for a capacity-bounded build)."""
         info = getattr(self, "edge_info_", None)

@@ -155,3 +155,20 @@ def test_no_product_import_of_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("CPU oracle", ""), f
+
+
+def test_library_issues_no_memset_calls():
+    """A memset NODE of a captured graph faults on replay next to a live RCCL communicator on the HIP runtime PyTorch 2.10
+    ships: the library zeroes buffers by kernels (launch_fill_words) and keeps its sorts off
+    rocPRIM's one-sweep radix sort, which issues hipMemsetAsync per pass."""
+    csrc = os.path.join(ROOT, "se3conv3d_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        code = "\n".join(line.split("//")[0] for line in open(os.path.join(csrc, name)).read().splitlines())
+        assert "hipMemsetAsync(" not in code and "hipMemset(" not in code, f"{name} calls hipMemset*"
+        if name != "geometry.hip":
+            assert "DeviceRadixSort" not in code, f"{name} sorts through hipcub::DeviceRadixSort directly"
+    geo = open(os.path.join(csrc, "geometry.hip")).read()
+    # the only direct use is inside sort_pairs_no_scratch (sizes up to rocPRIM's merge-sort limit)
+    assert geo.count("hipcub::DeviceRadixSort::SortPairs(") == 2, "radix sorts must go through sort_pairs_no_scratch"

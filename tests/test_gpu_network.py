@@ -181,3 +181,7 @@ def test_bench_rccl_path_with_one_rank():
     rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and list(rec["scene_checksums"]) == ["0"]
     assert rec["config"]["launch"].startswith("hipGraph"), rec["config"]["launch"]
+    # the level-to-level convolutions (bounded ball query + transposition + forward + backward as ONE captured graph) replay
+    # next to the communicator too: in round 4 they faulted there -- memset nodes of rocPRIM's one-sweep sort
+    legs = rec["down_up"]["headline"]
+    assert {legs["down"]["launch"], legs["up"]["launch"]} == {"hipGraph replay"}, legs
