@@ -29,7 +29,8 @@
  *     use (A/B knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP, SE3_OVERLAP_ROWS,
  *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32),
  *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower),
- *     SE3_TR_MERGE_SORT (se3_csr_transpose*: the merge-sort form for every graph, same result).
+ *     SE3_TR_MERGE_SORT (se3_csr_transpose*: the merge-sort form for every graph, same result), SE3_DX_PATH (feature
+ *     gradient edge-major: 1 wherever implemented, 0 never; default: where it moves less than half the bytes).
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - graph capture: every entry point that takes a stream can be captured into a HIP graph (no host synchronisation,
  *     nothing allocated) except the two-phase se3_ball_query_count / _store pair.  The library issues NO hipMemsetAsync
@@ -110,7 +111,8 @@ typedef struct se3conv_shape {
  * against (se3conv3d_amd/_lib.py does). */
 /* 3 = round 4: se3_side_stream_stats fills FIVE counters (was three); SE3_PRECISION_BF16X3_T16 and
  * se3conv_intermediate_row_bytes added. */
-#define SE3_ABI_VERSION 3
+/* 4 = round 4: se3_csr_transpose / _bounded and se3conv_bwd take `t_edge_ids` (optional). */
+#define SE3_ABI_VERSION 4
 int se3_abi_version(void);
 const char* se3_error_string(int code);
 /* Bytes per element of the row-sized intermediates [rows, C, K] the operator moves through memory for this shape --
@@ -255,8 +257,11 @@ int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int
  * t_samples[E] = sample id of every edge, grouped by source point (ascending sample inside a
  * group), t_ends[n_src] = inclusive end offsets. */
 size_t se3_csr_transpose_workspace_bytes(int64_t n_edges);
+/* `t_edge_ids` (optional, may be NULL; ABI 4): [E] the position of every entry in the sample-major list -- entry j of the
+ * result is row t_edge_ids[j] of `neighbors`.  se3conv_bwd's edge-major feature gradient (a convolution with many more
+ * input than output rows) gathers per-edge rows through it; without it that kernel looks every edge up itself. */
 int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, void* workspace,
-                      size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream);
+                      size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, int32_t* t_edge_ids, void* stream);
 /* The same for a capacity-sized buffer of se3_ball_query_bounded between two DIFFERENT clouds: `neighbors` has n_rows
  * rows of which only the first *n_valid (device word, e.g. info[0] of that call; clamped to n_rows) are edges -- the
  * unset tail is ignored (it sorts behind every group and no offset reaches it), t_samples [n_rows], t_ends [n_src].
@@ -264,7 +269,8 @@ int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, 
  * (info[1] != 0) the forward list is truncated and so is its transpose: outputs and gradients then belong to the
  * truncated graph, consistently -- rebuild with a larger buffer. */
 int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_rows, const int32_t* n_valid, int64_t n_src,
-                              void* workspace, size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream);
+                              void* workspace, size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, int32_t* t_edge_ids,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * rot tensors  <-  PNEConvLayerRotEquiv.get_rot_tenors
@@ -326,7 +332,8 @@ int se3_feat_basis_proj_grad(const float* basis, const float* feat, const int32_
  * backward: grad_out [N_out*F_out, C_out] -> any of grad_feat [N_in*F_in, C_in],
  *   grad_axes [9,K], grad_biases [K], grad_weights [C_in,K,C_out] (NULL = not wanted).  No
  *   gradient flows to points or frames (the reference builds geometry under no_grad, :67).
- *   `t_samples`/`t_ends` = se3_csr_transpose of `neighbors` (needed only for grad_feat);
+ *   `t_samples`/`t_ends` = se3_csr_transpose of `neighbors` (needed only for grad_feat); `t_edge_ids` = its optional
+ *   third result (may be NULL);
  *   `t_save` = the tensor written by the forward (needed for grad_weights; if NULL it is
  *   recomputed into the workspace).
  * ------------------------------------------------------------------------------------------- */
@@ -342,7 +349,7 @@ size_t se3conv_bwd_workspace_bytes(const se3conv_shape* shape, int want_feat, in
                                    int have_t_save);
 int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_in,
                 const float* frames_out, const int32_t* neighbors, const int32_t* ends,
-                const int32_t* t_samples, const int32_t* t_ends, const float* feat,
+                const int32_t* t_samples, const int32_t* t_ends, const int32_t* t_edge_ids, const float* feat,
                 const float* proj_axes, const float* proj_biases, const float* conv_weights,
                 const float* rho, const float* nu, const float* t_save, const float* grad_out,
                 const se3conv_shape* shape, float* grad_feat, float* grad_axes,

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", f"libse3conv_hip{os.environ.get('SE3_LIB_SUFFIX', '')}.so")  # suffix: variant builds, see build.py
 
 SE3_OK = 0
-ABI_VERSION = 3  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
+ABI_VERSION = 4  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x3_t16": 2}
 REL_ROT = {"6D": (0, 9), "matrix": (1, 12), "quaternion": (2, 7)}  # p_rel_rot -> (SE3_REL_ROT_*, descriptor dims)
 
@@ -59,8 +59,8 @@ SIGNATURES = {
     "se3_ball_query_store": (C.c_int, [_P, _P, _F, _I64, _I64, _P, _SZ, _P, _I64, _P, _P]),
     "se3_ball_query_bounded": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _I32, _P, _SZ, _I64, _P, _P, _P, _P, _P]),
     "se3_csr_transpose_workspace_bytes": (_SZ, [_I64]),
-    "se3_csr_transpose": (C.c_int, [_P, _I64, _I64, _P, _SZ, _P, _P, _P]),
-    "se3_csr_transpose_bounded": (C.c_int, [_P, _I64, _P, _I64, _P, _SZ, _P, _P, _P]),
+    "se3_csr_transpose": (C.c_int, [_P, _I64, _I64, _P, _SZ, _P, _P, _P, _P]),
+    "se3_csr_transpose_bounded": (C.c_int, [_P, _I64, _P, _I64, _P, _SZ, _P, _P, _P, _P]),
     "se3_rot_tensors": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SHP, _P, _P, _P, _P]),
     "se3_rot_tensors_rel": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SHP, _I32, _P, _P, _P, _P]),
     "se3_feat_basis_proj": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P]),
@@ -68,7 +68,7 @@ SIGNATURES = {
     "se3conv_fwd_workspace_bytes": (_SZ, [_SHP, C.c_int]),
     "se3conv_fwd": (C.c_int, [_P] * 12 + [_SHP, _P, _P, _P, _SZ, _P]),
     "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
-    "se3conv_bwd": (C.c_int, [_P] * 16 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
+    "se3conv_bwd": (C.c_int, [_P] * 17 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
     "se3_knn_query": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "se3_knn_query_pair": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I32, _P, _P]),
     "se3_grid_pick": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),

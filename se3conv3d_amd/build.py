@@ -22,7 +22,7 @@ SUFFIX = os.environ.get("SE3_LIB_SUFFIX", "")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj" + SUFFIX) if SUFFIX else LIBDIR
 LIB = os.path.join(LIBDIR, f"libse3conv_hip{SUFFIX}.so")
-SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "gemm.hip", "gemm_bf16.hip", "prep.hip", "frames.hip", "glue.hip", "api.hip"]
+SOURCES = ["geometry.hip", "edge_kernels.hip", "edge_bf16.hip", "edge_dx.hip", "gemm.hip", "gemm_bf16.hip", "prep.hip", "frames.hip", "glue.hip", "api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "edge_bf16_body.h"), os.path.join(os.path.dirname(PKG), "include", "se3conv.h")]
 ARCH = "gfx950"
 # -fno-slp-vectorize: the SLP pass packs adjacent fp32 ops into v_pk_fma_f32 / v_pk_mul_f32, which issue slower than the

@@ -259,11 +259,37 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
 
 struct BwdLayout {
   size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, split, geom_in, geom_out, total;
+  size_t dx_rows;  // edge-major feature gradient (use_edge_dx): D [edge rows * F_in, C_in] fp32
   size_t big_u, bt2_hi, bt2_lo, split2;  // feature-gradient branch when it runs beside the parameter branch
   int n_param_partials, tn_splits;
 };
+// The feature gradient of a convolution with many more input rows than edges per row can carry (a down-convolution)
+// goes edge-major (edge_dx.hip): D = phi gT^T per frame-edge, summed per source row -- instead of a U row per source
+// row and its GEMM.  Decided from the shape alone (bwd_layout and se3conv_bwd must agree): implemented shapes only, split-
+// bf16 arithmetic, and the bytes the two forms move through memory -- U written and read (3-byte rows) against D written
+// and gathered, plus grad_T when the parameter gradients do not need it anyway -- with a factor of two in favour of the
+// default.  SE3_DX_PATH=0 never, =1 whenever implemented (tests force both on the same shapes).
+bool use_edge_dx(const se3conv_shape* s, bool want_feat, bool want_params) {
+  static const int mode = [] {
+    const char* e = getenv("SE3_DX_PATH");
+    return e ? atoi(e) : -1;
+  }();
+  if (!want_feat || mode == 0 || s->precision == SE3_PRECISION_FP32 || s->num_basis != kBasis) return false;
+  if (s->n_in == 0 || s->n_out == 0) return false;
+  EdgeGeom g{};
+  g.f_ctr = s->f_out, g.f_nb = s->f_in;
+  if (!edge_dx_bf16_applicable(g, s->c_in)) return false;
+  if (s->n_edges * s->f_in * (int64_t)s->c_in >= (1ll << 31)) return false;
+  if (mode == 1) return true;
+  const double rows_in = (double)s->n_in * s->f_in, rows_out = (double)s->n_out * s->f_out;
+  const double u_bytes = rows_in * s->c_out * kBasis * 6.0;
+  const double d_bytes = (double)s->n_edges * s->f_in * s->c_in * 8.0 + (want_params ? 0.0 : rows_out * s->c_in * kBasis * 8.0);
+  return 2.0 * d_bytes < u_bytes;
+}
+
 BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
   BwdLayout l{};
+  const bool dx = use_edge_dx(s, want_feat != 0, want_params != 0);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t kb = s->num_basis;
@@ -286,7 +312,7 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     l.bt_lo = take(plane);
     l.featpk = want_params ? take(rows_in * s->c_in * 4) : 0;
     l.gpk = take(rows_out * s->c_out * 4);
-    size_t sp = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_out, s->c_in * (int)kb, s->c_out) : 0;
+    size_t sp = (want_params || dx) ? gemm_nn_bf16_split_bytes((int64_t)rows_out, s->c_in * (int)kb, s->c_out) : 0;
     const size_t sp3 = want_params ? gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_out * (int)kb, s->c_in) : 0;
     if (sp3 > sp) sp = sp3;
     const size_t sp2 = want_feat ? gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb) : 0;
@@ -296,7 +322,7 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   l.geom_in = take(rows_in * 64);
   l.geom_out = take(rows_out * 64);
   size_t big = 0;
-  if (want_params) big = rows_out * s->c_in * kb * 4;
+  if (want_params || dx) big = rows_out * s->c_in * kb * 4;
   if (want_feat && rows_in * s->c_out * kb * 4 > big) big = rows_in * s->c_out * kb * 4;
   l.big = take(big);
   if (fast && want_feat) {
@@ -308,6 +334,7 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     l.big_u = take(rows_in * s->c_out * kb * 4);
     l.split2 = take(gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb));
   }
+  l.dx_rows = dx ? take((size_t)s->n_edges * s->f_in * s->c_in * 4) : 0;
   l.t = (want_params && !have_t) ? take(rows_out * s->c_in * kb * 4) : 0;
   l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
   l.param_partials = want_params ? take((size_t)l.n_param_partials * edge_param_grad_bf16_channel_blocks(s->c_in) *
@@ -814,7 +841,8 @@ extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_f
 
 extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
                            const int32_t* neighbors, const int32_t* ends, const int32_t* t_samples,
-                           const int32_t* t_ends, const float* feat, const float* proj_axes, const float* proj_biases,
+                           const int32_t* t_ends, const int32_t* t_edge_ids, const float* feat, const float* proj_axes,
+                           const float* proj_biases,
                            const float* conv_weights, const float* rho, const float* nu, const float* t_save,
                            const float* grad_out, const se3conv_shape* s, float* grad_feat, float* grad_axes,
                            float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
@@ -841,7 +869,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       hipLaunchKernelGGL(slice_params_kernel, pgrid, dim3(256), 0, stream, proj_axes, proj_biases, conv_weights,
                          s->num_basis, k0, kn, s->c_in, s->c_out, a32, b32, w32);
       float* dx = !wf ? nullptr : (sl == 0 ? grad_feat : (float*)(ws + l.out_tmp));
-      if (int rc = se3conv_bwd(pts_in, pts_out, frames_in, frames_out, neighbors, ends, t_samples, t_ends, feat, a32, b32, w32, rho,
+      if (int rc = se3conv_bwd(pts_in, pts_out, frames_in, frames_out, neighbors, ends, t_samples, t_ends, t_edge_ids, feat, a32, b32, w32, rho,
                                nu, nullptr, grad_out, &s32, dx, da32, db32, dw32, ws + l.inner, l.total - l.inner, stream_))
         return rc;
       if (wf && sl > 0 && n_in_el > 0)
@@ -951,7 +979,8 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   const int t24_t = row_format(s, g, s->c_in, rows_out, s->c_out);  // as se3conv_fwd
   const int t24_u = feat_branch ? row_format(s, gt, s->c_out, rows_in, 0) : 0;
   const bool strip_t = gemm_strip_bf16_applicable(rows_out, ck, s->c_out);            // grad_T = g W^T
-  const bool gt16 = strip_t && grad_t_t16(s, g);                                      // ... written as T16 rows
+  const bool edge_dx = use_edge_dx(s, want_feat, want_params) && feat_branch;         // feature gradient edge-major (edge_dx.hip)
+  const bool gt16 = strip_t && !edge_dx && grad_t_t16(s, g);                          // ... written as T16 rows
   {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
     float* geom_in = (float*)(ws + l.geom_in);
     float* geom_out = (float*)(ws + l.geom_out);
@@ -962,12 +991,11 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (same_cloud) geom_out = geom_in;
     else pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     pb.split(grad_out, gpk, rows_out * s->c_out);
-    if (feat_branch) pb.weights(conv_weights, s->c_in, kb, s->c_out, 2, bx_hi, bx_lo, nullptr, 1.0f, false, t24_u);
-    if (want_params) {
-      pb.split(feat, featpk, rows_in * s->c_in);
+    if (feat_branch && !edge_dx) pb.weights(conv_weights, s->c_in, kb, s->c_out, 2, bx_hi, bx_lo, nullptr, 1.0f, false, t24_u);
+    if (want_params) pb.split(feat, featpk, rows_in * s->c_in);
+    if (want_params || edge_dx)
       // alpha = nu/F_in is folded into these weights (one multiply per weight instead of one per grad_T element)
       pb.weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, nu, inv_fin, strip_t, 0, gt16);
-    }
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
     gt.ctr_geom = geom_in, gt.nb_geom = geom_out;
@@ -999,6 +1027,26 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     return SE3_OK;
   };
 
+  if (edge_dx) {
+    // grad_T first (both branches read it), then the edge-major feature gradient and its per-source sums, then the
+    // parameter branch -- one stream: at these sizes (a sixth of a level's edges) nothing is worth a fork
+    if (strip_t) {
+      if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, rows_out, ck, s->c_out, stream, false)) return rc;
+    } else if (int rc = launch_gemm_nn_bf16("gemm_gradT", gpk, bt_hi, bt_lo, bigw, true, rows_out, ck, s->c_out,
+                                            (float*)(ws + l.split), nullptr, 1.0f, stream)) {
+      return rc;
+    }
+    float* d_rows = (float*)(ws + l.dx_rows);
+    if (int rc = launch_edge_dx_bf16("edge_dx", g, axes_ext, rho, bigw, s->c_in, d_rows, stream)) return rc;
+    if (int rc = launch_dx_gather_sum("dx_gather", d_rows, neighbors, ends, t_samples, t_ends, t_edge_ids, s->n_in, s->f_in * s->c_in,
+                                      1.0f / kGeluOut, grad_feat, stream))
+      return rc;
+    if (want_params) {
+      if (int rc = param_gradients(stream)) return rc;
+      if (int rc = weight_gradient()) return rc;
+    }
+    return final_sums.launch(stream);
+  }
   bool branch_forked = false;
   ForkJoin fj;  // joins on every exit path from here on
   if (feat_branch) {

@@ -383,6 +383,13 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
                                 float* partials, int n_partials, int* n_used, hipStream_t stream, bool gt16 = false);  // gt16: grad_t rows in the T16 block format
 bool edge_param_grad_bf16_t16_rows(const EdgeGeom& g, int channels);
+// edge-major feature gradient of a convolution with many more input than output rows (edge_dx.hip)
+bool edge_dx_bf16_applicable(const EdgeGeom& g, int channels);
+int launch_edge_dx_bf16(const char* tag, const EdgeGeom& g, const float* axes_ext, const float* rho, const uint32_t* grad_t,
+                        int channels, float* d_rows, hipStream_t stream);
+int launch_dx_gather_sum(const char* tag, const float* d_rows, const int32_t* neighbors, const int32_t* ends,
+                         const int32_t* t_samples, const int32_t* t_ends, const int32_t* t_edge_ids, int64_t n_src, int width,
+                         float scale, float* grad_feat, hipStream_t stream);
 int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, uint16_t* bt_hi, uint16_t* bt_lo,
                         hipStream_t stream, const float* scale_num = nullptr, float scale = 1.0f,
                         bool frag_layout = false);

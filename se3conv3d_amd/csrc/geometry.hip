@@ -377,15 +377,15 @@ __global__ __launch_bounds__(256) void batch_aabb_kernel(const float* __restrict
   flush();
 }
 
-// n_valid (device, may be NULL): rows from *n_valid on are unset (the tail of a capacity-bounded edge buffer) -- they
-// get the source id n_src, which sorts behind every real group and which no offset of group_ends_kernel reaches
+// (source, edge index) pairs of the list for the merge-sort form of the transposition.  n_valid (device, may be NULL): rows
+// from *n_valid on are unset (the tail of a capacity-bounded edge buffer) -- they get the source id n_src, which sorts
+// behind every real group and which no offset of group_ends_kernel reaches
 __global__ void split_edges_kernel(const int32_t* __restrict__ neighbors, int64_t e, const int32_t* __restrict__ n_valid,
-                                   int32_t n_src, int32_t* __restrict__ src, int32_t* __restrict__ smp) {
+                                   int32_t n_src, int32_t* __restrict__ src, int32_t* __restrict__ ids) {
   const int64_t valid = n_valid ? (int64_t)max(min((int64_t)*n_valid, e), (int64_t)0) : e;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
-    const bool ok = i < valid;
-    smp[i] = ok ? neighbors[i * 2] : 0;
-    src[i] = ok ? neighbors[i * 2 + 1] : n_src;
+    ids[i] = (int32_t)i;
+    src[i] = i < valid ? neighbors[i * 2 + 1] : n_src;
   }
 }
 
@@ -891,7 +891,7 @@ extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst
 // bit for bit), which costs what the forward query costs.
 namespace {
 struct TrLayout {
-  size_t tmp, cursor, temp, temp_bytes, total;       // counting form (n_src <= 2 * rows)
+  size_t tmp, tmp_ids, cursor, temp, temp_bytes, total;  // counting form (n_src <= 2 * rows)
   size_t src, smp, merge_temp, merge_bytes;           // merge-sort form (sparser graphs): keys / values sorted in place
 };
 struct TrLess {
@@ -903,6 +903,7 @@ TrLayout tr_layout(int64_t e) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = se3::align_up(off + bytes, 256); return o; };
   l.tmp = take(ne * 4);
+  l.tmp_ids = take(ne * 4);
   l.cursor = take(2 * ne * 4);
   (void)hipcub::DeviceScan::InclusiveSum(nullptr, l.temp_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(2 * ne));
   l.temp = take(l.temp_bytes);
@@ -941,16 +942,22 @@ __global__ void tr_count_kernel(const int32_t* __restrict__ neighbors, int64_t e
 // edge i goes to the next free slot of its source's segment; rows past the list (the unset tail of a bounded buffer) are zeroed
 __global__ void tr_scatter_kernel(const int32_t* __restrict__ neighbors, int64_t e, const int32_t* __restrict__ n_valid,
                                   int32_t n_src, const int32_t* __restrict__ ends, int32_t* __restrict__ cursor,
-                                  int32_t* __restrict__ tmp, int32_t* __restrict__ t_samples) {
+                                  int32_t* __restrict__ tmp, int32_t* __restrict__ tmp_ids, int32_t* __restrict__ t_samples,
+                                  int32_t* __restrict__ t_edge_ids) {
   const int64_t valid = valid_rows(n_valid, e);
   const int64_t total = n_src > 0 ? ends[n_src - 1] : 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i >= total) t_samples[i] = 0;  // nothing of the result is left unset
+    if (i >= total) {  // nothing of the result is left unset
+      t_samples[i] = 0;
+      if (t_edge_ids) t_edge_ids[i] = 0;
+    }
     if (i >= valid) continue;
     const int32_t p = neighbors[i * 2 + 1];
     if ((uint32_t)p >= (uint32_t)n_src) continue;
     const int32_t base = p > 0 ? ends[p - 1] : 0;
-    tmp[base + atomicAdd(&cursor[p], 1)] = neighbors[i * 2];
+    const int32_t slot = base + atomicAdd(&cursor[p], 1);
+    tmp[slot] = neighbors[i * 2];
+    tmp_ids[slot] = (int32_t)i;
   }
 }
 
@@ -959,15 +966,19 @@ __global__ void tr_scatter_kernel(const int32_t* __restrict__ neighbors, int64_t
 // registers and are compared through shuffles; up to kTrSegLds entries are staged in a wave-private piece of LDS and every
 // lane ranks its entries against broadcast reads, four at a time; longer ones are read back from memory (L^2 / 64 steps).
 constexpr int kTrSegLds = 2048;
-__global__ __launch_bounds__(256) void tr_segment_sort_kernel(const int32_t* __restrict__ tmp, const int32_t* __restrict__ ends,
-                                                              int64_t n_src, int32_t* __restrict__ t_samples) {
+__global__ __launch_bounds__(256) void tr_segment_sort_kernel(const int32_t* __restrict__ tmp, const int32_t* __restrict__ tmp_ids,
+                                                              const int32_t* __restrict__ ends, int64_t n_src,
+                                                              int32_t* __restrict__ t_samples, int32_t* __restrict__ t_edge_ids) {
   __shared__ __attribute__((aligned(16))) int32_t seg[4][kTrSegLds];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t p = (int64_t)blockIdx.x * 4 + wave; p < n_src; p += (int64_t)gridDim.x * 4) {
     const int start = p > 0 ? ends[p - 1] : 0;
     const int len = ends[p] - start;
     if (len <= 1) {
-      if (len == 1 && lane == 0) t_samples[start] = tmp[start];
+      if (len == 1 && lane == 0) {
+        t_samples[start] = tmp[start];
+        if (t_edge_ids) t_edge_ids[start] = tmp_ids[start];
+      }
       continue;
     }
     if (len <= 64) {
@@ -977,7 +988,10 @@ __global__ __launch_bounds__(256) void tr_segment_sort_kernel(const int32_t* __r
         const int vj = __shfl(v, j);
         rank += (vj < v || (vj == v && j < lane)) ? 1 : 0;
       }
-      if (lane < len) t_samples[start + rank] = v;
+      if (lane < len) {
+        t_samples[start + rank] = v;
+        if (t_edge_ids) t_edge_ids[start + rank] = tmp_ids[start + lane];
+      }
       continue;
     }
     if (len <= kTrSegLds) {
@@ -997,6 +1011,7 @@ __global__ __launch_bounds__(256) void tr_segment_sort_kernel(const int32_t* __r
           rank += (q.w < v || (q.w == v && j + 3 < i)) ? 1 : 0;
         }
         t_samples[start + rank] = v;
+        if (t_edge_ids) t_edge_ids[start + rank] = tmp_ids[start + i];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // the next source of this wavefront reuses the piece
@@ -1010,7 +1025,20 @@ __global__ __launch_bounds__(256) void tr_segment_sort_kernel(const int32_t* __r
         rank += (vj < v || (vj == v && j < i)) ? 1 : 0;
       }
       t_samples[start + rank] = v;
+      if (t_edge_ids) t_edge_ids[start + rank] = tmp_ids[start + i];
     }
+  }
+}
+
+// merge-sort form: the sorted values are edge indices -> the samples of those edges (rows behind the list: zeros)
+__global__ void tr_samples_of_ids_kernel(const int32_t* __restrict__ neighbors, const int32_t* __restrict__ sorted_src,
+                                         const int32_t* __restrict__ sorted_ids, int64_t e, int32_t n_src,
+                                         int32_t* __restrict__ t_samples, int32_t* __restrict__ t_edge_ids) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool ok = (uint32_t)sorted_src[i] < (uint32_t)n_src;
+    const int32_t id = ok ? sorted_ids[i] : 0;
+    t_samples[i] = ok ? neighbors[(int64_t)id * 2] : 0;
+    if (t_edge_ids) t_edge_ids[i] = id;
   }
 }
 
@@ -1020,7 +1048,7 @@ extern "C" size_t se3_csr_transpose_workspace_bytes(int64_t n_edges) { return tr
 
 extern "C" int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_rows, const int32_t* n_valid, int64_t n_src,
                                          void* workspace, size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends,
-                                         void* stream_) {
+                                         int32_t* t_edge_ids, void* stream_) {
   const int64_t n_edges = n_rows;
   if (n_edges < 0 || n_src < 0) return SE3_ERR_INVALID_ARGUMENT;
   if (n_edges >= (1ll << 30) || n_src >= (1ll << 31) - 1) return SE3_ERR_UNSUPPORTED;
@@ -1037,6 +1065,7 @@ extern "C" int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_row
   static const bool force_merge = getenv("SE3_TR_MERGE_SORT") != nullptr;  // A/B and test switch: the fallback form everywhere
   if (n_src <= 2 * n_edges && !force_merge) {
     int32_t* tmp = (int32_t*)(ws + l.tmp);
+    int32_t* tmp_ids = (int32_t*)(ws + l.tmp_ids);
     int32_t* cursor = (int32_t*)(ws + l.cursor);
     hipLaunchKernelGGL(tr_zero_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, t_ends, cursor, n_src);
     hipLaunchKernelGGL(tr_count_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, n_valid,
@@ -1045,8 +1074,9 @@ extern "C" int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_row
     if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, t_ends, t_ends, (int)n_src, stream) != hipSuccess)
       return SE3_ERR_LAUNCH;
     hipLaunchKernelGGL(tr_scatter_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, n_edges, n_valid,
-                       (int32_t)n_src, t_ends, cursor, tmp, t_samples);
-    hipLaunchKernelGGL(tr_segment_sort_kernel, dim3(blocks_for(n_src, 4)), dim3(256), 0, stream, tmp, t_ends, n_src, t_samples);
+                       (int32_t)n_src, t_ends, cursor, tmp, tmp_ids, t_samples, t_edge_ids);
+    hipLaunchKernelGGL(tr_segment_sort_kernel, dim3(blocks_for(n_src, 4)), dim3(256), 0, stream, tmp, tmp_ids, t_ends, n_src,
+                       t_samples, t_edge_ids);
     return check_launch();
   }
   // more than two sources per row of the list: stable merge sort of (source, sample) pairs, in place (no scratch either)
@@ -1057,14 +1087,16 @@ extern "C" int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_row
   size_t merge_bytes = l.merge_bytes;
   if (hipcub::DeviceMergeSort::StableSortPairs(ws + l.merge_temp, merge_bytes, src, smp, (int)n_edges, TrLess(), stream) != hipSuccess)
     return SE3_ERR_LAUNCH;
-  if (hipMemcpyAsync(t_samples, smp, (size_t)n_edges * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) return SE3_ERR_LAUNCH;
+  hipLaunchKernelGGL(tr_samples_of_ids_kernel, dim3(blocks_for(n_edges)), dim3(256), 0, stream, neighbors, src, smp, n_edges,
+                     (int32_t)n_src, t_samples, t_edge_ids);
   hipLaunchKernelGGL(group_ends_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, src, n_edges, n_src, t_ends);
   return check_launch();
 }
 
 extern "C" int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, void* workspace,
-                                 size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, void* stream) {
-  return se3_csr_transpose_bounded(neighbors, n_edges, nullptr, n_src, workspace, workspace_bytes, t_samples, t_ends, stream);
+                                 size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, int32_t* t_edge_ids, void* stream) {
+  return se3_csr_transpose_bounded(neighbors, n_edges, nullptr, n_src, workspace, workspace_bytes, t_samples, t_ends, t_edge_ids,
+                                   stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -262,21 +262,24 @@ class BallQuery(torch.autograd.Function):
         return None, None, None, None, None, None, None
 
 
-def csr_transpose(neighbors_i32: torch.Tensor, n_src: int, n_valid: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+def csr_transpose(neighbors_i32: torch.Tensor, n_src: int, n_valid: Optional[torch.Tensor] = None, want_edge_ids: bool = False):
     """Source-major copy of an edge list: ``t_samples [E]``, ``t_ends [n_src]`` (inclusive).  ``n_valid`` (device int32
     tensor, e.g. ``info`` of ``ball_query_bounded``): only the first ``n_valid[0]`` rows are edges -- the unset tail of a
-    capacity-sized buffer is ignored, without a host round trip."""
+    capacity-sized buffer is ignored, without a host round trip.  ``want_edge_ids``: a third result ``t_edge_ids [E]``,
+    the row of ``neighbors_i32`` every entry came from."""
     lib = _lib.load()
     dev = neighbors_i32.device
     e = neighbors_i32.shape[0]
     t_samples = torch.empty(e, dtype=torch.int32, device=dev)
     t_ends = torch.empty(n_src, dtype=torch.int32, device=dev)  # every entry is written by the library
+    t_ids = torch.empty(e, dtype=torch.int32, device=dev) if want_edge_ids else None
     ws = _workspace(lib.se3_csr_transpose_workspace_bytes(e), dev)
     _lib.check(lib.se3_csr_transpose_bounded(_ptr(neighbors_i32, torch.int32, "neighbors"), e,
                                              _ptr(n_valid, torch.int32, "n_valid", dev), n_src, C.c_void_p(ws.data_ptr()),
                                              ws.numel(), _ptr(t_samples, torch.int32, "t_samples"),
-                                             _ptr(t_ends, torch.int32, "t_ends"), _stream(dev)), "se3_csr_transpose_bounded")
-    return t_samples, t_ends
+                                             _ptr(t_ends, torch.int32, "t_ends"), _ptr(t_ids, torch.int32, "t_edge_ids"),
+                                             _stream(dev)), "se3_csr_transpose_bounded")
+    return (t_samples, t_ends, t_ids) if want_edge_ids else (t_samples, t_ends)
 
 
 # ------------------------------------------------------------------------- hierarchy build (row f-2)
@@ -612,6 +615,7 @@ class ConvGeometry:
     edge_info: Optional[torch.Tensor] = None  # [2] int32 on the device (bounded only): true edge count, overflow flag
     # the neighbourhood's own way to the source-major list (pc.BQNeighborhood.source_major), or None
     source_major_fn: Optional[Callable[[], Optional[Tuple[torch.Tensor, torch.Tensor]]]] = field(default=None, repr=False)
+    _edge_ids: Optional[torch.Tensor] = field(default=None, repr=False)  # third result of the library's transposition, if it built the list
 
     @staticmethod
     def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends, symmetric: bool = False) -> "ConvGeometry":
@@ -641,8 +645,9 @@ class ConvGeometry:
                     raise ValueError("a capacity-bounded edge buffer between two clouds needs its device-side edge count "
                                      "(edge_info) to be transposed: rows past it are unset")
                 # bounded: the unset tail of the buffer must not reach the sort (se3_csr_transpose_bounded)
-                self._transpose = csr_transpose(self.neighbors, self.pts_in.shape[0],
-                                                self.edge_info if self.bounded else None)
+                ts, te, self._edge_ids = csr_transpose(self.neighbors, self.pts_in.shape[0],
+                                                       self.edge_info if self.bounded else None, want_edge_ids=True)
+                self._transpose = (ts, te)
         return self._transpose
 
     def shape(self, c_in: int, c_out: int, num_basis: int, precision: Optional[str] = None) -> Se3Shape:
@@ -716,6 +721,7 @@ def se3conv_backward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weig
                                                     int(t_save is not None)), dev)
     rho_t, nu_t = _scalar(rho, "rho", dev), _scalar(nu, "nu", dev)
     _lib.check(lib.se3conv_bwd(*_geom_ptrs(geom), _ptr(t_samples, i32, "t_samples"), _ptr(t_ends, i32, "t_ends"),
+                               _ptr(geom._edge_ids if want_feat else None, i32, "t_edge_ids"),
                                _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),
                                _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
                                _ptr(rho_t, f32, "rho"), _ptr(nu_t, f32, "nu"), _ptr(t_save, f32, "t_save"),

@@ -1,8 +1,7 @@
 """GPU: the source-major copy of an edge list (se3_csr_transpose / se3_csr_transpose_bounded), every form of it against a
-stable sort of the list by source: per-wavefront LDS counters (few sources, long segments: an up-convolution), the counting
-form with its three segment rankings (<= 64 entries by shuffles, <= 2048 through LDS, longer ones from memory), the merge
-sort (more than two sources per row, and SE3_TR_MERGE_SORT=1 everywhere), bounded buffers with poisoned tails, and the
-whole thing captured into a HIP graph.  The reference has no such function: its backward scatters with float atomics
+stable sort of the list by source: the counting form with its three segment rankings (<= 64 entries by shuffles, <= 2048
+through LDS, longer ones from memory), the merge sort (more than two sources per row, and SE3_TR_MERGE_SORT=1 everywhere),
+bounded buffers with poisoned tails, the optional edge ids, and the whole thing captured into a HIP graph.  The reference has no such function: its backward scatters with float atomics
 (feat_basis_proj_grads.cu:126,140); this list is what replaces them with a deterministic gather."""
 import os
 import subprocess
@@ -43,11 +42,11 @@ def reference(nb, n_src):
 
 CASES = [
     # n_samples, n_src, degree, hub      which form
-    (6000, 300, 20, None),             # 120 k edges >= 32 x 300 sources: per-wavefront LDS counters
-    (20000, 2000, 4, None),            # 80 k edges, 40 per source: LDS counters again, one-entry-per-sample slices
-    (3000, 20000, 12, 7),              # counting form: short segments + one of 3000 entries (ranked from memory)
-    (4000, 5000, 3, 11),               # counting form (12 k < 32 x 5000): segments of 1..64, one of 4000
-    (1500, 40000, 2, 5),               # counting form, segment of 1500 (LDS ranking), most sources empty
+    (6000, 300, 20, None),             # few sources, segments of ~400 entries (ranked through LDS): an up-convolution's shape
+    (20000, 2000, 4, None),            # segments of ~40 (shuffles)
+    (3000, 20000, 12, 7),              # short segments + one of 3000 entries (ranked from memory)
+    (4000, 5000, 3, 11),               # segments of 1..64, one of 4000
+    (1500, 40000, 2, 5),               # a segment of 1500 (LDS ranking), most sources empty
     (40, 100000, 3, None),             # 120 rows, 100 k sources: the merge-sort form
     (1, 50, 9, None),                  # one sample
 ]
@@ -65,12 +64,18 @@ def test_transpose_is_the_stable_sort_by_source(amd, n_samples, n_src, degree, h
         tail = torch.stack((torch.randint(0, n_samples, (cap - e,), generator=g), torch.randint(0, n_src, (cap - e,), generator=g)), 1)
         buf = torch.cat((nb, tail.to(torch.int32))).to(DEV)
         info = torch.tensor([e, 0], dtype=torch.int32, device=DEV)
-        ts, te = amd.ops.csr_transpose(buf, n_src, info)
-        assert ts.shape[0] == cap and bool((ts[e:] == 0).all()), "rows behind the list must be zeroed"
+        ts, te, ti = amd.ops.csr_transpose(buf, n_src, info, want_edge_ids=True)
+        assert ts.shape[0] == cap and bool((ts[e:] == 0).all()) and bool((ti[e:] == 0).all()), "rows behind the list must be zeroed"
     else:
-        ts, te = amd.ops.csr_transpose(nb.to(DEV), n_src)
+        ts, te, ti = amd.ops.csr_transpose(nb.to(DEV), n_src, want_edge_ids=True)
     assert torch.equal(te.cpu(), want_e)
     assert torch.equal(ts[:e].cpu(), want_s)
+    # t_edge_ids: entry j of the result is row t_edge_ids[j] of the sample-major list
+    ti = ti[:e].cpu().long()
+    assert torch.equal(nb[ti, 0], want_s) and torch.equal(ti, torch.sort(nb[:, 1].long(), stable=True).indices)
+    # the third result is optional
+    ts2, te2 = amd.ops.csr_transpose(nb.to(DEV), n_src)
+    assert torch.equal(ts2.cpu(), want_s) and torch.equal(te2.cpu(), want_e)
 
 
 def test_transpose_of_an_empty_list_and_of_no_sources(amd):
