@@ -140,3 +140,47 @@ def test_level_to_level_convolution_against_oracle(amd, workload, direction):
         check_two_cloud_layer(amd, pc0, pc1, r0, c0, c1, seed=11)
     else:
         check_two_cloud_layer(amd, pc1, pc0, r1, c1, c0, seed=12)
+
+
+@pytest.mark.parametrize("f,c_in,c_out", [(2, 32, 64), (2, 64, 64), (4, 32, 32), (2, 128, 64)])
+def test_edge_major_feature_gradient_of_a_down_convolution(amd, f, c_in, c_out):
+    """A convolution with many more input than output rows takes the edge-major feature gradient (edge_dx.hip: D = phi gT^T per
+    frame-edge, summed per source point) in the split-bf16 modes: dX against the oracle, with and without the transposition's
+    edge ids (without them the kernel looks every edge up in the sample's neighbour list: same rows, same order, same bits),
+    for one and two pairs of centre frames, 32-channel rows and 64-channel blocks, and with the parameter gradients off
+    (grad_T is then computed for this path alone)."""
+    from se3conv3d_amd import ops
+    torch.manual_seed(f * 100 + c_in)
+    n_in, n_out = 6000, 700
+    cfg = {"pca": False, "n_frames": f, "fixed_axis": False}
+    pc_in = amd.pc.PointcloudRotEquiv(torch.rand(n_in, 3, device=DEV), torch.zeros(n_in, dtype=torch.int32, device=DEV), cfg)
+    pc_out = amd.pc.PointcloudRotEquiv(torch.rand(n_out, 3, device=DEV), torch.zeros(n_out, dtype=torch.int32, device=DEV), cfg)
+    r = W.radius_for_degree(n_in, 18)
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, r)
+    e = nbh.num_edges()
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c_in, c_out).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r), conv.norm_num_neighs_.fill_(n_out / e)
+    x = torch.randn(n_in * f, c_in, device=DEV)
+    g = torch.randn(n_out * f, c_out, device=DEV)
+    out, dx, da, db, dw = gpu_step(conv, pc_in, pc_out, nbh, x, g)
+    cpu = lambda t: t.detach().cpu()
+    ref = O.conv_forward_backward(cpu(pc_in.pts_), cpu(pc_out.pts_), cpu(pc_in.local_frames_), cpu(pc_out.local_frames_),
+                                  cpu(nbh.neighbors_), cpu(x), cpu(conv.proj_axes_), cpu(conv.proj_biases_), cpu(conv.conv_weights_),
+                                  1.0 / r, n_out / e, cpu(g))
+    tol = TOLS[ops._precision]
+    for got, want, name in zip((out, dx, da, db, dw), ref, ("out", "dX", "dA", "dbeta", "dW")):
+        assert rel_err(got, want) < tol, name
+    # the same backward without the edge ids, and with the parameter gradients off
+    geom = nbh._se3_geom[1]
+    assert geom._edge_ids is not None, "the library's transposition records where every entry came from"
+    ids, geom._edge_ids = geom._edge_ids, None
+    try:
+        _, dx_scan, *_ = gpu_step(conv, pc_in, pc_out, nbh, x, g)
+    finally:
+        geom._edge_ids = ids
+    assert torch.equal(dx_scan, dx)
+    for p in conv.parameters():
+        p.requires_grad_(False)
+    xg = x.clone().requires_grad_(True)
+    conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=xg, p_neighborhood=nbh).backward(g)
+    assert rel_err(xg.grad, ref[1]) < tol
