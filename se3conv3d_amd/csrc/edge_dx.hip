@@ -201,17 +201,24 @@ __global__ __launch_bounds__(256) void dx_gather_sum_kernel(const float* __restr
         }
       }
       const int cnt = min(G, t1 - (t0 + r * G));  // <= 0 for a group whose list has ended
-      for (int jj = 0; jj < G; ++jj) {
-        const int ee = __shfl(e, grp * G + jj);
-        if (jj >= cnt || ee < 0) continue;
-        const float4* blk = reinterpret_cast<const float4*>(d_rows + (int64_t)ee * width);
-        if (gl < w4) {
-          const float4 v = blk[gl];
-          acc[0].x += v.x, acc[0].y += v.y, acc[0].z += v.z, acc[0].w += v.w;
+      // four blocks in flight per lane: the loads of a step are issued before any of them is added (fixed order of the sum)
+      for (int j4 = 0; j4 < G; j4 += 4) {
+        int ee[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ee[u] = __shfl(e, grp * G + j4 + u);
+        if (__ballot(j4 < cnt) == 0) break;  // every group of the wavefront is past the end of its list
+        float4 v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = j4 + u < cnt && ee[u] >= 0;
+          const float4* blk = reinterpret_cast<const float4*>(d_rows + (int64_t)(ok ? ee[u] : 0) * width);
+          v0[u] = ok && gl < w4 ? blk[gl] : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (G == 64) v1[u] = ok && gl + 64 < w4 ? blk[gl + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (G == 64 && gl + 64 < w4) {
-          const float4 v = blk[gl + 64];
-          acc[1].x += v.x, acc[1].y += v.y, acc[1].z += v.z, acc[1].w += v.w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[0].x += v0[u].x, acc[0].y += v0[u].y, acc[0].z += v0[u].z, acc[0].w += v0[u].w;
+          if (G == 64) acc[1].x += v1[u].x, acc[1].y += v1[u].y, acc[1].z += v1[u].z, acc[1].w += v1[u].w;
         }
       }
     }
