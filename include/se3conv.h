@@ -382,6 +382,13 @@ int se3_knn_query_pair(const float* src_pts, const int32_t* src_batch, int64_t n
  * 27 cells is farther than one cell is recomputed by the all-pairs scan, so any cell size gives the exact
  * answer and a good one (about the expected k-NN distance) gives it ~100x faster on large clouds. */
 size_t se3_knn_query_grid_workspace_bytes(int64_t n);
+/* Grid parameters for se3_knn_query_grid from the per-batch boxes (se3_batch_aabb), one launch (round 4; as a dozen torch
+ * calls and a bincount they cost more than the search itself): cell = cell_factor x the k-NN distance a uniformly
+ * filled box of each batch element's extent and point count would have (the larger of the volume, area and length
+ * estimates, maximum over the batch elements; batch ids sorted) -> aabb_min [B,3] (box minima - 1e-6), num_cells [3],
+ * cell_size [3] (one value three times), all on the device.  Only a speed knob: the grid search is exact for any cell. */
+int se3_knn_grid_params(const int32_t* batch_ids, int64_t n, const float* box_min, const float* box_max, int32_t n_batches,
+                        int32_t k, float cell_factor, float* aabb_min, int32_t* num_cells, float* cell_size, void* stream);
 int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, const float* aabb_min, const int32_t* num_cells,
                        const float* cell_size, int64_t n, int32_t k, int32_t* out, void* workspace,
                        size_t workspace_bytes, void* stream);

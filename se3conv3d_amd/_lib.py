@@ -75,6 +75,7 @@ SIGNATURES = {
     "se3_rows_gather": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "se3_rows_scatter": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "se3_knn_query_grid_workspace_bytes": (C.c_size_t, [_I64]),
+    "se3_knn_grid_params": (C.c_int, [_P, _I64, _P, _P, _I32, _I32, C.c_float, _P, _P, _P, _P]),
     "se3_knn_query_grid": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_size_t, _P]),
     "se3_pca_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_glue_workspace_bytes": (_SZ, [_I32]),

@@ -660,6 +660,83 @@ extern "C" int se3_ball_query_grid(const float* pts_src, const int32_t* batch_sr
 }
 
 
+namespace {
+// se3_knn_grid_params: one workgroup; thread b takes batch element b, b + 256, ...
+__global__ __launch_bounds__(256) void knn_grid_params_kernel(const int32_t* __restrict__ batch_ids, int64_t n,
+                                                              const float* __restrict__ box_min, const float* __restrict__ box_max,
+                                                              int n_batches, int k, float cell_factor, float* __restrict__ aabb_min,
+                                                              int32_t* __restrict__ num_cells, float* __restrict__ cell_size) {
+  __shared__ float s_c[256], s_e[256];
+  __shared__ int s_cells[3][256];
+  __shared__ float s_cell;
+  float c_best = 0.f, e_best = 0.f;
+  for (int b = threadIdx.x; b < n_batches; b += 256) {
+    // points of batch element b (ids sorted): upper bound - lower bound
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] < b) lo = mid + 1; else hi = mid; }
+    const int64_t first = lo;
+    hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (batch_ids[mid] <= b) lo = mid + 1; else hi = mid; }
+    const float cnt = fmaxf((float)(lo - first), 1.0f);
+    float e[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) e[d] = fmaxf(box_max[b * 3 + d] - box_min[b * 3 + d], 0.f);
+    const float e1 = fmaxf(e[0], fmaxf(e[1], e[2])), e3 = fminf(e[0], fminf(e[1], e[2]));
+    const float e2 = e[0] + e[1] + e[2] - e1 - e3;
+    const float c_vol = cbrtf((float)k * e1 * e2 * e3 / (4.19f * cnt));
+    const float c_area = sqrtf((float)k * e1 * e2 / (3.14f * cnt));
+    const float c_len = (float)k * e1 / (2.0f * cnt);
+    c_best = fmaxf(c_best, fmaxf(c_vol, fmaxf(c_area, c_len)));
+    e_best = fmaxf(e_best, e1);
+  }
+  s_c[threadIdx.x] = c_best, s_e[threadIdx.x] = e_best;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      s_c[threadIdx.x] = fmaxf(s_c[threadIdx.x], s_c[threadIdx.x + st]);
+      s_e[threadIdx.x] = fmaxf(s_e[threadIdx.x], s_e[threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_cell = fmaxf(cell_factor * s_c[0], fmaxf(s_e[0] * 1e-6f, 1e-30f));
+  __syncthreads();
+  const float cell = s_cell;
+  int cells[3] = {1, 1, 1};
+  for (int b = threadIdx.x; b < n_batches; b += 256) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float mn = box_min[b * 3 + d] - 1e-6f;
+      aabb_min[b * 3 + d] = mn;
+      cells[d] = max(cells[d], (int)fminf((box_max[b * 3 + d] - mn) / cell, 1048576.0f) + 1);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) s_cells[d][threadIdx.x] = cells[d];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) s_cells[d][threadIdx.x] = max(s_cells[d][threadIdx.x], s_cells[d][threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) {
+    num_cells[threadIdx.x] = s_cells[threadIdx.x][0];
+    cell_size[threadIdx.x] = cell;
+  }
+}
+}  // namespace
+
+extern "C" int se3_knn_grid_params(const int32_t* batch_ids, int64_t n, const float* box_min, const float* box_max,
+                                   int32_t n_batches, int32_t k, float cell_factor, float* aabb_min, int32_t* num_cells,
+                                   float* cell_size, void* stream) {
+  if (n < 0 || n_batches < 1 || k < 1 || !(cell_factor > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
+  if (!box_min || !box_max || !aabb_min || !num_cells || !cell_size || (n > 0 && !batch_ids)) return SE3_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, batch_ids, n, box_min, box_max,
+                     (int)n_batches, (int)k, cell_factor, aabb_min, num_cells, cell_size);
+  return check_launch();
+}
+
 extern "C" size_t se3_knn_query_grid_workspace_bytes(int64_t n) { return knn_layout(n).total; }
 
 extern "C" int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, const float* aabb_min,

@@ -509,10 +509,11 @@ def _knn_cell_size(mn, mx, counts, k: int) -> torch.Tensor:
     return torch.maximum(c, (e1.max() * 1e-6).clamp_min(1e-30))
 
 
-def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: str = "auto") -> torch.Tensor:
+def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: str = "auto", box=None) -> torch.Tensor:
     """``point_cloud_lib_ops.knn_query``: self-kNN inside each batch element, ``[N,k]`` int32 (self first,
     ascending distance, ties to the lower index, -1 padded).  ``method``: "grid" (cell grid + exact fallback),
-    "scan" (all pairs inside the batch element) or "auto" (grid from KNN_GRID_MIN_POINTS points on)."""
+    "scan" (all pairs inside the batch element) or "auto" (grid from KNN_GRID_MIN_POINTS points on).  ``box``: the
+    cloud's ``batch_aabb`` result when the caller has it (``Pointcloud.aabb()``)."""
     lib = _lib.load()
     pts = _as(pts, torch.float32)
     b = _as(batch_ids, torch.int32)
@@ -532,12 +533,17 @@ def knn_query(pts, batch_ids, k: int, n_batches: Optional[int] = None, method: s
         _lib.check(lib.se3_knn_query(_ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), n, int(k),
                                      _ptr(out, i32, "out"), _stream(dev)), "se3_knn_query")
         return out
-    mn, mx = batch_aabb(pts, b, n_batches)
-    counts = torch.bincount(b.to(torch.int64), minlength=mn.shape[0])
-    cell = _knn_cell_size(mn, mx, counts, int(k))
-    mn = (mn - 1e-6).contiguous()
-    num_cells = (((mx - mn) / cell).clamp_max(2.0 ** 20).to(i32) + 1).max(dim=0)[0].to(i32).contiguous()
-    cell3 = cell.to(f32).reshape(1).expand(3).contiguous()
+    # boxes, then cell size / shifted minima / cell counts in ONE launch (se3_knn_grid_params: what _knn_cell_size and the
+    # lines of BallQuery.py:34-38 compute -- as a dozen torch calls and a bincount they cost more than the search)
+    box_mn, mx = box if box is not None else batch_aabb(pts, b, n_batches)
+    nb = box_mn.shape[0]
+    mn = torch.empty((nb, 3), dtype=f32, device=dev)
+    num_cells = torch.empty(3, dtype=i32, device=dev)
+    cell3 = torch.empty(3, dtype=f32, device=dev)
+    _lib.check(lib.se3_knn_grid_params(_ptr(b, i32, "batch_ids", dev), n, _ptr(box_mn, f32, "box_min", dev),
+                                       _ptr(mx, f32, "box_max", dev), nb, int(k), float(KNN_CELL_FACTOR), _ptr(mn, f32, "aabb_min"),
+                                       _ptr(num_cells, i32, "num_cells"), _ptr(cell3, f32, "cell_size"), _stream(dev)),
+               "se3_knn_grid_params")
     ws = _workspace(lib.se3_knn_query_grid_workspace_bytes(n), dev)
     _lib.check(lib.se3_knn_query_grid(
         _ptr(pts, f32, "pts"), _ptr(b, i32, "batch_ids", dev), _ptr(mn, f32, "aabb_min"), _ptr(num_cells, i32, "num_cells"),

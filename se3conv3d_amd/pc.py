@@ -360,7 +360,12 @@ class KnnNeighborhood(Neighborhood):
     def __compute_neighborhood__(self):
         self_query = self.pc_src_ is self.samples_
         if self_query:
-            ids = ops.KNNQuery.apply(self.pc_src_.pts_, self.pc_src_.batch_ids_, self.k_)
+            # the op behind ops.KNNQuery (which stays for code that uses it directly), with what the cloud already knows:
+            # its batch count and its boxes (no device read-back, no second pass over the points)
+            pc = self.pc_src_
+            grid = pc.pts_.shape[0] >= ops.KNN_GRID_MIN_POINTS and self.k_ <= 32 and hasattr(pc, "aabb")
+            ids = ops.knn_query(pc.pts_, pc.batch_ids_, self.k_, pc.num_batches() if hasattr(pc, "num_batches") else None,
+                                box=pc.aabb() if grid else None)
         else:
             ids = ops.knn_query_pair(self.pc_src_.pts_, self.pc_src_.batch_ids_, self.samples_.pts_,
                                      self.samples_.batch_ids_, self.k_)
