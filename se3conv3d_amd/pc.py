@@ -300,8 +300,8 @@ class BQNeighborhood(Neighborhood):
 
     def source_major(self):
         """The source-major copy of the edge list the operator's backward reads -- ``(t_samples [rows], t_ends [N_src])`` -- or
-        ``None`` when the library's transposition of the list is the better way to get it.  Fewer sources than samples (an
-        up-convolution: every source has hundreds of edges) is the case se3_csr_transpose is slow for; the list is then a
+        ``None`` when the library's transposition of the list is the better way to get it.  Long segments (an
+        up-convolution: every source has hundreds of edges) are the case se3_csr_transpose is slow for; the list is then a
         SECOND ball query with the clouds' roles swapped: ``||(s - p) / r|| < 1`` is bit for bit the same predicate both
         ways, so it finds exactly the same edges, grouped by source, in an order that depends on the points only
         (deterministic; not ascending in the sample id, which no consumer needs).  Capacity-bounded like the forward list
@@ -309,11 +309,15 @@ class BQNeighborhood(Neighborhood):
         if self.symmetric_ or self.max_neighbors_ != 0 or getattr(self, "neighbors_i32_", None) is None:
             return None
         n_src, n_smp = self.pc_src_.pts_.shape[0], self.samples_.pts_.shape[0]
-        if n_src >= n_smp or n_src == 0:
+        rows = int(self.neighbors_i32_.shape[0])
+        # segments of 16 entries and up (rows of the edge buffer per source: an up-convolution has hundreds, two clouds of
+        # one size ~30, a down-convolution ~4): the second query is cheaper than the library's transposition there (0.2
+        # against 0.32 ms at 65 k points x 31 edges); shorter segments are the transposition's good case, and the case the
+        # edge-major feature gradient wants its edge ids for
+        if n_src == 0 or rows < 16 * n_src:
             return None
         cached = getattr(self, "_source_major", None)
         if cached is None:
-            rows = int(self.neighbors_i32_.shape[0])
             box = self.samples_.aabb() if hasattr(self.samples_, "aabb") and ops.ball_query_needs_grid(n_smp) else None
             _, t_ends, info, t_samples = ops.ball_query_bounded(
                 self.samples_.pts_, self.pc_src_.pts_, self.samples_.batch_ids_, self.pc_src_.batch_ids_, self.radius_, rows,
