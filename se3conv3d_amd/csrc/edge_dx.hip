@@ -66,7 +66,21 @@ __global__ __launch_bounds__(128, SE3_DX_WAVES) void edge_dx_bf16_kernel(EdgeGeo
   for (int a0 = 0; a0 < g.f_ctr; a0 += 2) {
     __syncthreads();             // the previous pair's fragments are no longer read (first one: the MLP weights are in place)
 
-    // this wavefront's frame of the item: grad_T row -> B fragments of D = phi gT^T
+    auto row_of_fe = [&](int fe) {
+      const int e = start + (POW2 ? fe >> fnb_shift : fe / g.f_nb);
+      const int nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+      return (POW2 ? nb << fnb_shift : nb * g.f_nb) + (POW2 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
+    };
+    const int c_first = 32 * wv;
+    float xn_nx[3], rn_nx[9], yc[3], rc[9];
+    // Every load of the item's start goes out before any result is needed: the centre's record (half h: centre frame a0 + h),
+    // the first chunk's neighbour id, this wavefront's grad_T row (its frame of the pair), and -- once the id is there --
+    // the neighbour's record; the fragments are built and parked in LDS behind all of that.
+    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + h), yc, rc);
+    const int fe0 = min(c_first + kcol, n_total - 1);
+    int nb0 = 0;
+    if (c_first < n_total) nb0 = g.nbr[(int64_t)(start + (POW2 ? fe0 >> fnb_shift : fe0 / g.f_nb)) * g.nbr_stride + g.nbr_offset];
+    uint4 gw[CT][2][2];
     {
       const uint32_t* gt_row = grad_t + (((int64_t)ctr * g.f_ctr + a0 + wv) * row_ch + c_off) * kBasis;
 #pragma unroll
@@ -74,27 +88,24 @@ __global__ __launch_bounds__(128, SE3_DX_WAVES) void edge_dx_bf16_kernel(EdgeGeo
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const uint32_t* src = gt_row + (32 * t + kcol) * kBasis + 16 * s + 4 * h;
-          const uint4 p0 = *reinterpret_cast<const uint4*>(src);       // k = 16 s + 4 h + 0..3  = acc_row(8 s + j, h), j = 0..3
-          const uint4 p1 = *reinterpret_cast<const uint4*>(src + 8);   // k = 16 s + 8 + 4 h + .. = acc_row(8 s + j, h), j = 4..7
-          const uint32_t w[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-          u32x4 f_hi, f_lo;
-          frags_from_words(w, f_hi, f_lo);
-          *reinterpret_cast<u32x4*>(&lds_gt[wv][t][s][0][lane][0]) = f_hi;
-          *reinterpret_cast<u32x4*>(&lds_gt[wv][t][s][1][lane][0]) = f_lo;
+          gw[t][s][0] = *reinterpret_cast<const uint4*>(src);       // k = 16 s + 4 h + 0..3  = acc_row(8 s + j, h), j = 0..3
+          gw[t][s][1] = *reinterpret_cast<const uint4*>(src + 8);   // k = 16 s + 8 + 4 h + .. = acc_row(8 s + j, h), j = 4..7
         }
     }
-    float yc[3], rc[9];
-    load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + h), yc, rc);  // half h: centre frame a0 + h
+    if (c_first < n_total)
+      load_geom_record(nbg_rs, (POW2 ? nb0 << fnb_shift : nb0 * g.f_nb) + (POW2 ? fe0 & ((1 << fnb_shift) - 1) : fe0 % g.f_nb), xn_nx, rn_nx);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {  // grad_T words -> B fragments of D = phi gT^T
+        const uint32_t w[8] = {gw[t][s][0].x, gw[t][s][0].y, gw[t][s][0].z, gw[t][s][0].w,
+                               gw[t][s][1].x, gw[t][s][1].y, gw[t][s][1].z, gw[t][s][1].w};
+        u32x4 f_hi, f_lo;
+        frags_from_words(w, f_hi, f_lo);
+        *reinterpret_cast<u32x4*>(&lds_gt[wv][t][s][0][lane][0]) = f_hi;
+        *reinterpret_cast<u32x4*>(&lds_gt[wv][t][s][1][lane][0]) = f_lo;
+      }
     __syncthreads();  // both frames' fragments are in place
-
-    auto row_of_fe = [&](int fe) {
-      const int e = start + (POW2 ? fe >> fnb_shift : fe / g.f_nb);
-      const int nb = g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-      return (POW2 ? nb << fnb_shift : nb * g.f_nb) + (POW2 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
-    };
-    const int c_first = 32 * wv;
-    float xn_nx[3], rn_nx[9];
-    if (c_first < n_total) load_geom_record(nbg_rs, row_of_fe(min(c_first + kcol, n_total - 1)), xn_nx, rn_nx);
 
     for (int c0 = c_first; c0 < n_total; c0 += 64) {
       const int cnt = min(32, n_total - c0);
