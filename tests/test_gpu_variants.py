@@ -7,8 +7,8 @@ re-running a slice of the parity suite in a child process with the variable set:
   SE3_NO_T24=1      T and U as packed hi/lo words instead of the 3-byte row format (what C < 64 always uses)
   SE3_OVERLAP=1     backward branches on two streams at every size (default: 4 k - 32 k output rows only)
   SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
-  SE3_DX_PATH=1     feature gradient edge-major (edge_dx.hip) wherever it is implemented, =0 never (the default decides by the
-                    bytes either form moves: down-convolutions only)
+  SE3_DX_PATH=1     feature gradient edge-major (edge_dx.hip) wherever it is implemented (the default decides by the bytes
+                    either form moves -- down-convolutions and sparse levels only -- so the rest of the suite runs the U form)
 
 (The merged backward kernel, the fused edge + contraction kernel and the chunk-stream kernels of rounds 1-2 lost their A/B
 measurements -- profiles/r02_levels_fused.txt, r02_stream_kernel_ab.txt, r03_merged_backward_and_stash_ab.txt -- and were
@@ -29,7 +29,7 @@ SLICE = "golden or random_shapes or headline_subset or features_only or empty_ro
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("var", ["SE3_NO_PAIR", "SE3_PG_SINGLE", "SE3_PAIR_PERSIST=64", "SE3_NO_T24", "SE3_OVERLAP",
-                                 "SE3_BWD_BRANCH_ORDER", "SE3_DX_PATH=1", "SE3_DX_PATH=0"])
+                                 "SE3_BWD_BRANCH_ORDER", "SE3_DX_PATH=1"])
 def test_variant_passes_parity_slice(var):
     env = dict(os.environ)
     name, _, value = var.partition("=")
