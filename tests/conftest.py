@@ -58,3 +58,49 @@ def built_library():
     from se3conv3d_amd import build
 
     return build.build(verbose=False)
+
+
+# ----------------------------------------------------------------------- the reference network's own conv calls
+NETWORK_FIXTURE = os.path.join(GOLDEN, "network_faust_calls.npz")
+
+
+def network_calls():
+    """The 21 convolution calls of the reference's FPNSegUNetMLPGeluRotEqFAUST recorded by tools/gen_golden.py
+    (`network_case`): a list of dicts with the clouds, the neighbourhood, buffers, input, output and the gradients
+    autograd delivered.  The 9.2 M weights are not stored: they are re-drawn from their seeds by the generator's own
+    function and checked against the stored sums (bit-for-bit the same torch CPU generator calls)."""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from gen_golden import _seeded_conv_params
+
+    z = load_npz(NETWORK_FIXTURE)
+    calls = []
+    for i in range(int(z["n_calls"])):
+        p = f"c{i:02d}/"
+        conv_index, ci, co, ni, c_in, c_out = (int(v) for v in z[p + "meta"])
+        axes, biases, weights = _seeded_conv_params(conv_index, 9, c_in, 32, c_out)
+        sums = [float(t.double().sum()) for t in (axes, biases, weights)] + [float(weights.double().abs().sum())]
+        assert np.allclose(sums, z[p + "param_sums"].numpy(), rtol=1e-12, atol=1e-12), \
+            "the seeded parameters of the network fixture did not re-draw identically (another torch CPU generator?)"
+        rec = {"index": i, "c_in": c_in, "c_out": c_out, "proj_axes": axes, "proj_biases": biases, "conv_weights": weights,
+               "rho": z[p + "rho"], "nu": z[p + "nu"], "same_cloud": ci == co}
+        for side, c in (("in", ci), ("out", co)):
+            rec["pts_" + side], rec["batch_" + side] = z[f"cloud{c}/pts"], z[f"cloud{c}/batch"]
+            rec["frames_" + side] = z[f"cloud{c}/frames"]
+        rec["neighbors"], rec["ends"], rec["radius"] = z[f"nbh{ni}/neighbors"], z[f"nbh{ni}/ends"], float(z[f"nbh{ni}/radius"])
+        for k in ("x", "out", "grad_out", "dx", "dA", "dbeta", "dW", "dW_pos", "dW_at", "dW_norm"):
+            if p + k in z:
+                rec[k] = z[p + k]
+        calls.append(rec)
+    return calls
+
+
+def check_weight_gradient(got: torch.Tensor, rec, tol: float):
+    """dW of a recorded call: in full where the fixture holds it, else at the fixture's sampled positions + its norm."""
+    if "dW" in rec:
+        assert rel_err(got, rec["dW"]) < tol
+        return
+    at = got.detach().reshape(-1).cpu()[rec["dW_pos"].long()]
+    assert rel_err(at, rec["dW_at"]) < tol
+    assert abs(float(got.detach().double().norm()) / float(rec["dW_norm"]) - 1.0) < tol

@@ -464,6 +464,154 @@ def pne_case(pclib, seed, n_in, n_out, c_in, c_out, k_deg, batches):
     }
 
 
+
+def _seeded_conv_params(index, dims, c_in, num_basis, c_out):
+    """Parameters of conv call `index` of the network fixture, from a seed alone (the 21 convolutions of the reference's
+    FAUST network hold 9.2 M weights = 37 MB: the fixture stores the seeds' results as checksums, tests/test_gpu_network_replay.py
+    re-draws them with the same calls).  Same distributions as the reference's init (PNEConvLayer.py:79-88), biases
+    moved off zero."""
+    g = torch.Generator().manual_seed(7000 + index)
+    ba, bw = float(np.sqrt(1.0 / dims)), float(np.sqrt(1.0 / (c_in * num_basis)))
+    axes = (torch.rand(dims, num_basis, generator=g) * 2 - 1) * ba
+    biases = (torch.rand(num_basis, generator=g) * 2 - 1) * 0.5
+    weights = (torch.rand(c_in, num_basis, c_out, generator=g) * 2 - 1) * bw
+    return axes, biases, weights
+
+
+NET_SAMPLE = 2048  # entries of a weight gradient with more than 4 096 entries that the fixture keeps (seeded positions)
+
+
+def network_case(pclib, seed):
+    """BASELINE.json config 2: the reference's own FPNSegUNetMLPGeluRotEqFAUST (models/FPNSegUNet.py:198-223,
+    Encoder.py:116-173, FPNDecoder.py:87-137, tasks/SemSeg/seg_models.py:16-108) built by the reference, fed through the
+    call sequence of the task script (create_hierarchy, tasks/SemSeg/train_dfaust_rot.py:108-158, with the configuration
+    confs/dfaust/dfaust_I_rot_pca_2F.yaml: init / output sub-sample 0.04, grid sub-samples 0.05 ... 0.4, PCA frames from
+    kNN 16, F = 2) on two synthetic bodies, one pre-process pass (EMA buffers) and one training-mode forward + backward.
+    A forward hook on every PNEConvLayerRotEquiv records what the network feeds to and gets from each of its 21
+    convolution calls: clouds, neighbourhood, buffers, input, output, and the gradients autograd delivers (tensor hooks).
+    Weights are re-drawn per conv from a seed (see _seeded_conv_params) before the pass; weight gradients above 4 096
+    entries are kept at NET_SAMPLE seeded positions plus their norm.  Data only."""
+    import importlib
+
+    from einops import repeat
+
+    for path in ("/root/reference", "/root/reference/tasks/SemSeg"):
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        seg = importlib.import_module("seg_models")
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = seg.FPNSegUNetMLPGeluRotEqFAUST(1, 8, 0.5, 0.0)
+    convs = [m for m in model.modules() if isinstance(m, pclib.layers.PNEConvLayerRotEquiv)]
+    md = {"init_subsample": 0.04, "output_subsample": 0.04, "grid_subsamples": [0.05, 0.1, 0.2, 0.4],
+          "RefFrames": {"pca": True, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}, "fixed_axis": False, "n_frames": 2}}
+
+    def body(n, scale, g):  # a thin shell around an ellipsoid of roughly a torso's proportions
+        u = torch.randn(n, 3, generator=g)
+        u = u / u.norm(dim=1, keepdim=True)
+        return u * torch.tensor([0.25, 0.85, 0.15]) * scale + 0.01 * torch.randn(n, 3, generator=g)
+
+    g = torch.Generator().manual_seed(seed + 1)
+    n_raw = 1100
+    pts = torch.cat([body(n_raw, 0.40, g), body(n_raw, 0.34, g) + torch.tensor([2.0, 0.0, 0.0])])
+    bid = torch.cat([torch.zeros(n_raw, dtype=torch.int32), torch.ones(n_raw, dtype=torch.int32)])
+    feats = torch.ones(2 * n_raw, 1)
+    with torch.no_grad():  # create_hierarchy(p_init_subsample=True) of the task script
+        pc = pclib.pc.Pointcloud(pts, bid)
+        samp = pclib.pc.GridSubSample(pc, md["init_subsample"])
+        new_pts = samp.__subsample_tensor__(pc.pts_, "avg")
+        new_bid = samp.__subsample_tensor__(pc.batch_ids_, "max")
+        new_f = samp.__subsample_tensor__(feats, "avg")
+        new_pc = pclib.pc.PointcloudRotEquiv(new_pts, new_bid, md["RefFrames"])
+        hier = pclib.pc.PointHierarchyRotEquiv(new_pc, len(md["grid_subsamples"]), "grid_avg", grid_radii=md["grid_subsamples"])
+        radii = [md["init_subsample"]] + md["grid_subsamples"]
+        samp2 = pclib.pc.GridSubSample(pc, md["output_subsample"], p_rnd_sample=True)
+        out_pc = pclib.pc.PointcloudRotEquiv(samp2.__subsample_tensor__(pc.pts_, "avg"),
+                                             samp2.__subsample_tensor__(pc.batch_ids_, "max"), md["RefFrames"])
+    x0 = repeat(new_f, "n d -> (n times) d", times=md["RefFrames"]["n_frames"])
+    # seeded parameters (see _seeded_conv_params), in the order model.modules() lists the convolutions
+    with torch.no_grad():
+        for i, c in enumerate(convs):
+            a, b, w = _seeded_conv_params(i, 9, c.conv_weights_.shape[0], 32, c.conv_weights_.shape[2])
+            c.proj_axes_.copy_(a), c.proj_biases_.copy_(b), c.conv_weights_.copy_(w)
+    model.eval()
+    model.start_pre_process()
+    with torch.no_grad():
+        for _ in range(3):
+            model(hier, x0, radii, out_pc)
+    model.end_pre_process()
+    model.train()
+
+    calls = []
+
+    def hook(mod, args, kwargs, out):
+        rec = {"mod": mod, "kw": kwargs, "out": out, "grad_out": None, "dx": None}
+        out.register_hook(lambda gr, rec=rec: rec.__setitem__("grad_out", gr.detach().clone()))
+        xin = kwargs["p_in_features"]
+        if xin.requires_grad:
+            xin.register_hook(lambda gr, rec=rec: rec.__setitem__("dx", gr.detach().clone()))
+        calls.append(rec)
+
+    handles = [c.register_forward_hook(hook, with_kwargs=True) for c in convs]
+    y = model(hier, x0, radii, out_pc)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    for h in handles:
+        h.remove()
+    assert len(calls) == len(convs) == 21
+
+    clouds, nbhs = [], []
+
+    def cloud_id(pcx):
+        for i, c in enumerate(clouds):
+            if c is pcx:
+                return i
+        clouds.append(pcx)
+        return len(clouds) - 1
+
+    def nbh_id(nb):
+        for i, c in enumerate(nbhs):
+            if c is nb:
+                return i
+        nbhs.append(nb)
+        return len(nbhs) - 1
+
+    data = {"n_calls": np.int32(len(calls)), "sample": np.int32(NET_SAMPLE)}
+    for i, rec in enumerate(calls):
+        mod, kw = rec["mod"], rec["kw"]
+        ci, co, ni = cloud_id(kw["p_pc_in"]), cloud_id(kw["p_pc_out"]), nbh_id(kw["p_neighborhood"])
+        w = mod.conv_weights_
+        p = f"c{i:02d}/"
+        data[p + "meta"] = np.array([convs.index(mod), ci, co, ni, w.shape[0], w.shape[2]], dtype=np.int32)
+        data[p + "rho"], data[p + "nu"] = mod.norm_neigh_dist_.numpy(), mod.norm_num_neighs_.numpy()
+        data[p + "param_sums"] = np.array([float(t.detach().double().sum()) for t in (mod.proj_axes_, mod.proj_biases_, w)] +
+                                          [float(w.detach().double().abs().sum())])
+        data[p + "x"], data[p + "out"] = kw["p_in_features"].detach().numpy(), rec["out"].detach().numpy()
+        data[p + "grad_out"] = rec["grad_out"].numpy()
+        if rec["dx"] is not None:
+            data[p + "dx"] = rec["dx"].numpy()
+        data[p + "dA"], data[p + "dbeta"] = mod.proj_axes_.grad.numpy(), mod.proj_biases_.grad.numpy()
+        dw = w.grad
+        if dw.numel() <= 4096:
+            data[p + "dW"] = dw.numpy()
+        else:
+            pos = torch.randperm(dw.numel(), generator=torch.Generator().manual_seed(9000 + i))[:NET_SAMPLE]
+            data[p + "dW_pos"], data[p + "dW_at"] = pos.numpy().astype(np.int32), dw.reshape(-1)[pos].numpy()
+            data[p + "dW_norm"] = np.float64(dw.double().norm())
+    for i, c in enumerate(clouds):
+        data[f"cloud{i}/pts"], data[f"cloud{i}/batch"] = c.pts_.numpy(), c.batch_ids_.numpy().astype(np.int32)
+        data[f"cloud{i}/frames"] = c.local_frames_.numpy()
+    for i, nb in enumerate(nbhs):
+        data[f"nbh{i}/neighbors"] = nb.neighbors_.numpy().astype(np.int32)
+        data[f"nbh{i}/ends"] = nb.start_ids_.numpy().astype(np.int32)
+        data[f"nbh{i}/radius"] = np.float64(nb.radius_)
+    data["n_clouds"], data["n_nbhs"] = np.int32(len(clouds)), np.int32(len(nbhs))
+    return data
+
+
 PNE_CASES = [
     # name,              seed, n_in, n_out, c_in, c_out, k, batches
     ("pne_n300_c32",       9, 300, None, 32, 32, 16, 1),
@@ -512,6 +660,15 @@ def main():
             json.dump(state_dict_keys(pclib), fh, indent=1, sort_keys=True)
         print(f"{path}: written")
     if only == "keys":
+        return
+    if only in ("", "network"):
+        path = os.path.join(OUT, "network_faust_calls.npz")
+        data = network_case(pclib, 23)
+        np.savez_compressed(path, **data)
+        print("level points:", [int(data[f"cloud{i}/pts"].shape[0]) for i in range(int(data["n_clouds"]))])
+        print(f"{path}: calls={int(data['n_calls'])} clouds={int(data['n_clouds'])} nbhs={int(data['n_nbhs'])} "
+              f"size={os.path.getsize(path) / 1e6:.2f} MB")
+    if only == "network":
         return
     if only in ("", "block"):
         path = os.path.join(OUT, "resnetformer_block.npz")
