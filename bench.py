@@ -149,7 +149,8 @@ def profile_level(lib, lv, reps, fn=None):
             continue
         ms, cnt = C.c_double(0), C.c_int64(0)
         lib.se3_profile_read(tag.encode(), C.byref(ms), C.byref(cnt))
-        stages[tag] = (ms.value / max(cnt.value, 1), cnt.value)
+        # (average per launch, launches, total per step): a row-sliced schedule (SE3_SLICE_MB) launches a stage once per slice
+        stages[tag] = (ms.value / max(cnt.value, 1), cnt.value, ms.value / reps)
     lib.se3_profile_reset()
     return stages
 
@@ -420,8 +421,8 @@ def run_rank(args):
         core = {t: v for t, v in stages.items() if t in own}
         roofline = None
         if core:
-            dom = max(core, key=lambda t: core[t][0])
-            sec = core[dom][0] * 1e-3
+            dom = max(core, key=lambda t: core[t][2])
+            sec = core[dom][2] * 1e-3  # the stage's launches of one step together (one launch unless the rows are sliced)
             gbs, tf = own[dom] / sec / 1e9, fl.get(dom, 0) / sec / 1e12
             # measured PMC traffic of the same kernel: separate rocprofv3 --pmc passes of an EARLIER run, committed under
             # profiles/ with the hash of the kernel sources they were taken with -- reported only while that still matches
@@ -444,10 +445,11 @@ def run_rank(args):
                         "algorithmic_bytes_per_launch": own[dom],
                         "traffic_over_algorithmic": round(traffic / own[dom], 3) if traffic else None,
                         "mfma_frac": round(tf / peak_tf, 4), "avg_launch_ms": round(core[dom][0], 4),
-                        "launches": core[dom][1],
+                        "launches": core[dom][1], "launches_per_step": core[dom][1] // 5, "stage_ms_per_step": round(core[dom][2], 4),
                         "note": "achieved = SURVEY 8d bytes this launch owns (geometry + gathered rows; no row-sized "
                                 "intermediates) / its HIP-event time; intermediates appear in traffic only",
-                        "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}}
+                        "stages_ms": {t: round(v[2], 4) for t, v in sorted(stages.items())},
+                        "stages_note": "per step: every launch of the stage in one forward + backward of the layer summed (prep runs in both passes)"}
         # what the library says it moves through memory for this shape (3-byte rows / 4-byte words / nothing)
         shp = _lib.Se3Shape(lv0["n"], lv0["n"], lv0["e"], frames, frames, lv0["c"], lv0["c"], W.NUM_BASIS,
                             _lib.PRECISIONS[args.precision])
@@ -636,7 +638,7 @@ def run_rank(args):
                     "neighbourhood_and_transpose_ms": round(ms_n - ms_c, 4),
                     "algorithmic_bytes": ab, "layer_frac": round(ab / (ms_c * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                     "layer_frac_with_neighbourhood": round(ab / (ms_n * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                    "stages_ms": {t: round(v[0], 4) for t, v in sorted(stages.items())}}
+                    "stages_ms": {t: round(v[2], 4) for t, v in sorted(stages.items())}}
             return leg
 
         try:
@@ -696,7 +698,7 @@ def run_rank(args):
                     "rel_err_vs_fp32_mode": dict(zip(names, (float(f"{e:.3g}") for e in err_t16))),
                     "default_mode_rel_err_vs_fp32_mode": dict(zip(names, (float(f"{e:.3g}") for e in err_def))),
                     "worst_rel_err": float(f"{max(err_t16):.3g}"),
-                    "stages_ms": {t: round(v[0], 4) for t, v in sorted(st16.items())},
+                    "stages_ms": {t: round(v[2], 4) for t, v in sorted(st16.items())},
                     "note": "same stack, bf16x3 products, T / U rows as 16-bit mantissas with one exponent per 4 channels (2.25 B per "
                             "element instead of 3); errors = ||x - x_fp32mode|| / ||x_fp32mode|| of the full-size level-0 layer"}
             except RuntimeError as exc:

@@ -30,7 +30,11 @@
  *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32),
  *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower),
  *     SE3_TR_MERGE_SORT (se3_csr_transpose*: the merge-sort form for every graph, same result), SE3_DX_PATH (feature
- *     gradient edge-major: 1 wherever implemented, 0 never; default: where it moves less than half the bytes).
+ *     gradient edge-major: 1 wherever implemented, 0 never; default: where it moves less than half the bytes),
+ *     SE3_SLICE_MB (+ _STREAMS) (row-sliced schedule: every producer -> consumer pair of a row-sized intermediate per
+ *     slice of at most that many MB, consumers on the side stream with SE3_SLICE_STREAMS=2; se3conv_fwd then uses the
+ *     side-stream set of (2) too), SE3_PAIR_OCC (diagnostic: caps the wave-pair edge kernel at 1 - 3 wavefronts per
+ *     SIMD by padding its LDS).  A side-stream set in use by a call is pinned: the cap never hands it to another caller.
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - graph capture: every entry point that takes a stream can be captured into a HIP graph (no host synchronisation,
  *     nothing allocated) except the two-phase se3_ball_query_count / _store pair.  The library issues NO hipMemsetAsync

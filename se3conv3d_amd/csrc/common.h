@@ -381,7 +381,9 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
 int edge_param_grad_bf16_channel_blocks(int channels);
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
-                                float* partials, int n_partials, int* n_used, hipStream_t stream, bool gt16 = false);  // gt16: grad_t rows in the T16 block format
+                                float* partials, int n_partials, int* n_used, hipStream_t stream, bool gt16 = false,  // gt16: grad_t rows in the T16 block format
+                                int64_t row_lo = -1, int64_t row_hi = -1);  // rows row_lo .. row_hi - 1 only (edge_param_grad_bf16_row_ranges)
+bool edge_param_grad_bf16_row_ranges(const EdgeGeom& g, int channels);
 bool edge_param_grad_bf16_t16_rows(const EdgeGeom& g, int channels);
 // edge-major feature gradient of a convolution with many more input than output rows (edge_dx.hip)
 bool edge_dx_bf16_applicable(const EdgeGeom& g, int channels);

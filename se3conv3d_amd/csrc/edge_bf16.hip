@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
                                                              int64_t feat_rows, const float* __restrict__ axes_ext,
                                                              const float* __restrict__ rho_p,
                                                              uint32_t* __restrict__ t_out, int64_t n_items,
-                                                             int fnb_shift) {
+                                                             int fnb_shift, int64_t item_lo) {  // items item_lo .. n_items - 1
   static_assert(!T24 || VW <= 2, "3-byte rows need the two channels of a pair in one lane (edge_bf16_body.h)");
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
   if (threadIdx.x < 64) mlp_weights_to_lds<FC>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
-  const int64_t item = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int64_t item = __builtin_amdgcn_readfirstlane((int)(item_lo + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (item >= n_items) return;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * channels * 4);
   const int row_words = channels * kBasis;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
                                                                          const float* __restrict__ rho_p,
                                                                          const uint32_t* __restrict__ grad_t,
                                                                          float* __restrict__ partials, int64_t n_items,
-                                                                         int fnb_shift) {
+                                                                         int fnb_shift, int64_t item_lo = 0) {
   // Rows wider than 64 channels are covered by blockIdx.y: block row y handles channels 64y .. 64y+63 (gphi, hence
   // d[A;beta], is linear in the channel sum, so every channel block contributes an independent partial; each block
   // row recomputes the descriptors and GELU').  row_ch = channels per row (a multiple of 16).
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
 #endif
   for (int64_t item_f = PAIR ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * NW + wave; item_f < n_items;
        item_f += PAIR ? (int64_t)gridDim.x : (int64_t)gridDim.x * NW) {
-    const int64_t item = SE3_PG_REVERSE ? n_items - 1 - item_f : item_f;
+    const int64_t item = item_lo + (SE3_PG_REVERSE ? n_items - 1 - item_f : item_f);  // items item_lo .. item_lo + n_items - 1
     const int groups = g.f_ctr / NFR;
     // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
     const int64_t ctr = (uint32_t)item / (uint32_t)groups;
@@ -957,8 +957,8 @@ static bool edge_t_bf16_uses_pair(const EdgeGeom& g, int channels) {
   return channels >= 64 && getenv("SE3_NO_PAIR") == nullptr && !(channels == 64 && g.f_ctr % 2 == 1);
 }
 
-// row ranges (producer / consumer interleaving over slices of the rows): the wave-pair kernel only
-bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels) { return edge_t_bf16_uses_pair(g, channels); }
+// row ranges (producer / consumer interleaving over slices of the rows): every form (multiples of the rows per item)
+bool edge_t_bf16_row_ranges(const EdgeGeom& g, int channels) { return true; }
 
 // Which launches can write their rows in the 3-byte format: the wave-pair kernel, and the single-wavefront kernel at one
 // or two channels per lane (rows of up to 32 channels, and the 64-channel rows it takes), where the two channels of a
@@ -1012,8 +1012,18 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     if (n_range <= 0) return SE3_OK;
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
+    // diagnostic knob (profiles/r05_fused_tile_ab.txt): SE3_PAIR_OCC=n caps the kernel at n wavefronts per SIMD by padding
+    // every workgroup's LDS (dynamic shared memory nobody touches) -- what the edge phase of a register-resident fused
+    // tile would run at.  Same results at any n.
+    static const unsigned occ_pad = [] {
+      const char* e = getenv("SE3_PAIR_OCC");
+      const int n = e ? atoi(e) : 0;
+      if (n < 1 || n > 3) return 0u;
+      // 2n workgroups per CU on top of the kernel's 18 KB of static LDS: 64 / 36 / 25 KB per workgroup
+      return n == 1 ? 46u * 1024u : (n == 2 ? 18u * 1024u : 7u * 1024u);
+    }();
 #define SE3_PAIR_T(CT, FULL, NF, P2, TR)                                                                                \
-  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
+  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, occ_pad, stream, g, feat, channels, feat_rows, \
                      axes_ext, rho, t_out, item_lo, item_hi, shift, rowfmt)
 #define SE3_PAIR_L(CT, FULL, NF, P2)                 \
   do {                                               \
@@ -1036,10 +1046,13 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
 #undef SE3_PAIR_T
     return check_launch();
   }
-  const dim3 grid((unsigned)((items + 3) / 4));
+  // row range: items of fc rows each
+  const int64_t s_item_lo = row_lo >= 0 ? row_lo / fc : 0, s_item_hi = row_lo >= 0 ? row_hi / fc : items;
+  if (s_item_hi <= s_item_lo) return SE3_OK;
+  const dim3 grid((unsigned)((s_item_hi - s_item_lo + 3) / 4));
 #define SE3_LAUNCH(VW, FC, FULL, T24)                                                                                 \
   hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL, T24>), grid, block, 0, stream, g, feat, channels, feat_rows,     \
-                     axes_ext, rho, t_out, items, shift)
+                     axes_ext, rho, t_out, s_item_hi, shift, s_item_lo)
 #define SE3_LAUNCH_T(VW, FC, FULL)                   \
   do {                                               \
     if (t24) SE3_LAUNCH(VW, FC, FULL, true);         \
@@ -1068,13 +1081,25 @@ bool edge_param_grad_bf16_t16_rows(const EdgeGeom& g, int channels) {
   return pair_on && getenv("SE3_PG_SINGLE") == nullptr && g.f_ctr % 2 == 0 && channels % 64 == 0 && channels >= 64;
 }
 
+// row ranges (slices of the rows): every form for rows of a multiple of 16 channels
+bool edge_param_grad_bf16_row_ranges(const EdgeGeom& g, int channels) {
+  static const bool pair_on = [] {
+    const char* e = getenv("SE3_PG_PAIR");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  (void)pair_on;
+  return channels % 16 == 0 && channels > 0;  // every MFMA form of the kernel walks an item range
+}
+
 // partials: room for n_partials x edge_param_grad_bf16_channel_blocks(channels) slots of 320 floats; *n_used = slots written
 int edge_param_grad_bf16_channel_blocks(int channels) { return channels > 64 && channels % 16 == 0 ? (channels + 63) / 64 : 1; }
 
 int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat, int channels,
                                 int64_t feat_rows, const float* axes_ext, const float* rho, const uint32_t* grad_t,
-                                float* partials, int n_partials, int* n_used, hipStream_t stream, bool gt16) {
+                                float* partials, int n_partials, int* n_used, hipStream_t stream, bool gt16, int64_t row_lo,
+                                int64_t row_hi) {
   const int64_t rows = g.n_ctr * g.f_ctr;
+  if (row_lo >= 0 && !edge_param_grad_bf16_row_ranges(g, channels)) return SE3_ERR_UNSUPPORTED;
   if (feat_rows * (int64_t)channels * 4 >= (int64_t)kOobOffset) return SE3_ERR_UNSUPPORTED;
   if (gt16 && !edge_param_grad_bf16_t16_rows(g, channels)) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
@@ -1088,6 +1113,13 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
     static const bool force_single = getenv("SE3_PG_SINGLE") != nullptr;
     const bool two = g.f_ctr % 2 == 0 && !force_single;
     const int64_t items = two ? rows / 2 : rows;
+    // row range (slices of the rows, api.hip): items item_lo .. item_lo + n_range - 1 only
+    const int64_t item_lo = row_lo >= 0 ? row_lo / (two ? 2 : 1) : 0;
+    const int64_t n_range = row_lo >= 0 ? row_hi / (two ? 2 : 1) - item_lo : items;
+    if (n_range <= 0) {
+      *n_used = 0;
+      return SE3_OK;
+    }
     const int blocks_y = edge_param_grad_bf16_channel_blocks(channels);
     // pair form (two wavefronts share an item and its grad_T image, 3 wavefronts per SIMD): SE3_PG_PAIR=0 turns it off
     static const bool pair_on = [] {
@@ -1116,28 +1148,28 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       }();
       int64_t wgs = (int64_t)n_cu * per_cu;
       if (wgs > n_partials) wgs = n_partials;
-      if (wgs > items) wgs = items;
+      if (wgs > n_range) wgs = n_range;
       if (wgs < 1) wgs = 1;
       *n_used = (int)wgs * blocks_y;
       const dim3 pgrid((unsigned)wgs, (unsigned)blocks_y);
       if (channels == 32 && shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<2, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
       else if (channels == 32)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<2, 2, true, false>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
       else if (gt16 && shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
       else if (gt16)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, false, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
       else if (shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
       else
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, false>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, items, shift);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
       return check_launch();
     }
     const int n_blocks = n_partials < 512 ? n_partials : 512;  // the 512-thread form: one workgroup per CU and round
@@ -1145,7 +1177,7 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
     const dim3 grid((unsigned)n_blocks, (unsigned)blocks_y);
 #define SE3_PG_L(CH16, NFR, P2, THREADS)                                                                                  \
   hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<CH16, NFR, false, P2>), grid, dim3(THREADS), 0, stream, g, feat, channels, \
-                     feat_rows, axes_ext, rho, grad_t, partials, items, shift)
+                     feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo)
 #define SE3_PG(CH16)                                       \
   do {                                                     \
     if (two && shift >= 0) SE3_PG_L(CH16, 2, true, 512);   \

@@ -492,6 +492,12 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4* __restrict_
 // therefore take the stable merge sort explicitly (keys here are non-negative with zero bits above end_bit, so both
 // orders agree).
 constexpr int kRadixIsMergeLimit = 1 << 20;
+// The guard rests on rocPRIM's dispatch rule (device_radix_sort.hpp: block sort, then merge sort up to
+// radix_sort_config<>::merge_sort_limit for keys wider than 2 bytes, one-sweep above): a rocPRIM whose default limit is
+// lower would send sizes below kRadixIsMergeLimit to the one-sweep sort again -- that build must fail, not fault on a GPU
+// (ADVICE r4).  tests/test_gpu_graph_nodes.py checks the captured graphs themselves for memset nodes.
+static_assert(rocprim::radix_sort_config<>::merge_sort_limit >= (size_t)kRadixIsMergeLimit,
+              "rocPRIM's radix sort leaves its merge-sort form below kRadixIsMergeLimit: lower the constant to its limit");
 struct KeyLess {
   template <class K>
   __device__ __forceinline__ bool operator()(const K& a, const K& b) const { return a < b; }
@@ -499,6 +505,7 @@ struct KeyLess {
 template <class Key>
 hipError_t sort_pairs_no_scratch(void* temp, size_t& temp_bytes, const Key* kin, Key* kout, const int32_t* vin, int32_t* vout,
                                  int n, int begin_bit = 0, int end_bit = (int)sizeof(Key) * 8, hipStream_t stream = nullptr) {
+  static_assert(sizeof(Key) > 2, "rocPRIM sends 1- and 2-byte keys to the one-sweep sort from 100 000 items on");
   if (temp == nullptr) {  // size query: the larger of the two forms
     size_t a = 0, b = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, kin, kout, vin, vout, n, begin_bit, end_bit, stream);
@@ -1140,7 +1147,12 @@ extern "C" int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_row
     return check_launch();
   }
   static const bool force_merge = getenv("SE3_TR_MERGE_SORT") != nullptr;  // A/B and test switch: the fallback form everywhere
-  if (n_src <= 2 * n_edges && !force_merge) {
+  // The counting form ranks every source's segment by itself: up to kTrSegLds entries per segment in registers / LDS, longer
+  // ones from memory at L^2 / 64 steps of ONE wavefront -- fine for the odd long segment, seconds for a list whose segments
+  // are all that long (a coarsest-level up-convolution handed over as a plain list: 1e5 .. 1e6 edges per source).  Lists
+  // averaging more than kTrSegLds / 2 edges per source take the merge-sort form, whose time does not depend on the segment
+  // lengths (the list's LONGEST segment is only known on the device, so the average decides).
+  if (n_src <= 2 * n_edges && n_edges <= (int64_t)(kTrSegLds / 2) * n_src && !force_merge) {
     int32_t* tmp = (int32_t*)(ws + l.tmp);
     int32_t* tmp_ids = (int32_t*)(ws + l.tmp_ids);
     int32_t* cursor = (int32_t*)(ws + l.cursor);

@@ -9,6 +9,9 @@ re-running a slice of the parity suite in a child process with the variable set:
   SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
   SE3_DX_PATH=1     feature gradient edge-major (edge_dx.hip) wherever it is implemented (the default decides by the bytes
                     either form moves -- down-convolutions and sparse levels only -- so the rest of the suite runs the U form)
+  SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2  the row-sliced schedule of round 5 (every producer -> consumer pair per slice of the
+                    rows, consumers on the side stream; 1 MB so that the small shapes of the slice are cut too) -- lost its
+                    A/B at every slice size (profiles/r05_slice_ab.txt) and stays as a switch
 
 (The merged backward kernel, the fused edge + contraction kernel and the chunk-stream kernels of rounds 1-2 lost their A/B
 measurements -- profiles/r02_levels_fused.txt, r02_stream_kernel_ab.txt, r03_merged_backward_and_stash_ab.txt -- and were
@@ -29,11 +32,12 @@ SLICE = "golden or random_shapes or headline_subset or features_only or empty_ro
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("var", ["SE3_NO_PAIR", "SE3_PG_SINGLE", "SE3_PAIR_PERSIST=64", "SE3_NO_T24", "SE3_OVERLAP",
-                                 "SE3_BWD_BRANCH_ORDER", "SE3_DX_PATH=1"])
+                                 "SE3_BWD_BRANCH_ORDER", "SE3_DX_PATH=1", "SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2"])
 def test_variant_passes_parity_slice(var):
     env = dict(os.environ)
-    name, _, value = var.partition("=")
-    env[name] = value or "1"
+    for part in var.split(","):
+        name, _, value = part.partition("=")
+        env[name] = value or "1"
     proc = subprocess.run(
         [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
          "-k", SLICE, "-p", "no:cacheprovider"],
