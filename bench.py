@@ -508,6 +508,37 @@ def run_rank(args):
         result["eager"] = {"ms_per_step": round(ms_eager, 4), "value": mpts(ms_eager),
                            "note": "same step launched from Python every iteration (no graph replay)"}
 
+        # The same step with its four levels on four streams inside ONE captured graph (fork at the start, join at the end).
+        # The stack's levels do not feed each other in this benchmark, so this is legal here -- and it is NOT `value`: in the
+        # reference's encoder consecutive convolutions are dependent.  What it shows is what independent convolutions gain
+        # from a scheduler that overlaps them (the three lateral convolutions of FPNDecoder.py:118-131 are independent, so are
+        # the parameter-gradient branches of any two layers): the small levels' launch latencies hide under level 0.
+        mark("levels_concurrent")
+        lv_streams = [torch.cuda.Stream() for _ in levels[1:]]
+
+        def step_levels_concurrent(lvls):
+            cur = torch.cuda.current_stream()
+            for st in lv_streams:
+                st.wait_stream(cur)
+            for lv, st in zip(lvls[1:], lv_streams):
+                with torch.cuda.stream(st):
+                    step([lv])
+            step(lvls[:1])
+            for st in lv_streams:
+                cur.wait_stream(st)
+
+        try:
+            if args.no_extra:
+                raise RuntimeError("skipped (--no-extra)")
+            run_cc = (lambda: step_levels_concurrent(levels)) if args.no_graph else GraphedStep(levels, fn=step_levels_concurrent)
+            ms_cc = timed(run_cc, args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
+            result["levels_concurrent"] = {"ms_per_step": round(ms_cc, 4), "value": mpts(ms_cc), "unit": "Mpoints/s",
+                                           "note": "NOT the headline: the four (mutually independent) levels of the step on four streams "
+                                                   "of one captured graph; what a scheduler gains on independent convolutions"}
+        except RuntimeError as exc:
+            result["levels_concurrent"] = {"error": str(exc)[:200]}
+            torch.cuda.synchronize()
+
         mark("forward_only")
         # inference: the forward pass of the same stack alone (eval mode, no autograd graph, T in the workspace)
         def forward_only(lvls):

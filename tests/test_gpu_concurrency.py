@@ -211,3 +211,48 @@ def test_tensors_on_another_device_are_refused(amd):
 
     with pytest.raises(ValueError, match="current device"):
         ops._stream(torch.device("cuda", torch.cuda.current_device() + 1))
+
+
+def test_more_concurrent_backward_calls_than_the_cap(amd):
+    """with more caller streams in flight than the 16-owner cap, the eviction must never hand a side-stream set
+    that is between its fork and its join to another caller (both calls would record and wait on the same events, and one
+    call's side-branch kernels could start before its own preparation had finished: silently wrong gradients).  20 threads,
+    each on a stream of its own, run backward at the same time, several rounds; every result equals the serial one bit for bit."""
+    import threading
+
+    n_threads = 20
+    cases = [_case(amd, 20 + (i % 4), n=5000) for i in range(4)]   # 10 000 output rows: backward forks
+    refs = [_fwd_bwd(c) for c in cases]
+    torch.cuda.synchronize()
+    # one set of tensors per thread (shared clouds / neighbourhoods / parameters are read-only; grads are per thread)
+    work = []
+    for i in range(n_threads):
+        c = cases[i % 4]
+        conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(64, 64).to(DEV)
+        conv.load_state_dict(c["conv"].state_dict())
+        work.append(dict(pc=c["pc"], nbh=c["nbh"], conv=conv, x=c["x"].detach().clone().requires_grad_(True), g=c["g"]))
+    got, errs = [None] * n_threads, []
+    start = threading.Barrier(n_threads)
+
+    def run(i):
+        try:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            start.wait()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    got[i] = _fwd_bwd(work[i])
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(n_threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(n_threads):
+        for u, v in zip(got[i], refs[i % 4]):
+            assert torch.equal(u, v), f"thread {i}"
+    assert _side_stats_all()[0] <= 16 + n_threads  # owners never shrink below what is pinned; nothing leaked beyond the threads
