@@ -516,16 +516,34 @@ def run_rank(args):
         mark("levels_concurrent")
         lv_streams = [torch.cuda.Stream() for _ in levels[1:]]
 
+        from se3conv3d_amd import layers as _layers, ops as _ops
+
+        def raw_step(lv):
+            """forward + backward of one level through the raw operator calls (no autograd engine: its worker thread and a
+            multi-stream capture do not mix on this runtime -- the module-level step on side streams made capture_end crash)"""
+            conv = lv["conv"]
+            geom = _layers._geometry_of(lv["pc"], lv["pc"], lv["nbh"])
+            with torch.no_grad():
+                out, t_save = _ops.se3conv_forward(geom, lv["x"], conv.proj_axes_, conv.proj_biases_, conv.conv_weights_,
+                                                   conv.norm_neigh_dist_, conv.norm_num_neighs_, save_t=True)
+                return _ops.se3conv_backward(geom, lv["x"], conv.proj_axes_, conv.proj_biases_, conv.conv_weights_,
+                                             conv.norm_neigh_dist_, conv.norm_num_neighs_, t_save, lv["g"])
+
         def step_levels_concurrent(lvls):
             cur = torch.cuda.current_stream()
             for st in lv_streams:
                 st.wait_stream(cur)
+            keep = []
             for lv, st in zip(lvls[1:], lv_streams):
                 with torch.cuda.stream(st):
-                    step([lv])
-            step(lvls[:1])
+                    keep.append(raw_step(lv))
+            keep.append(raw_step(lvls[0]))
             for st in lv_streams:
                 cur.wait_stream(st)
+            for outs in keep:  # results produced on a side stream are used (and freed) on the launch stream
+                for t in outs:
+                    if t is not None:
+                        t.record_stream(cur)
 
         try:
             if args.no_extra:

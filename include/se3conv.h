@@ -17,7 +17,10 @@
  *   - re-entrant: calls on different streams (or from different threads) share no events, streams
  *     or buffers.  Process-wide state, all of it listed here: (1) the profiling switch below;
  *     (2) se3conv_bwd keeps one internal side stream + fork/join event pair per (device, caller
- *     stream) it has been called on, for running its two branches side by side on mid-sized levels --
+ *     stream) it has been called on, for running its two branches side by side -- OPT-IN since round 5
+ *     (SE3_OVERLAP / SE3_OVERLAP_ROWS / se3_set_overlap_rows: with the kernels as they are the fork loses at every size,
+ *     and a fork from a stream that is itself a forked branch of a graph capture crashes this HIP runtime's
+ *     hipStreamEndCapture, see se3_set_overlap_rows) --
  *     the side stream is always joined back into `stream` before the call returns, on error paths too.
  *     These objects are only ever created by a call whose stream is NOT being captured into a HIP graph:
  *     every eager se3conv_fwd / se3conv_bwd keeps two spare sets per device ready, a capturing stream that
@@ -34,7 +37,7 @@
  *     SE3_SLICE_MB (+ _STREAMS) (row-sliced schedule: every producer -> consumer pair of a row-sized intermediate per
  *     slice of at most that many MB, consumers on the side stream with SE3_SLICE_STREAMS=2; se3conv_fwd then uses the
  *     side-stream set of (2) too), SE3_PAIR_OCC (diagnostic: caps the wave-pair edge kernel at 1 - 3 wavefronts per
- *     SIMD by padding its LDS).  A side-stream set in use by a call is pinned: the cap never hands it to another caller.
+ *     SIMD by padding its LDS), SE3_NN_KG (=1: the dense products over 3-byte rows never use their two-k-group form).  A side-stream set in use by a call is pinned: the cap never hands it to another caller.
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - graph capture: every entry point that takes a stream can be captured into a HIP graph (no host synchronisation,
  *     nothing allocated) except the two-phase se3_ball_query_count / _store pair.  The library issues NO hipMemsetAsync
@@ -115,7 +118,8 @@ typedef struct se3conv_shape {
  * against (se3conv3d_amd/_lib.py does). */
 /* 3 = round 4: se3_side_stream_stats fills FIVE counters (was three); SE3_PRECISION_BF16X3_T16 and
  * se3conv_intermediate_row_bytes added. */
-/* 4 = round 4: se3_csr_transpose / _bounded and se3conv_bwd take `t_edge_ids` (optional). */
+/* 4 = round 4: se3_csr_transpose / _bounded and se3conv_bwd take `t_edge_ids` (optional).
+ * (round 5 added se3_set_overlap_rows; no signature changed.) */
 #define SE3_ABI_VERSION 4
 int se3_abi_version(void);
 const char* se3_error_string(int code);
@@ -258,8 +262,10 @@ int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int
 
 /* Source-major (transposed) copy of an edge list, used by the backward pass in place of the
  * reference's global float atomics on the feature gradient (feat_basis_proj_grads.cu:126,140):
- * t_samples[E] = sample id of every edge, grouped by source point (ascending sample inside a
- * group), t_ends[n_src] = inclusive end offsets. */
+ * t_samples[E] = sample id of every edge, grouped by source point, t_ends[n_src] = inclusive end
+ * offsets.  se3_csr_transpose* returns every group in ascending sample order; se3conv_bwd does not
+ * rely on any order INSIDE a group (a caller may pass a list grouped by source in any order -- the
+ * Python drop-in builds long-segment lists as a second ball query with the clouds' roles swapped). */
 size_t se3_csr_transpose_workspace_bytes(int64_t n_edges);
 /* `t_edge_ids` (optional, may be NULL; ABI 4): [E] the position of every entry in the sample-major list -- entry j of the
  * result is row t_edge_ids[j] of `neighbors`.  se3conv_bwd's edge-major feature gradient (a convolution with many more
@@ -271,7 +277,10 @@ int se3_csr_transpose(const int32_t* neighbors, int64_t n_edges, int64_t n_src, 
  * unset tail is ignored (it sorts behind every group and no offset reaches it), t_samples [n_rows], t_ends [n_src].
  * Workspace: se3_csr_transpose_workspace_bytes(n_rows).  No host synchronisation.  If the buffer overflowed
  * (info[1] != 0) the forward list is truncated and so is its transpose: outputs and gradients then belong to the
- * truncated graph, consistently -- rebuild with a larger buffer. */
+ * truncated graph, consistently -- rebuild with a larger buffer.  (That consistency holds for THIS call.  A source-major
+ * list obtained any other way from an overflowed buffer -- the role-swapped second query of the Python drop-in, which
+ * truncates in source-major order -- is a different sub-graph: after an overflow the gradients are not those of the
+ * forward pass and the step must be redone, which the overflow flag is there to tell.) */
 int se3_csr_transpose_bounded(const int32_t* neighbors, int64_t n_rows, const int32_t* n_valid, int64_t n_src,
                               void* workspace, size_t workspace_bytes, int32_t* t_samples, int32_t* t_ends, int32_t* t_edge_ids,
                               void* stream);
@@ -465,6 +474,13 @@ int se3_profile_enable(int on);
  * branches back to back -- correct, slower on 4 k - 32 k-row levels), [4] sets the 16-owner cap handed back to the
  * spares.  Sets are only created by calls whose stream is NOT being captured. */
 int se3_side_stream_stats(int32_t* stats);
+/* Process-wide switch of state (2): se3conv_bwd runs its feature branch on the internal side stream for layers of at most
+ * `rows` output rows (and more than 4096; every size from 2^40 on).  0 = never (the default since round 5), < 0 = back to the
+ * environment (SE3_OVERLAP=1 / SE3_OVERLAP_ROWS=n, read once).  Measured on MI355X the fork costs 0.4 - 2.3 % of a step on
+ * every workload (profiles/r05_no_fork_ab.txt).  Do NOT turn it on for calls made on a stream that is itself a forked
+ * branch of a graph capture: a fork from a forked stream makes hipStreamEndCapture segfault on the HIP runtime PyTorch
+ * 2.10+rocm7.0 ships (tools/probes/nested_fork_capture.py reproduces it with torch streams and events alone). */
+int se3_set_overlap_rows(int64_t rows);
 int se3_profile_reset(void);
 int se3_profile_read(const char* tag, double* total_ms, int64_t* launches);
 int se3_profile_tags(char* buf, size_t len);

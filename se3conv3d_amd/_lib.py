@@ -88,6 +88,7 @@ SIGNATURES = {
     "se3_linear_wgrad_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
     "se3_linear_wgrad": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _SZ, _P]),
     "se3_side_stream_stats": (C.c_int, [_P]),
+    "se3_set_overlap_rows": (C.c_int, [C.c_int64]),
     "se3_profile_enable": (C.c_int, [C.c_int]),
     "se3_profile_reset": (C.c_int, []),
     "se3_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

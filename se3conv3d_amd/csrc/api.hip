@@ -1,4 +1,5 @@
 // extern "C" entry points of the fused operator + the API-parity ops (see include/se3conv.h).
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -395,12 +396,27 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
 }
 
 // Second stream for the backward pass: the parameter branch (grad_T GEMM -> edge_param_grad, weight-gradient GEMM)
-// and the feature branch (transposed edge kernel -> grad_X GEMM) are independent.  Measured on MI355X at the headline
-// shape: the kernels slow each other down more than in proportion (2.15 ms side by side vs 2.07 back to back), so
-// it is used for mid-sized levels only (kOverlapRows; SE3_OVERLAP=1 forces it, SE3_OVERLAP_ROWS=n moves the limit).
-// backward branches on two streams for this range of output rows: above it every kernel fills the chip by itself
-// (measured: 2.15 vs 2.07 ms at 131 k rows), below it the fork / join costs more than the overlap returns
-constexpr int kOverlapRows = 32768, kOverlapMinRows = 4096;
+// and the feature branch (transposed edge kernel -> grad_X GEMM) are independent.  OFF by default since round 5: measured
+// on MI355X with the kernels as they are now (writers first, non-temporal producer stores), the fork loses at every size --
+// headline stack 2.437 -> 2.405 ms without it (its 18 k-row level 0.341 -> 0.330), dfaust_f2 1.918 -> 1.873, dfaust_f4
+// 6.97 -> 6.93, scannet150k_f1 2.572 -> 2.561 (profiles/r05_no_fork_ab.txt; at 131 k rows it always lost: 2.15 vs 2.07 ms
+// in round 1).  It also keeps the library out of a hazard of this HIP runtime: a fork FROM A FORKED STREAM inside a graph
+// capture segfaults in hipStreamEndCapture (tools/probes/nested_fork_capture.py: torch streams and events alone do it), which
+// is what a caller who captures the library on a side stream of its own would have triggered.  SE3_OVERLAP=1 (every size) /
+// SE3_OVERLAP_ROWS=n (up to n output rows) / se3_set_overlap_rows(n) turn it on; levels of fewer than kOverlapMinRows rows
+// fork only when the limit was raised explicitly.
+constexpr int kOverlapRows = 0, kOverlapMinRows = 4096;
+std::atomic<int64_t> g_overlap_rows{-1};  // se3_set_overlap_rows: >= 0 overrides the environment
+int64_t overlap_rows_limit() {
+  const int64_t v = g_overlap_rows.load(std::memory_order_relaxed);
+  if (v >= 0) return v;
+  static const int64_t env = [] {
+    if (getenv("SE3_OVERLAP") != nullptr) return (int64_t)1 << 62;
+    const char* e = getenv("SE3_OVERLAP_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)kOverlapRows;
+  }();
+  return env;
+}
 // One side stream + fork / join event pair per (device, caller stream), kept for the life of the process: two backward
 // calls on two caller streams (or threads) never share events or a stream, and a caller stream on device 1 never gets a
 // side stream of device 0.  Two calls racing on the SAME caller stream are the caller's race anyway.  The table only
@@ -1232,14 +1248,10 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     hipStream_t fs = stream;
     uint32_t* ubuf = bigw;
     float* fsplit = (float*)(ws + l.split);
-    // small levels cannot fill the chip with one kernel at a time: their two branches run side by side
-    static const int64_t overlap_rows = [] {
-      if (getenv("SE3_OVERLAP") != nullptr) return (int64_t)1 << 62;
-      const char* e = getenv("SE3_OVERLAP_ROWS");
-      return e ? (int64_t)atoll(e) : (int64_t)kOverlapRows;
-    }();
+    // opt-in (see kOverlapRows): the two branches side by side
+    const int64_t overlap_rows = overlap_rows_limit();
     SideStream side;
-    if (want_params && l.big_u != 0 && rows_out <= overlap_rows && (rows_out > kOverlapMinRows || overlap_rows > kOverlapRows) &&
+    if (want_params && l.big_u != 0 && rows_out <= overlap_rows && (rows_out > kOverlapMinRows || overlap_rows >= ((int64_t)1 << 40)) &&
         (side = side_stream_for(stream)).ok) {
       if (int rc = fj.fork(side, stream)) return rc;
       fs = side.stream;
@@ -1348,6 +1360,11 @@ extern "C" int se3_side_stream_stats(int32_t* stats) {
   stats[2] = t.created;
   stats[3] = t.unforked_in_capture;
   stats[4] = t.evicted;
+  return SE3_OK;
+}
+
+extern "C" int se3_set_overlap_rows(int64_t rows) {
+  se3::g_overlap_rows.store(rows < 0 ? -1 : rows, std::memory_order_relaxed);
   return SE3_OK;
 }
 

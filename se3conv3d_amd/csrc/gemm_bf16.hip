@@ -232,8 +232,13 @@ __global__ __launch_bounds__(256) void gemm_nn_bf16_kernel(const uint32_t* __res
 // (256-row workgroups -- 8 wavefronts, the weight planes fetched from L2 half as often -- were measured in round 3:
 // nothing at the headline shape, 15 % slower on a 150 k-row scene whose 586 workgroups no longer divide into full rounds:
 // profiles/r03_gemm_256row_ab.txt.)
-template <int OUT_MODE, int NB>
-__global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restrict__ a,
+// KG = k groups per workgroup (round 5): 1 -- four wavefronts walk the workgroup's super tiles -- or 2 -- eight wavefronts,
+// group g walks half of them with LDS tiles of its own and the two partial tiles are added through LDS at the end.  For
+// products whose row blocks cannot fill the chip (levels of 4 k - 40 k rows: fewer workgroups than CUs x 2): a workgroup
+// alone on its CU is bound by its own chain of loads, barriers and MFMAs (~0.75 us per 32-k tile whatever is in flight), so
+// two chains side by side halve its time without the partial-sum round trip and the reduction launch a split over grid.z costs.
+template <int OUT_MODE, int NB, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_nn_t24_kernel(const uint8_t* __restrict__ a,
                                                           const uint16_t* __restrict__ bt_hi,
                                                           const uint16_t* __restrict__ bt_lo, void* __restrict__ c,
                                                           int64_t m, int n, int k, int st_per_split,
@@ -244,16 +249,23 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
   constexpr int RPL = 64;          // rows one load pass of the lo plane covers (4 threads per row): 2 passes = RB rows
   constexpr int CP = 32;           // weight columns one load pass covers: 2 * NB passes per plane
   constexpr int NBP = 2 * NB;
-  __shared__ __attribute__((aligned(16))) uint16_t ash[2][RB][BK + 8];   // 80-byte pitch
-  __shared__ __attribute__((aligned(16))) uint8_t asl[2][RB][BK + 16];   // 48-byte pitch
-  __shared__ __attribute__((aligned(16))) uint16_t bsh[2][BNW][B_LD];
-  __shared__ __attribute__((aligned(16))) uint16_t bsl[2][BNW][B_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // one block of LDS, carved: per k group the four tile images; the partial tile of group 1 reuses group 0's images at the end
+  constexpr int kAsh = 2 * RB * (BK + 8) * 2, kAsl = 2 * RB * (BK + 16), kBs = 2 * BNW * B_LD * 2;
+  constexpr int kGroup = kAsh + kAsl + 2 * kBs;
+  static_assert(KG == 1 || RB * BNW * 4 <= kGroup, "the partial tile must fit the tile images it reuses");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // KG * kGroup bytes (gemm_nn_t24_lds_bytes): 52 / 104 / 72 / 144 KB
+  const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+  auto ash = reinterpret_cast<uint16_t(*)[RB][BK + 8]>(smem + grp * kGroup);                    // [2][RB][BK + 8], 80-byte pitch
+  auto asl = reinterpret_cast<uint8_t(*)[RB][BK + 16]>(smem + grp * kGroup + kAsh);             // [2][RB][BK + 16], 48-byte pitch
+  auto bsh = reinterpret_cast<uint16_t(*)[BNW][B_LD]>(smem + grp * kGroup + kAsh + kAsl);       // [2][BNW][B_LD]
+  auto bsl = reinterpret_cast<uint16_t(*)[BNW][B_LD]>(smem + grp * kGroup + kAsh + kAsl + kBs);
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // thread / wavefront inside the k group
   const int rl = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * RB;
   const int n0 = blockIdx.y * BNW;
-  const int st_begin = blockIdx.z * st_per_split;
-  const int ns = min(k / 64 - st_begin, st_per_split);  // super tiles of this block (> 0 by construction)
+  const int ns_wg = min(k / 64 - (int)blockIdx.z * st_per_split, st_per_split);  // super tiles of this workgroup (> 0 by construction)
+  const int ns = KG == 1 ? ns_wg : ns_wg / 2;                                    // ... of this k group (the host keeps ns_wg even)
+  const int st_begin = blockIdx.z * st_per_split + grp * ns;
 
   struct Super { u32x4 ah[4], al[2], bh[NBP], bl[NBP]; };
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -323,7 +335,8 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
   };
   // Two super tiles in registers (= the 4 k-tiles in flight of the kernel above).  Step A computes the first half
   // while the second goes to LDS buffer 1; step B computes the second half, stores the next super tile's first half
-  // to buffer 0 and refills the register set that just emptied.
+  // to buffer 0 and refills the register set that just emptied.  (KG = 2: both k groups run the same number of steps, so
+  // the workgroup barriers line up.)
   Super t0, t1;
   load_super(t0, 0);
   if (ns > 1) load_super(t1, 1);
@@ -359,6 +372,23 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
 #undef SE3_T24_STEP
 #undef SE3_T24_STEP_FULL
 
+  if constexpr (KG == 2) {
+    // group 1's partial tile -> LDS (over the tile images, which nobody reads any more: the loop ended on a barrier),
+    // group 0 adds it to its own.  [row][column] floats, column fastest: conflict-free both ways.
+    float* red = reinterpret_cast<float*>(smem);
+    if (grp == 1) {
+#pragma unroll
+      for (int ct = 0; ct < 2 * NB; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + acc_row(r, h)) * BNW + 32 * ct + rl] = acc[ct][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int ct = 0; ct < 2 * NB; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] += red[(wave * 32 + acc_row(r, h)) * BNW + 32 * ct + rl];
+  }
   const float alpha = OUT_MODE == 2 ? 1.0f : (alpha_num ? *alpha_num : 1.0f) * alpha_scale;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -377,6 +407,10 @@ __global__ __launch_bounds__(256) void gemm_nn_t24_kernel(const uint8_t* __restr
       }
     }
   }
+}
+
+constexpr int gemm_nn_t24_lds_bytes(int nb, int kg) {
+  return kg * (2 * BM * (BK + 8) * 2 + 2 * BM * (BK + 16) + 2 * (2 * BN * nb * B_LD * 2));
 }
 
 // NN GEMM over A rows in the 2.25-byte block format (common.h, T16; k a multiple of 256 = one mega tile of the exponent
@@ -1121,16 +1155,29 @@ int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, u
 // short-k, wide-n products (grad_T beyond the strip kernel's k <= 64) the narrow tile keeps more blocks in flight
 int gemm_nn_bf16_col_blocks(int n, int k) { return n > BN && k >= 512 ? 2 : 1; }
 
-int gemm_nn_bf16_splits(int64_t m, int n, int k) {
+// k groups per workgroup of the 3-byte-row kernel (gemm_nn_t24_kernel, KG): two when the output tiles alone leave the chip
+// under-filled and the super tiles of a workgroup divide evenly.  SE3_NN_KG=1 turns the form off (A/B switch).
+int gemm_nn_t24_k_groups(int64_t m, int n, int k) {
+  static const int forced = [] {
+    const char* e = getenv("SE3_NN_KG");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1 || k % 128 != 0) return 1;
+  const int bnw = BN * gemm_nn_bf16_col_blocks(n, k);
+  const int64_t tiles = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
+  return tiles > 0 && tiles <= 384 ? 2 : 1;  // beyond 1.5 workgroups per CU the plain form covers its own latencies
+}
+
+int gemm_nn_bf16_splits(int64_t m, int n, int k, int kg) {
   const int bnw = BN * gemm_nn_bf16_col_blocks(n, k);
   const int64_t tiles = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
   const int nkt = (k + BK - 1) / BK;
-  constexpr int target = 512;  // workgroups aimed at (two per CU); 1024 and 256 measured slower on the 9 k-point level
+  const int target = 512 / kg;  // workgroups aimed at (two per CU; one of eight wavefronts); 1024 and 256 measured slower on the 9 k-point level
   if (tiles < 1 || tiles >= target / 2 || nkt < 8) return 1;  // (tiles = 0: an empty cloud)
   // at most `target` workgroups (one more split than fits starts a second, nearly empty round: 144 tiles x 4 splits =
   // 576 on 512 slots took as long as two full rounds), at least 4 k-tiles per split
   int64_t s_max = target / tiles;
-  if (s_max > nkt / 4) s_max = nkt / 4;
+  if (s_max > nkt / (4 * kg)) s_max = nkt / (4 * kg);
   if (s_max < 1) s_max = 1;
   static const int forced = [] {  // A/B knob: SE3_NN_SPLITS=n forces the split count (clamped to what the shape allows)
     const char* e = getenv("SE3_NN_SPLITS");
@@ -1153,7 +1200,7 @@ int gemm_nn_bf16_splits(int64_t m, int n, int k) {
     const int per = (int)((nkt + s - 1) / s);
     const int s_eff = (nkt + per - 1) / per;
     const double fill = (double)(tiles * s_eff) / (double)target;
-    const double t_loop = per * t_tile, t_stream = a_bytes / (rate * (fill < 1.0 ? fill : 1.0));
+    const double t_loop = per * t_tile / kg, t_stream = a_bytes / (rate * (fill < 1.0 ? fill : 1.0));
     const double cost = (t_loop > t_stream ? t_loop : t_stream) + (s_eff > 1 ? 12.0 + s_eff * out_bytes * 0.5e-6 : 0.0);
     if (cost < best_cost) best_cost = cost, best = s_eff;
   }
@@ -1213,7 +1260,8 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
   const bool a24 = afmt == 1, a16 = afmt == 2;  // A rows: 0 packed words, 1 3-byte rows, 2 T16 (common.h)
   const int kp = (k + 31) / 32 * 32;
   const int nkt = kp / BK;
-  int splits = split_ws ? gemm_nn_bf16_splits(m, n, k) : 1;
+  const int kg = a24 ? gemm_nn_t24_k_groups(m, n, k) : 1;
+  int splits = split_ws ? gemm_nn_bf16_splits(m, n, k, kg) : 1;
   const int per = (nkt + splits - 1) / splits;
   splits = (nkt + per - 1) / per;
   const int nbw = gemm_nn_bf16_col_blocks(n, k);
@@ -1226,14 +1274,28 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
     return SE3_ERR_UNSUPPORTED;
   int st_per = (per + 1) / 2;  // 3-byte / T16 rows: the kernels walk super tiles of 64 k
   if (a16) st_per = (st_per + 3) / 4 * 4;  // whole mega tiles per split
+  if (kg == 2) st_per = (st_per + 1) / 2 * 2;  // two k groups: an even number of super tiles per workgroup (k % 128 == 0)
   if (a24 || a16) splits = (k / 64 + st_per - 1) / st_per;
   const dim3 grid24((unsigned)((m + BM - 1) / BM), grid.y, (unsigned)splits);
 #define SE3_NN_LAUNCH(MODE, F, NBV, OUT)                                                                              \
   hipLaunchKernelGGL((gemm_nn_bf16_kernel<MODE, F, NBV>), grid, dim3(256), 0, stream, a, bt_hi, bt_lo, (void*)(OUT), m, n, \
                      k, kp, per, alpha_num, alpha_scale)
-#define SE3_NN_LAUNCH24(MODE, NBV, OUT)                                                                               \
-  hipLaunchKernelGGL((gemm_nn_t24_kernel<MODE, NBV>), grid24, dim3(256), 0, stream, (const uint8_t*)a, bt_hi, bt_lo,   \
-                     (void*)(OUT), m, n, k, st_per, alpha_num, alpha_scale)
+#define SE3_NN_LAUNCH24_KG(MODE, NBV, KGV, OUT)                                                                       \
+  do {                                                                                                                \
+    constexpr int lds_bytes = gemm_nn_t24_lds_bytes(NBV, KGV);                                                         \
+    if (lds_bytes > 64 * 1024) {  /* beyond the default dynamic-LDS limit: raise it once per instantiation */           \
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nn_t24_kernel<MODE, NBV, KGV>), \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);     \
+      if (attr != hipSuccess) return SE3_ERR_LAUNCH;                                                                   \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((gemm_nn_t24_kernel<MODE, NBV, KGV>), grid24, dim3(256 * KGV), lds_bytes, stream, (const uint8_t*)a, \
+                       bt_hi, bt_lo, (void*)(OUT), m, n, k, st_per, alpha_num, alpha_scale);                          \
+  } while (0)
+#define SE3_NN_LAUNCH24(MODE, NBV, OUT)                    \
+  do {                                                     \
+    if (kg == 2) SE3_NN_LAUNCH24_KG(MODE, NBV, 2, OUT);    \
+    else SE3_NN_LAUNCH24_KG(MODE, NBV, 1, OUT);            \
+  } while (0)
 #define SE3_NN_LAUNCH16(MODE, NBV, OUT)                                                                               \
   hipLaunchKernelGGL((gemm_nn_t16_kernel<MODE, NBV>), grid24, dim3(256), 0, stream, (const uint8_t*)a, bt_hi, bt_lo,   \
                      (void*)(OUT), m, n, k, st_per, alpha_num, alpha_scale)
@@ -1268,6 +1330,7 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
 #undef SE3_NN
 #undef SE3_NN_LAUNCH
 #undef SE3_NN_LAUNCH24
+#undef SE3_NN_LAUNCH24_KG
 #undef SE3_NN_LAUNCH16
   return check_launch();
 }
@@ -1295,7 +1358,9 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
 }
 
 size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k) {
-  const int s = gemm_nn_bf16_splits(m, n, k);
+  // the caller does not know the row format yet: room for whichever form (one or two k groups) splits further
+  const int s1 = gemm_nn_bf16_splits(m, n, k, 1), s2 = gemm_nn_bf16_splits(m, n, k, gemm_nn_t24_k_groups(m, n, k));
+  const int s = s1 > s2 ? s1 : s2;  // (rounding the super tiles per split up to an even count can only remove a split)
   return s > 1 ? (size_t)s * m * n * 4 : 0;
 }
 

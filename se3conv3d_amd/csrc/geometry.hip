@@ -960,7 +960,7 @@ extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst
 // transposition used until then -- the captured level 1 -> 0 convolution next to a live communicator faulted in 7 of 7
 // runs, at the first replay behind the first barrier; the same graph with a merge sort (no memset) was clean, a counting
 // form with two hipMemsetAsync faulted again, the same form zeroing its arrays by a kernel is clean
-// (tools/debug_up_graph.py, tools/r04_fault_bisect.sh).  The one-sweep kernels also use scratch
+// (tools/debug_up_graph.py, tools/fault_bisect_memset.sh).  The one-sweep kernels also use scratch
 // memory (80 bytes per lane), the only kernels of this file that do; sorts stay on scratch-free forms too.
 // The list arrives grouped by sample in ascending sample order and a sample lists a source at most once, so "stable sort
 // by source" = per source the ascending list of its samples: count per source (atomics), inclusive scan, scatter into

@@ -305,7 +305,10 @@ class BQNeighborhood(Neighborhood):
         SECOND ball query with the clouds' roles swapped: ``||(s - p) / r|| < 1`` is bit for bit the same predicate both
         ways, so it finds exactly the same edges, grouped by source, in an order that depends on the points only
         (deterministic; not ascending in the sample id, which no consumer needs).  Capacity-bounded like the forward list
-        (same row count), no host synchronisation: capturable."""
+        (same row count, hence the same overflow flag: both queries find the same E edges), no host synchronisation:
+        capturable.  After an overflow the two lists are truncated differently (sample-major / source-major order), i.e.
+        backward would differentiate another sub-graph than forward ran on: ``overflowed()`` must be checked and the step
+        redone with a larger buffer -- as for any overflowed neighbourhood (include/se3conv.h, se3_csr_transpose_bounded)."""
         if self.symmetric_ or self.max_neighbors_ != 0 or getattr(self, "neighbors_i32_", None) is None:
             return None
         n_src, n_smp = self.pc_src_.pts_.shape[0], self.samples_.pts_.shape[0]

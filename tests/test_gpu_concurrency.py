@@ -14,9 +14,15 @@ DEV = "cuda:0"
 
 @pytest.fixture(scope="module")
 def amd(built_library):
+    """The two-stream backward pass is opt-in since round 5 (it lost its A/B at every size): this module, which tests the
+    side-stream machinery, turns it on for layers of up to 32 k output rows and restores the default afterwards."""
     import se3conv3d_amd as amd
+    from se3conv3d_amd import _lib
+
     amd.set_precision("bf16x3")
-    return amd
+    _lib.load().se3_set_overlap_rows(32768)
+    yield amd
+    _lib.load().se3_set_overlap_rows(-1)
 
 
 def _case(amd, seed, n=5000, f=2, c=64):
@@ -165,6 +171,8 @@ sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
 import se3conv3d_amd as amd
 import test_gpu_concurrency as T
 amd.set_precision("bf16x3")
+from se3conv3d_amd import _lib
+_lib.load().se3_set_overlap_rows(32768)   # the two-stream backward pass is opt-in
 # geometry, neighbourhood and parameters are built eagerly (they are inputs); the operator itself first runs captured
 c = T._case(amd, 7)
 assert T._side_stats() == [0, 0, 0]

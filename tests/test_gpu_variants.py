@@ -5,7 +5,8 @@ re-running a slice of the parity suite in a child process with the variable set:
   SE3_PG_SINGLE=1   one row per wavefront in the parameter-gradient kernel (what odd frame counts use)
   SE3_PAIR_PERSIST=n  wave-pair edge kernel with n persistent workgroups walking strided items
   SE3_NO_T24=1      T and U as packed hi/lo words instead of the 3-byte row format (what C < 64 always uses)
-  SE3_OVERLAP=1     backward branches on two streams at every size (default: 4 k - 32 k output rows only)
+  SE3_OVERLAP=1     backward branches on two streams at every size (default since round 5: never -- the fork lost its A/B,
+                    profiles/r05_no_fork_ab.txt)
   SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
   SE3_DX_PATH=1     feature gradient edge-major (edge_dx.hip) wherever it is implemented (the default decides by the bytes
                     either form moves -- down-convolutions and sparse levels only -- so the rest of the suite runs the U form)
