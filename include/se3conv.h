@@ -37,7 +37,7 @@
  *     SE3_SLICE_MB (+ _STREAMS) (row-sliced schedule: every producer -> consumer pair of a row-sized intermediate per
  *     slice of at most that many MB, consumers on the side stream with SE3_SLICE_STREAMS=2; se3conv_fwd then uses the
  *     side-stream set of (2) too), SE3_PAIR_OCC (diagnostic: caps the wave-pair edge kernel at 1 - 3 wavefronts per
- *     SIMD by padding its LDS), SE3_NN_KG (=1: the dense products over 3-byte rows never use their two-k-group form).  A side-stream set in use by a call is pinned: the cap never hands it to another caller.
+ *     SIMD by padding its LDS), SE3_NN_KG (=2: the dense products over 3-byte rows of under-filled levels run two k groups per workgroup; lost its A/B).  A side-stream set in use by a call is pinned: the cap never hands it to another caller.
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - graph capture: every entry point that takes a stream can be captured into a HIP graph (no host synchronisation,
  *     nothing allocated) except the two-phase se3_ball_query_count / _store pair.  The library issues NO hipMemsetAsync

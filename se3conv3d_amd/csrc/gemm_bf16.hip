@@ -1155,14 +1155,17 @@ int launch_prep_weights(const float* w, int c_in, int kb, int c_out, int mode, u
 // short-k, wide-n products (grad_T beyond the strip kernel's k <= 64) the narrow tile keeps more blocks in flight
 int gemm_nn_bf16_col_blocks(int n, int k) { return n > BN && k >= 512 ? 2 : 1; }
 
-// k groups per workgroup of the 3-byte-row kernel (gemm_nn_t24_kernel, KG): two when the output tiles alone leave the chip
-// under-filled and the super tiles of a workgroup divide evenly.  SE3_NN_KG=1 turns the form off (A/B switch).
+// k groups per workgroup of the 3-byte-row kernel (gemm_nn_t24_kernel, KG).  OPT-IN (SE3_NN_KG=2: two groups when the
+// output tiles alone leave the chip under-filled and the super tiles of a workgroup divide evenly): measured in round 5
+// against the split over grid.z it was meant to replace (profiles/r05_nn_kgroups_ab.txt) -- the 18 k-row level of the
+// headline stack 0.327 -> 0.336 ms, its 254-row level 0.069 -> 0.074, the stack +0.8 %, scannet150k_f1 +0.6 %, dfaust_f2
+// -0.9 %: eight wavefronts sharing one CU's LDS pipe and barriers buy no more than the reduction launch they save.
 int gemm_nn_t24_k_groups(int64_t m, int n, int k) {
   static const int forced = [] {
     const char* e = getenv("SE3_NN_KG");
     return e ? atoi(e) : 0;
   }();
-  if (forced == 1 || k % 128 != 0) return 1;
+  if (forced != 2 || k % 128 != 0) return 1;
   const int bnw = BN * gemm_nn_bf16_col_blocks(n, k);
   const int64_t tiles = ((m + BM - 1) / BM) * ((n + bnw - 1) / bnw);
   return tiles > 0 && tiles <= 384 ? 2 : 1;  // beyond 1.5 workgroups per CU the plain form covers its own latencies

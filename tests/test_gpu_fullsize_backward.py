@@ -184,11 +184,14 @@ _DFAUST_ORACLE = {}
 
 def test_dfaust_f2_batch_against_oracle(amd):
     """configs[1]: 32 bodies x 2 200 points (4096 sampled -> 0.04 grid), F = 2 PCA frames from 16-NN, the network's
-    first convolution C_in = 1 -> 32 (tasks/SemSeg/confs/dfaust/dfaust_I_rot_pca_2F.yaml:4,17,37-38) -- whole batch
-    against the oracle: edge sets bit-exact, output and every gradient within tolerance."""
+    first convolution C_in = 1 -> 32 (tasks/SemSeg/confs/dfaust/dfaust_I_rot_pca_2F.yaml:4,17,37-38).  The GPU runs the
+    whole batch; the oracle runs the first 10 bodies (bodies do not interact: batch ids are part of the ball query), which
+    pins the edge set of those bodies bit-exactly, their output rows, their rows of dX and -- with the output gradient
+    zeroed on the other 22 bodies -- every parameter gradient.  (Round 5: the oracle on all 32 bodies took 58 s of the
+    suite for the same evidence.)"""
     torch.manual_seed(3)
-    bodies, n_per, f = 32, 2200, 2
-    n = bodies * n_per
+    bodies, n_per, f, sub = 32, 2200, 2, 10
+    n, m = bodies * n_per, sub * n_per
     pts = torch.rand(n, 3, device=DEV)
     bid = torch.arange(bodies, dtype=torch.int32, device=DEV).repeat_interleave(n_per)
     pc = amd.pc.PointcloudRotEquiv(pts, bid, {"pca": True, "n_frames": f, "fixed_axis": False, "neigh_method": "knn",
@@ -196,20 +199,25 @@ def test_dfaust_f2_batch_against_oracle(amd):
     assert pc.local_frames_.shape == (n, f, 9)
     r = radius_for_degree(n_per, 14)
     nbh, conv, x, g = make_layer(amd, pc, r, 1, 32, seed=30)
+    g = g.clone()
+    g[m * f:] = 0.0  # the parameter gradients then are those of the 10-body sub-problem
     cpu = lambda t: t.detach().cpu()
-    inputs = [pts.cpu(), pc.local_frames_.cpu(), x.detach().cpu(), cpu(conv.proj_axes_), cpu(conv.proj_biases_),
-              cpu(conv.conv_weights_), cpu(conv.norm_neigh_dist_), cpu(conv.norm_num_neighs_), g.cpu()]
-    # the oracle takes a minute on this batch and its inputs do not depend on the arithmetic mode of the library:
-    # computed once per session, reused when the second mode presents bit-identical inputs
+    inputs = [pts[:m].cpu(), pc.local_frames_[:m].cpu(), x.detach()[:m * f].cpu(), cpu(conv.proj_axes_), cpu(conv.proj_biases_),
+              cpu(conv.conv_weights_), cpu(conv.norm_neigh_dist_), cpu(conv.norm_num_neighs_), g[:m * f].cpu()]
+    # the oracle's inputs do not depend on the arithmetic mode of the library: computed once per session, reused when the
+    # next mode presents bit-identical inputs
     cached = _DFAUST_ORACLE.get("inputs")
     if cached is None or not all(torch.equal(a, b) for a, b in zip(cached, inputs)):
-        nb_ref, ends_ref = O.ball_query(pts.cpu(), pts.cpu(), bid.cpu(), bid.cpu(), r)
+        nb_ref, ends_ref = O.ball_query(pts[:m].cpu(), pts[:m].cpu(), bid[:m].cpu(), bid[:m].cpu(), r)
         ref = O.conv_forward_backward(inputs[0], inputs[0], inputs[1], inputs[1], nb_ref, inputs[2], *inputs[3:])
         _DFAUST_ORACLE.update(inputs=inputs, nb=nb_ref, ends=ends_ref, ref=ref)
     nb_ref, ends_ref, ref = _DFAUST_ORACLE["nb"], _DFAUST_ORACLE["ends"], _DFAUST_ORACLE["ref"]
-    assert torch.equal(nbh.start_ids_.cpu(), ends_ref) and torch.equal(canon_edges(nbh.neighbors_), canon_edges(nb_ref))
-    got = gpu_backward(conv, pc, nbh, x, g)
-    for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), got, ref):
+    e_sub = int(nbh.start_ids_[m - 1])
+    assert torch.equal(nbh.start_ids_[:m].cpu(), ends_ref) and torch.equal(canon_edges(nbh.neighbors_[:e_sub]), canon_edges(nb_ref))
+    out, dx, da, db, dw = gpu_backward(conv, pc, nbh, x, g)
+    assert bool((dx[m * f:] == 0).all()), "no gradient reaches the bodies whose output gradient is zero"
+    # nu in the layer is M / E of the whole batch, the oracle's inputs carry the same buffer value
+    for name, u, v in zip(("out", "dX", "dA", "dbeta", "dW"), (out[:m * f], dx[:m * f], da, db, dw), ref):
         assert rel_err(u, v) < tol(amd), (name, rel_err(u, v))
 
 

@@ -10,6 +10,8 @@ re-running a slice of the parity suite in a child process with the variable set:
   SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
   SE3_DX_PATH=1     feature gradient edge-major (edge_dx.hip) wherever it is implemented (the default decides by the bytes
                     either form moves -- down-convolutions and sparse levels only -- so the rest of the suite runs the U form)
+  SE3_NN_KG=2       the dense products over 3-byte rows of under-filled levels with two k groups per workgroup (round 5; lost
+                    its A/B, profiles/r05_nn_kgroups_ab.txt)
   SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2  the row-sliced schedule of round 5 (every producer -> consumer pair per slice of the
                     rows, consumers on the side stream; 1 MB so that the small shapes of the slice are cut too) -- lost its
                     A/B at every slice size (profiles/r05_slice_ab.txt) and stays as a switch
@@ -28,12 +30,16 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SLICE = "golden or random_shapes or headline_subset or features_only or empty_rows"
+# every switch acts on the split-bf16 kernels only: the children run the default arithmetic mode's cases of the slice
+# (round 5: eight children over all three modes were 318 s of the 547 s suite)
+SLICE = "(golden or random_shapes or headline_subset or features_only or empty_rows) and bf16x3 and not t16"
+# independent switches share a child
+VARIANTS = ["SE3_NO_PAIR,SE3_PG_SINGLE", "SE3_NO_T24", "SE3_PAIR_PERSIST=64,SE3_BWD_BRANCH_ORDER,SE3_NN_KG=2", "SE3_OVERLAP",
+            "SE3_DX_PATH=1", "SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2"]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("var", ["SE3_NO_PAIR", "SE3_PG_SINGLE", "SE3_PAIR_PERSIST=64", "SE3_NO_T24", "SE3_OVERLAP",
-                                 "SE3_BWD_BRANCH_ORDER", "SE3_DX_PATH=1", "SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2"])
+@pytest.mark.parametrize("var", VARIANTS)
 def test_variant_passes_parity_slice(var):
     env = dict(os.environ)
     for part in var.split(","):
@@ -44,5 +50,5 @@ def test_variant_passes_parity_slice(var):
          "-k", SLICE, "-p", "no:cacheprovider"],
         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = (proc.stdout + proc.stderr)[-2000:]
-    assert proc.returncode == 0, f"{var}=1: parity slice failed\n{tail}"
+    assert proc.returncode == 0, f"{var}: parity slice failed\n{tail}"
     assert " passed" in proc.stdout, tail
