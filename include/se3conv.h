@@ -119,7 +119,7 @@ typedef struct se3conv_shape {
 /* 3 = round 4: se3_side_stream_stats fills FIVE counters (was three); SE3_PRECISION_BF16X3_T16 and
  * se3conv_intermediate_row_bytes added. */
 /* 4 = round 4: se3_csr_transpose / _bounded and se3conv_bwd take `t_edge_ids` (optional).
- * (round 5 added se3_set_overlap_rows; no signature changed.) */
+ * (round 5 added se3_set_overlap_rows and se3conv_bwd_needs_t; no signature changed.) */
 #define SE3_ABI_VERSION 4
 int se3_abi_version(void);
 const char* se3_error_string(int code);
@@ -358,6 +358,13 @@ int se3conv_fwd(const float* pts_in, const float* pts_out, const float* frames_i
                 const se3conv_shape* shape, float* out, float* t_save, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* Whether se3conv_bwd (with parameter gradients wanted) makes use of the forward pass's T (`t_save`): 1 = yes -- without
+ * it the weight gradient re-runs the forward edge pass; 0 = no -- the weight gradient is taken from U, the tensor the
+ * feature gradient's transposed pass produces anyway (dW[i,k,o] = alpha sum_p f[p,i] U[p,o,k]; split-bf16 modes, U form of
+ * the feature gradient, C_in a multiple of 4, even C_out), so se3conv_fwd can be called with t_save = NULL and the layer keeps
+ * no row-sized activation (0.8 GB per layer at the headline shape).  `want_feat`: whether grad_feat will be asked for.
+ * When a `t_save` is passed anyway, se3conv_bwd still prefers U where U has fewer entries than T (an up-convolution). */
+int se3conv_bwd_needs_t(const se3conv_shape* shape, int want_feat);
 size_t se3conv_bwd_workspace_bytes(const se3conv_shape* shape, int want_feat, int want_params,
                                    int have_t_save);
 int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_in,

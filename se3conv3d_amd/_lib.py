@@ -68,6 +68,7 @@ SIGNATURES = {
     "se3conv_fwd_workspace_bytes": (_SZ, [_SHP, C.c_int]),
     "se3conv_fwd": (C.c_int, [_P] * 12 + [_SHP, _P, _P, _P, _SZ, _P]),
     "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
+    "se3conv_bwd_needs_t": (C.c_int, [_SHP, C.c_int]),
     "se3conv_bwd": (C.c_int, [_P] * 17 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
     "se3_knn_query": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "se3_knn_query_pair": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I32, _P, _P]),

@@ -331,9 +331,27 @@ bool use_edge_dx(const se3conv_shape* s, bool want_feat, bool want_params) {
   return 2.0 * d_bytes < u_bytes;
 }
 
+// The weight gradient from U instead of T (round 5): dW[i,k,o] = alpha sum_p f[p,i] U[p,o,k] -- U is the transposed pass's
+// tensor, which backward produces anyway for the feature gradient.  Available in the split-bf16 modes whenever the U form
+// of the feature gradient runs; then the forward pass need not keep T (0.8 GB per layer at the headline shape: the largest
+// saved activation by a factor of 24), and for an up-convolution the product walks the few rows of the coarse level
+// instead of the many of the fine one.  Used when T was not saved, or when U has fewer (row x channel) entries than T.
+// From the shape alone: se3conv_bwd_workspace_bytes, se3conv_bwd and se3conv_bwd_needs_t must agree.
+bool dw_from_u_available(const se3conv_shape* s, bool want_feat, bool want_params) {
+  if (!want_feat || !want_params || s->precision == SE3_PRECISION_FP32 || s->num_basis != kBasis) return false;
+  if (s->n_in == 0 || s->n_out == 0 || s->c_in % 4 != 0 || s->c_out % 2 != 0) return false;
+  static const bool branch_order = getenv("SE3_BWD_BRANCH_ORDER") != nullptr;  // that order overwrites U before the product would read it
+  return !branch_order && !use_edge_dx(s, true, true);
+}
+bool use_u_for_dw(const se3conv_shape* s, bool want_feat, bool want_params, bool have_t) {
+  if (!dw_from_u_available(s, want_feat, want_params)) return false;
+  return !have_t || (double)s->n_in * s->f_in * s->c_out < (double)s->n_out * s->f_out * s->c_in;
+}
+
 BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
   BwdLayout l{};
   const bool dx = use_edge_dx(s, want_feat != 0, want_params != 0);
+  const bool dw_u = use_u_for_dw(s, want_feat != 0, want_params != 0, have_t != 0);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t kb = s->num_basis;
@@ -381,7 +399,7 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
     l.split2 = take(gemm_nn_bf16_split_bytes((int64_t)rows_in, s->c_in, s->c_out * (int)kb));
   }
   l.dx_rows = dx ? take((size_t)s->n_edges * s->f_in * s->c_in * 4) : 0;
-  l.t = (want_params && !have_t) ? take(rows_out * s->c_in * kb * 4) : 0;
+  l.t = (want_params && !have_t && !dw_u) ? take(rows_out * s->c_in * kb * 4) : 0;
   l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
   if (fast && want_params && want_feat && !dx) {  // every slice's launch leaves its own partial sums (sliced_rows_grad_t)
     const int64_t per = sliced_rows_grad_t(s);
@@ -389,7 +407,8 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   }
   l.param_partials = want_params ? take((size_t)l.n_param_partials * edge_param_grad_bf16_channel_blocks(s->c_in) *
                                          kDescExt * kBasis * 4) : 0;
-  l.tn_splits = gemm_tn_splits((int64_t)rows_out, s->c_in * (int)kb, s->c_out);
+  l.tn_splits = dw_u ? gemm_tn_splits((int64_t)rows_in, s->c_out * (int)kb, s->c_in)
+                     : gemm_tn_splits((int64_t)rows_out, s->c_in * (int)kb, s->c_out);
   l.tn_partials = want_params ? take((size_t)l.tn_splits * wsz) : 0;
   l.total = off;
   return l;
@@ -958,6 +977,12 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
                              (float*)(ws + l.split), nu, inv_phi, stream, t24);
 }
 
+extern "C" int se3conv_bwd_needs_t(const se3conv_shape* s, int want_feat) {
+  if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
+  if (s->num_basis != kBasis) return 0;  // other K: T is recomputed per slice of 32 basis functions, `t_save` is never read
+  return dw_from_u_available(s, want_feat != 0, true) ? 0 : 1;
+}
+
 extern "C" size_t se3conv_bwd_workspace_bytes(const se3conv_shape* s, int want_feat, int want_params, int have_t) {
   if (!shape_ok(s)) return 0;
   if (s->num_basis != kBasis) {
@@ -1132,8 +1157,16 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   // The sums that end the pass -- split-K partials of the grad_X GEMM, row-range partials of the weight-gradient GEMM,
   // per-workgroup partials of d[A; beta] -- write final outputs nobody in this call reads: one launch folds them all
   ReduceBatch final_sums;
+  const bool dw_u = grad_weights != nullptr && feat_branch && !edge_dx && use_u_for_dw(s, want_feat, want_params, t_save != nullptr);
+  const uint32_t* u_rows = nullptr;  // where the transposed pass wrote U (set by whoever launches it)
   auto weight_gradient = [&](hipStream_t st) -> int {
     if (!grad_weights) return SE3_OK;
+    if (dw_u) {
+      if (!u_rows) return SE3_ERR_LAUNCH;  // (a schedule that has not produced U yet: a bug, not an input error)
+      // C'[(o,k), i] = sum_p U[p,(o,k)] f[p,i]; the batched reduction stores it as dW[i,k,o]
+      return launch_gemm_tn_bf16("gemm_gradW", u_rows, featpk, grad_weights, tn_partials, l.tn_splits, rows_in, s->c_out * kb,
+                                 s->c_in, nu, inv_phi, st, t24_u, &final_sums, true);
+    }
     const uint32_t* t = (const uint32_t*)t_save;
     if (!t) {
       uint32_t* tt = (uint32_t*)(ws + l.t);
@@ -1193,6 +1226,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       }
       const bool two = side_s != stream;
       uint32_t* ubuf = (uint32_t*)(ws + l.big_u);
+      u_rows = ubuf;
       // phase 1: U slices -- transposed edge pass on the caller's stream, their grad_X product behind it (side stream)
       {
         const int64_t step = per_u > 0 ? per_u : rows_in;
@@ -1268,6 +1302,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (!branch_order && !branch_forked && want_params && l.big_u != 0) {
       ubuf = (uint32_t*)(ws + l.big_u);
       fsplit = (float*)(ws + l.split2);
+      u_rows = ubuf;
       if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, fs, -1, -1, t24_u))
         return rc;
       if (strip_t) {
@@ -1288,6 +1323,10 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
     if (int rc = launch_gemm_nn_bf16("gemm_gradX", ubuf, bx_hi, bx_lo, grad_feat, false, rows_in, s->c_in, s->c_out * kb,
                                      fsplit, nu, inv_phi, fs, t24_u, &final_sums))
       return rc;
+    if (dw_u) {  // the weight gradient reads U: on the stream that wrote it, before the parameter branch reuses `big`
+      u_rows = ubuf;
+      if (int rc = weight_gradient(fs)) return rc;
+    }
   }
   if (want_params) {
     if (strip_t) {
@@ -1297,7 +1336,8 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
       return rc;
     }
     if (int rc = param_gradients(stream)) return rc;
-    if (int rc = weight_gradient(stream)) return rc;
+    if (!(dw_u && feat_branch))
+      if (int rc = weight_gradient(stream)) return rc;
   }
   if (int rc = fj.join()) return rc;  // the side stream's grad_X partials are complete before they are folded
   return final_sums.launch(stream);

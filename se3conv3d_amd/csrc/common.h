@@ -358,6 +358,7 @@ struct ReduceJob {
   int splits, packed;       // packed: out holds packed hi/lo words
   const float* alpha_num;
   float alpha_scale;
+  int perm_n;               // type 0, > 0: the partials are C'[(o, k), i] with i < perm_n, the output is dW[i, k, o] (kBasis k's)
 };
 struct ReduceJobs {
   int count;
@@ -365,7 +366,8 @@ struct ReduceJobs {
 };
 struct ReduceBatch {
   ReduceJobs jobs{};
-  void sum(const float* partials, void* out, int64_t count, int splits, const float* alpha_num, float alpha_scale, bool packed);
+  void sum(const float* partials, void* out, int64_t count, int splits, const float* alpha_num, float alpha_scale, bool packed,
+           int perm_n = 0);
   void params(const float* partials, int n_partials, float* grad_axes, float* grad_biases, float scale);
   int launch(hipStream_t stream);
 };
@@ -487,6 +489,7 @@ int launch_gemm_nn_bf16(const char* tag, const uint32_t* a, const uint16_t* bt_h
 size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k);
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
                         int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, int afmt = 0,
-                        ReduceBatch* defer = nullptr);  // defer (both GEMMs): the reduction joins the caller's ReduceBatch
+                        ReduceBatch* defer = nullptr,  // defer (both GEMMs): the reduction joins the caller's ReduceBatch
+                        bool out_ikn = false);  // out_ikn (needs defer): ka = (o, k), n = i -> c is dW[i, k, o] (the weight gradient from U)
 
 }  // namespace se3

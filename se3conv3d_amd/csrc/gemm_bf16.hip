@@ -1369,9 +1369,10 @@ size_t gemm_nn_bf16_split_bytes(int64_t m, int n, int k) {
 
 int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, float* c, float* partials, int splits,
                         int64_t m, int ka, int n, const float* alpha_num, float alpha_scale, hipStream_t stream, int afmt,
-                        ReduceBatch* defer) {
+                        ReduceBatch* defer, bool out_ikn) {
   const bool a24 = afmt == 1, a16 = afmt == 2;
   if (ka == 0 || n == 0) return SE3_OK;
+  if (out_ikn && (!defer || ka % kBasis != 0)) return SE3_ERR_INVALID_ARGUMENT;  // the permuted store lives in the batched reduction
   ProfScope prof(tag, stream);
   int64_t chunk = (m + splits - 1) / splits;
   chunk = (chunk + BK - 1) / BK * BK;
@@ -1408,7 +1409,7 @@ int launch_gemm_tn_bf16(const char* tag, const uint32_t* a, const uint32_t* b, f
       hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, 0>), grid, dim3(256), 0, stream, ab, bb, pb, mb, ka, n, chunk);
   }
   if (defer) {
-    defer->sum(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, false);
+    defer->sum(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, false, out_ikn ? n : 0);
     return check_launch();
   }
   return launch_reduce_partials(partials, c, (int64_t)ka * n, splits, alpha_num, alpha_scale, stream);

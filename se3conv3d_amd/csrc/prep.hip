@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceJobs jobs) {
 #pragma unroll 8
       for (int z = 0; z < j.splits; ++z) s += j.partials[(int64_t)z * j.count + i];
       if (j.packed) static_cast<uint32_t*>(j.out)[i] = split_pack(alpha * s);
-      else static_cast<float*>(j.out)[i] = alpha * s;
+      else if (j.perm_n > 0) {  // C'[(o * kBasis + k), ci] -> dW[(ci * kBasis + k), o]
+        const int64_t ok = i / j.perm_n;
+        const int ci = (int)(i - ok * j.perm_n), k = (int)(ok % kBasis);
+        const int64_t o = ok / kBasis, c_out = j.count / ((int64_t)j.perm_n * kBasis);
+        static_cast<float*>(j.out)[((int64_t)ci * kBasis + k) * c_out + o] = alpha * s;
+      } else static_cast<float*>(j.out)[i] = alpha * s;
     }
     return;
   }
@@ -175,12 +180,12 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceJobs jobs) {
 }  // namespace
 
 void ReduceBatch::sum(const float* partials, void* out, int64_t count, int splits, const float* alpha_num, float alpha_scale,
-                      bool packed) {
+                      bool packed, int perm_n) {
   if (count == 0) return;
   ReduceJob& j = jobs.job[jobs.count++];
   j = ReduceJob{};
   j.type = 0, j.blocks = blocks_for(count, 2048), j.partials = partials, j.out = out, j.count = count, j.splits = splits;
-  j.packed = packed ? 1 : 0, j.alpha_num = alpha_num, j.alpha_scale = alpha_scale;
+  j.packed = packed ? 1 : 0, j.alpha_num = alpha_num, j.alpha_scale = alpha_scale, j.perm_n = perm_n;
 }
 
 void ReduceBatch::params(const float* partials, int n_partials, float* grad_axes, float* grad_biases, float scale) {

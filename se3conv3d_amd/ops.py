@@ -747,8 +747,16 @@ class SE3ConvFunction(torch.autograd.Function):
     def forward(ctx, feat, proj_axes, proj_biases, conv_weights, geom: ConvGeometry, rho, nu):
         need_params = any(ctx.needs_input_grad[1:4])
         ctx.precision = _precision
+        save_t = need_params
+        if save_t:
+            # T ([rows, C_in, K]: 0.8 GB per layer at the headline shape, the largest activation a layer would keep) is only
+            # saved where backward has a use for it: when the feature gradient is wanted too, the library takes the weight
+            # gradient from U, the tensor its transposed pass produces anyway (se3conv_bwd_needs_t, include/se3conv.h)
+            c_in, kb, c_out = conv_weights.shape
+            shp = geom.shape(c_in, c_out, kb, ctx.precision)
+            save_t = _lib.load().se3conv_bwd_needs_t(C.byref(shp), int(bool(ctx.needs_input_grad[0]))) != 0
         out, t_save = se3conv_forward(geom, feat, proj_axes, proj_biases, conv_weights, rho, nu,
-                                      save_t=need_params, precision=ctx.precision)
+                                      save_t=save_t, precision=ctx.precision)
         ctx.geom = geom
         ctx.in_dtype = feat.dtype
         ctx.save_for_backward(feat, proj_axes, proj_biases, conv_weights, _scalar(rho, "rho", out.device),

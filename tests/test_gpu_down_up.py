@@ -184,3 +184,56 @@ def test_edge_major_feature_gradient_of_a_down_convolution(amd, f, c_in, c_out):
     xg = x.clone().requires_grad_(True)
     conv(p_pc_in=pc_in, p_pc_out=pc_out, p_in_features=xg, p_neighborhood=nbh).backward(g)
     assert rel_err(xg.grad, ref[1]) < tol
+
+
+@pytest.mark.parametrize("kind", ["same", "up", "down"])
+def test_weight_gradient_from_u_and_from_t_agree(amd, kind):
+    """Round 5: se3conv_bwd takes dW from U (the transposed pass's tensor: dW[i,k,o] = alpha sum_p f[p,i] U[p,o,k]) when the
+    forward pass kept no T, and also with a T at hand when U is the smaller tensor (an up-convolution); from T otherwise.
+    Raw calls with and without `t_save`: both results against the oracle, `se3conv_bwd_needs_t` consistent with what the module
+    saves, and without the feature gradient (no U) the T path is what runs."""
+    import ctypes as C
+
+    from se3conv3d_amd import _lib, layers, ops
+    if ops._precision == "fp32":
+        pytest.skip("the exact-fp32 mode always keeps T")
+    torch.manual_seed(40)
+    f, c_in, c_out = 2, 64, 64
+    n_a, n_b = 3000, 900
+    cfg = {"pca": False, "n_frames": f, "fixed_axis": False}
+    pc_a = amd.pc.PointcloudRotEquiv(torch.rand(n_a, 3, device=DEV), torch.zeros(n_a, dtype=torch.int32, device=DEV), cfg)
+    pc_b = amd.pc.PointcloudRotEquiv(torch.rand(n_b, 3, device=DEV), torch.zeros(n_b, dtype=torch.int32, device=DEV), cfg)
+    pc_in, pc_out = {"same": (pc_a, pc_a), "up": (pc_b, pc_a), "down": (pc_a, pc_b)}[kind]
+    r = W.radius_for_degree(n_a if kind != "up" else n_b, 20)
+    nbh = amd.pc.BQNeighborhood(pc_in, pc_out, r)
+    n_in, n_out, e = pc_in.pts_.shape[0], pc_out.pts_.shape[0], nbh.num_edges()
+    conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c_in, c_out).to(DEV)
+    conv.norm_neigh_dist_.fill_(1.0 / r), conv.norm_num_neighs_.fill_(n_out / e)
+    with torch.no_grad():
+        conv.proj_biases_.uniform_(-0.5, 0.5)
+    x = torch.randn(n_in * f, c_in, device=DEV)
+    g = torch.randn(n_out * f, c_out, device=DEV)
+    geom = layers._geometry_of(pc_in, pc_out, nbh)
+    args = (geom, x, conv.proj_axes_.detach(), conv.proj_biases_.detach(), conv.conv_weights_.detach(), conv.norm_neigh_dist_,
+            conv.norm_num_neighs_)
+    out, t_save = ops.se3conv_forward(*args, save_t=True)
+    out2, none = ops.se3conv_forward(*args, save_t=False)
+    assert none is None and torch.equal(out, out2)
+    with_t = ops.se3conv_backward(*args, t_save, g)
+    without_t = ops.se3conv_backward(*args, None, g)
+    params_only = ops.se3conv_backward(*args, t_save, g, want_feat=False)
+    cpu = lambda t: t.detach().cpu()
+    ref = O.conv_forward_backward(cpu(pc_in.pts_), cpu(pc_out.pts_), cpu(pc_in.local_frames_), cpu(pc_out.local_frames_),
+                                  cpu(nbh.neighbors_), cpu(x), *(cpu(a) for a in args[2:5]), 1.0 / r, n_out / e, cpu(g))
+    tol = TOLS[ops._precision]
+    for got in (with_t, without_t):
+        for u, v, name in zip(got, ref[1:], ("dX", "dA", "dbeta", "dW")):
+            assert rel_err(u, v) < tol, (kind, name)
+    assert params_only[0] is None and rel_err(params_only[3], ref[4]) < tol
+    shp = geom.shape(c_in, c_out, 32)
+    needs = _lib.load().se3conv_bwd_needs_t(C.byref(shp), 1)
+    # a down-convolution of this size takes the edge-major feature gradient (no U): T is needed; the others do without
+    assert needs == (1 if kind == "down" else 0)
+    assert _lib.load().se3conv_bwd_needs_t(C.byref(shp), 0) == 1  # no feature gradient, no U
+    if kind == "up":    # U (n_b rows) is the smaller tensor: the product reads it even though T is there -> identical results
+        assert torch.equal(with_t[3], without_t[3])

@@ -579,7 +579,10 @@ def test_other_basis_counts_at_the_c_abi(amd, kb, c_in, c_out):
     dx2, none_a, _, _ = ops.se3conv_backward(geom, d(x), d(a), d(b), d(w), rho, nu, None, d(go), want_params=False)
     assert none_a is None and torch.equal(dx2, dx)
     _, da2, db2, dw2 = ops.se3conv_backward(geom, d(x), d(a), d(b), d(w), rho, nu, None, d(go), want_feat=False)
-    assert torch.equal(da2, da) and torch.equal(db2, db) and torch.equal(dw2, dw)
+    assert torch.equal(da2, da) and torch.equal(db2, db)
+    # the weight gradient comes from U when the feature gradient is computed too and from a recomputed T when it is not
+    # (round 5): two summation orders of the same sum
+    assert rel_err(dw2, ref[4]) < tol(amd) and rel_err(dw2, dw) < 2 * tol(amd)
 
 
 @pytest.mark.parametrize("kb", [8, 16, 64, 40])
