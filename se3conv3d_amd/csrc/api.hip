@@ -328,7 +328,15 @@ bool use_edge_dx(const se3conv_shape* s, bool want_feat, bool want_params) {
   const double rows_in = (double)s->n_in * s->f_in, rows_out = (double)s->n_out * s->f_out;
   const double u_bytes = rows_in * s->c_out * kBasis * 6.0;
   const double d_bytes = (double)s->n_edges * s->f_in * s->c_in * 8.0 + (want_params ? 0.0 : rows_out * s->c_in * kBasis * 8.0);
-  return 2.0 * d_bytes < u_bytes;
+  // Cost model in microseconds, fitted in round 5 to the stage times of the reference network's own convolution calls
+  // (profiles/r05_faust_network_convs.txt: the default against SE3_DX_PATH=1) and of the bench levels: the U form pays a
+  // latency floor for its two launches on levels too small to fill the chip (~45 us: the grad_X GEMM of a 3.7 k-row level
+  // takes as long as that of an 18 k-row one) plus its bytes at the rate of a just-written tensor; the edge-major form
+  // ~15 us plus its bytes at the rate of its row gathers -- and loses whatever the bytes say where a source owns more than
+  // ~20 edges (its per-source sum walks the segment: headline level 2, 27 edges per point, 0.108 -> 0.115 ms; a lateral
+  // convolution with 357 edges per source: dx_gather 330 us).  Round 4's rule was 2 d_bytes < u_bytes.
+  if ((double)s->n_edges > 20.0 * (double)s->n_in) return false;
+  return 15.0 + d_bytes / 2.2e6 < 45.0 + u_bytes / 6.0e6;
 }
 
 // The weight gradient from U instead of T (round 5): dW[i,k,o] = alpha sum_p f[p,i] U[p,o,k] -- U is the transposed pass's

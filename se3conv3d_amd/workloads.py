@@ -211,3 +211,65 @@ def stage_hbm_bytes(n: int, e: int, f: int, c: int, bytes_per_el=(3, 3, 4), kb: 
     table = 4 * n * f * c
     return {t: v - stage_gather_bytes(n, e, f, c).get(t, 0) + (table if t in ("edge_t_fwd", "edge_t_transposed", "edge_param_grad") else 0)
             for t, v in moved.items()}
+
+
+# ---- BASELINE config 2 at its own shapes: the 21 convolution calls of the reference's FAUST network -----------------------
+def faust_network_calls(fixture_path: str) -> List[dict]:
+    """The call list of the reference's FPNSegUNetMLPGeluRotEqFAUST as recorded from the reference itself
+    (tests/golden/network_faust_calls.npz, tools/gen_golden.py `network_case`): per call the hierarchy level of the input
+    and of the output cloud (5 = the task script's randomly sub-sampled output cloud), the neighbourhood radius and the
+    channel counts -- patch encoder (0 -> 1, 1 -> 1), two blocks per level 1..4 with the down-convolutions between them,
+    the decoder's up-convolutions, the three FPN laterals onto level 1, the patch decoder (1 -> 0) and the head (0 -> out)."""
+    import numpy as np
+
+    calls = []
+    with np.load(fixture_path) as z:
+        for i in range(int(z["n_calls"])):
+            _, ci, co, ni, c_in, c_out = (int(v) for v in z[f"c{i:02d}/meta"])
+            calls.append(dict(level_in=ci, level_out=co, radius=float(z[f"nbh{ni}/radius"]), c_in=c_in, c_out=c_out))
+    return calls
+
+
+def build_faust_network_convs(device, fixture_path: str, bodies: int = 32, sampled: int = 4096, seed: int = 0) -> List[dict]:
+    """The hierarchy the task script builds for a DFaust batch (tasks/SemSeg/train_dfaust_rot.py:108-158 with
+    confs/dfaust/dfaust_I_rot_pca_2F.yaml: 4096 sampled points per body, init / output sub-sample 0.04, grid sub-samples
+    0.05 .. 0.4, PCA frames from 16-NN, F = 2) on synthetic bodies -- thin shells of a torso's proportions, ~2 k points per
+    body at level 0 -- and one bench record per convolution call of the network (``faust_network_calls``): clouds,
+    ball-query neighbourhood with the call's radius, a layer with converged EMA buffers, features and an output gradient."""
+    from . import layers, pc as _pc
+
+    torch.manual_seed(seed)
+    cfg = {"pca": True, "n_frames": 2, "fixed_axis": False, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
+    u = torch.randn(bodies * sampled, 3, device=device)
+    u = u / u.norm(dim=1, keepdim=True)
+    scale = 1.0 + 0.15 * torch.rand(bodies, 1, device=device).repeat_interleave(sampled, 0)
+    pts = u * torch.tensor([0.27, 0.9, 0.17], device=device) * scale + 0.01 * torch.randn(bodies * sampled, 3, device=device)
+    pts = pts + torch.arange(bodies, device=device, dtype=torch.float32).repeat_interleave(sampled)[:, None] * torch.tensor([3.0, 0.0, 0.0], device=device)
+    bid = torch.arange(bodies, device=device, dtype=torch.int32).repeat_interleave(sampled)
+    raw = _pc.Pointcloud(pts, bid)
+    samp = _pc.GridSubSample(raw, 0.04)
+    pc0 = _pc.PointcloudRotEquiv(samp.__subsample_tensor__(raw.pts_, "avg"), samp.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
+    hier = _pc.PointHierarchyRotEquiv(pc0, 4, "grid_avg", grid_radii=[0.05, 0.1, 0.2, 0.4])
+    samp_out = _pc.GridSubSample(raw, 0.04, p_rnd_sample=True)
+    out_pc = _pc.PointcloudRotEquiv(samp_out.__subsample_tensor__(raw.pts_, "avg"),
+                                    samp_out.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
+    clouds = list(hier.pcs_) + [out_pc]
+    factory = layers.PNEConvLayerRotEquivFactory(9, NUM_BASIS, "mlp_gelu")
+    recs, nbhs = [], {}
+    for i, c in enumerate(faust_network_calls(fixture_path)):
+        pc_in, pc_out = clouds[c["level_in"]], clouds[c["level_out"]]
+        key = (c["level_in"], c["level_out"], c["radius"])
+        if key not in nbhs:  # the network builds a neighbourhood once and shares it between the convolutions that use it
+            nbhs[key] = _pc.BQNeighborhood(pc_in, pc_out, c["radius"])
+        nbh = nbhs[key]
+        conv = factory.create_conv_layer(c["c_in"], c["c_out"]).to(device)
+        conv.norm_neigh_dist_.fill_(1.0 / c["radius"])
+        conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.num_edges(), 1))
+        n_in, n_out = pc_in.pts_.shape[0], pc_out.pts_.shape[0]
+        # the network's first convolution reads the input features (no gradient); every other one is fed by a layer
+        x = torch.randn(n_in * 2, c["c_in"], device=device, requires_grad=i > 0)
+        g = torch.randn(n_out * 2, c["c_out"], device=device)
+        recs.append(dict(name=f"call{i:02d}", pc_in=pc_in, pc_out=pc_out, nbh=nbh, conv=conv, x=x, g=g, n_in=n_in, n_out=n_out,
+                         e=nbh.num_edges(), r=c["radius"], c_in=c["c_in"], c_out=c["c_out"], f=2, level_in=c["level_in"],
+                         level_out=c["level_out"]))
+    return recs

@@ -204,7 +204,7 @@ def test_weight_gradient_from_u_and_from_t_agree(amd, kind):
     pc_a = amd.pc.PointcloudRotEquiv(torch.rand(n_a, 3, device=DEV), torch.zeros(n_a, dtype=torch.int32, device=DEV), cfg)
     pc_b = amd.pc.PointcloudRotEquiv(torch.rand(n_b, 3, device=DEV), torch.zeros(n_b, dtype=torch.int32, device=DEV), cfg)
     pc_in, pc_out = {"same": (pc_a, pc_a), "up": (pc_b, pc_a), "down": (pc_a, pc_b)}[kind]
-    r = W.radius_for_degree(n_a if kind != "up" else n_b, 20)
+    r = W.radius_for_degree(n_a if kind != "up" else n_b, 28)  # (denser than 20 edges per source: the same-level case keeps the U form)
     nbh = amd.pc.BQNeighborhood(pc_in, pc_out, r)
     n_in, n_out, e = pc_in.pts_.shape[0], pc_out.pts_.shape[0], nbh.num_edges()
     conv = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu").create_conv_layer(c_in, c_out).to(DEV)
