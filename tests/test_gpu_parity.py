@@ -225,6 +225,18 @@ def test_random_shapes_against_oracle(case, amd):
     assert torch.equal(canon_edges(torch.stack((ts, srcs), 1)), canon_edges(nb_ref))
 
 
+@pytest.mark.parametrize("scale", [8.0, 60.0, 3000.0])
+def test_large_preactivations_saturate_like_the_reference(amd, scale):
+    """Kernel-MLP weights far outside their initial range: pre-activations of +-10 ... +-10^4, i.e. beyond the interval the
+    value-only GELU of the split-bf16 edge passes is fitted on (common.h gelu_scaled: exp2 of a degree-7 polynomial whose
+    leading coefficient is pinned negative) -- GELU must saturate to x / 0 there exactly as the erf form does."""
+    c = random_case(31, 500, None, 2, 2, 64, 64, 24, 1)
+    c["a"], c["b"] = c["a"] * scale, c["b"] * scale
+    errs, _, _ = run_case_against_oracle(c, 2, 2, amd)
+    for key, err in errs.items():
+        assert err < tol(amd), (key, err, scale)
+
+
 def test_features_only_backward_and_frozen_params(amd):
     """needs_input_grad combinations: only dX (frozen layer) and only parameter grads."""
     c = random_case(21, 300, None, 2, 2, 32, 32, 12)
