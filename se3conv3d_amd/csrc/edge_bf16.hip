@@ -493,8 +493,7 @@ __global__ __launch_bounds__(256) void edge_param_grad_bf16_kernel(EdgeGeom g, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = acc_row(r, h);
-        float y, dy;
-        gelu_scaled_grad(pre[r], y, dy);  // dy = 2 GELU': the factor 0.5 is applied where the partials are reduced
+        const float dy = gelu_scaled_dgrad(pre[r]);  // 2 GELU': the factor 0.5 is applied where the partials are reduced
         const float gp = n < cnt ? gphi[r] * dy : 0.f;
         const float4* src = reinterpret_cast<const float4*>(&lds_desc[wave][n][0]);
         const float4 d0 = src[0], d1 = src[1];
@@ -814,9 +813,8 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         const f32x16 pre = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float y;
           if (SE3_PG_ABLATE & 1) dy[r] = pre[r];
-          else gelu_scaled_grad(pre[r], y, dy[r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
+          else dy[r] = gelu_scaled_dgrad(pre[r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
         }
       };
       // gphi = F gT on the gathered rows, gpre = gphi * GELU', and the d[A;beta] product of frame a
