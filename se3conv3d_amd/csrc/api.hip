@@ -723,6 +723,7 @@ EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* fr
   g.nbr = neighbors, g.nbr_stride = 2, g.nbr_offset = 1, g.ends = ends;
   g.n_ctr = s->n_out, g.f_ctr = s->f_out, g.f_nb = s->f_in, g.transposed = 0;
   g.n_nb = s->n_in;
+  g.n_edges = s->n_edges;
   return g;
 }
 
@@ -1070,6 +1071,7 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   gt.nbr = t_samples, gt.nbr_stride = 1, gt.nbr_offset = 0, gt.ends = t_ends;
   gt.n_ctr = s->n_in, gt.f_ctr = s->f_in, gt.f_nb = s->f_out, gt.transposed = 1;
   gt.n_nb = s->n_out;
+  gt.n_edges = s->n_edges;
   float* partials = (float*)(ws + l.param_partials);
   float* tn_partials = (float*)(ws + l.tn_partials);
 

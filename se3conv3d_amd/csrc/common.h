@@ -382,6 +382,7 @@ struct EdgeGeom {            // one side-agnostic view of the geometry for the e
   const float* ctr_geom;     // packed 64-byte records per (point, frame) row (pack_geometry_kernel); bf16 kernels
   const float* nb_geom;
   int64_t n_nb;              // number of points on the neighbour side
+  int64_t n_edges;           // rows of the id list (the edge buffer's capacity); 0: unknown (kernels that bounds-check ids are not used)
   const int32_t* nbr;        // neighbour id of edge e at nbr[e*nbr_stride + nbr_offset]
   int nbr_stride, nbr_offset;
   const int32_t* ends;       // [Nc] inclusive end offsets of every centre's edge group

@@ -29,6 +29,49 @@
 #include "common.h"
 #include "edge_bf16_body.h"
 
+// SE3_TIMELINE=1 (diagnostic build only, tools/edge_timeline.py): s_memtime stamps at the phase boundaries of the wave-pair
+// edge kernel and of the pair form of the parameter-gradient kernel.  Every stamp is one asm statement with its own
+// lgkmcnt(0) between two scheduling barriers (cdna_hip_programming.md section 7, "In-kernel stamps"); a load's wait is made
+// a segment of its own by pinning the loaded value between two stamps.  The per-wave records go to a buffer of their own
+// (se3_timeline_set) that nothing else reads.  The shipped library contains no stamp and no such symbol.
+#ifndef SE3_TIMELINE
+#define SE3_TIMELINE 0
+#endif
+#if SE3_TIMELINE
+#define TL(...) __VA_ARGS__
+namespace se3 {
+constexpr int kTlWords = 64;  // words per record; region r starts at r * cap records (0 edge_t forward, 1 transposed, 2 parameter gradient)
+__device__ uint32_t* g_tl_buf = nullptr;
+__device__ uint32_t g_tl_cap = 0;
+__device__ __forceinline__ uint32_t tl_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return (uint32_t)t;
+}
+template <class T>
+__device__ __forceinline__ void tl_pin(const T& x) { asm volatile("" ::"v"(x)); }
+// stamps are parked in a wave-private LDS record (every lane writes the same word: no exec games, two instructions) and
+// leave for the buffer once, at the wave's end
+__device__ __forceinline__ void tl_mark(uint32_t* rec, int slot) { const uint32_t t = tl_now(); if (slot < kTlWords) rec[slot] = t; }
+// persistent kernels: the time since the previous stamp is added to segment `slot`
+__device__ __forceinline__ void tl_seg(uint32_t* rec, uint32_t& prev, int slot) { const uint32_t t = tl_now(); rec[slot] += t - prev; prev = t; }
+__device__ __forceinline__ void tl_flush(int region, uint32_t idx, const uint32_t* rec) {
+  if (g_tl_buf == nullptr || idx >= g_tl_cap) return;
+  g_tl_buf[((size_t)region * g_tl_cap + idx) * kTlWords + (threadIdx.x & 63)] = rec[threadIdx.x & 63];
+}
+}  // namespace se3
+extern "C" int se3_timeline_set(void* buf, uint32_t cap_records) {
+  uint32_t* b = static_cast<uint32_t*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(se3::g_tl_buf), &b, sizeof(b)) != hipSuccess) return SE3_ERR_LAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(se3::g_tl_cap), &cap_records, sizeof(cap_records)) != hipSuccess) return SE3_ERR_LAUNCH;
+  return SE3_OK;
+}
+#else
+#define TL(...)
+#endif
+
 namespace se3 {
 
 namespace {
@@ -186,10 +229,12 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
     int t24) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
   __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
+  TL(__shared__ uint32_t tl_lds[2][kTlWords]; uint32_t* tl_rec = tl_lds[threadIdx.x >> 6]; tl_rec[threadIdx.x & 63] = 0u; tl_mark(tl_rec, 0); int tl_ch = 16;)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kcol = lane & 31, h = lane >> 5;
   if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
   __syncthreads();
+  TL(tl_mark(tl_rec, 1);)  // [0] entry, [1] arguments, MLP weights into LDS, barrier
   const float rho = *rho_p;
   const int row_bytes = C * 4;
   const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
@@ -213,6 +258,7 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
   const int n_total = (SE3_PAIR_ABLATE & 32) ? 31 * g.f_nb : (g.ends[ctr] - start) * g.f_nb;
   float yc[3], rc[9];
   load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (NF == 2 ? wv : 0)), yc, rc);  // this wavefront's frame
+  TL(tl_mark(tl_rec, 2); asm volatile("" ::"s"(n_total)); tl_mark(tl_rec, 3); tl_rec[15] = (uint32_t)n_total;)  // [2] item set-up issued, [3] row extents in
 
   // Neighbour ids are fetched two chunks ahead and the geometry records one chunk ahead, so that no load result is
   // needed in the chunk that issues it (the dependent chain ids -> record/feature rows costs one memory latency
@@ -248,9 +294,11 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
     if (n_total > 0) {
       const int nb_a = nbr_of(0);
       nb_b = nbr_of(32);
+      TL(tl_mark(tl_rec, 4); tl_pin(nb_a); tl_mark(tl_rec, 5);)  // [4] id loads issued, [5] ids of chunk 0 in
       q_a = row_of(nb_a, 0);
       load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
     }
+    TL(tl_mark(tl_rec, 6);)  // [6] chunk loop entered
     for (int c0 = 0; c0 < n_total; c0 += 32, buf ^= 1) {
       const int cnt = min(32, n_total - c0);
       // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
@@ -297,6 +345,10 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
         }
       load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       q_a = q_b;
+      // segments of a chunk: gathers issued | this chunk's record in | descriptor + kernel MLP | GELU + split + publish |
+      // barrier | feature words of k-step 0 in | aggregation issued
+      // (record words 16 + 8 j + i: stamp i of chunk j, chunks 0 .. 5; stamp 7 = the chunk's end)
+      TL(tl_mark(tl_rec, tl_ch + 1); tl_pin(xn[0]); tl_pin(rn[7]); tl_pin(rn[8]); tl_mark(tl_rec, tl_ch + 2);)
 
       if (TR == 0 || (TR < 0 && !g.transposed))
         edge_descriptor(xn, rn, yc, rc, rho, d);
@@ -314,6 +366,7 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
         const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
         const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
         const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+        TL(tl_pin(phi[0]); tl_mark(tl_rec, tl_ch + 3);)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s * 16 < cnt && (NF == 2 || s == wv)) {
@@ -332,7 +385,9 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
           }
         }
       }
+      TL(tl_mark(tl_rec, tl_ch + 4);)
       if (!(SE3_PAIR_ABLATE & 64)) __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
+      TL(tl_mark(tl_rec, tl_ch + 5); tl_pin(fw[0][0][7]); tl_mark(tl_rec, tl_ch + 6);)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s * 16 < cnt) {
@@ -351,7 +406,9 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
           }
         }
       }
+      TL(tl_mark(tl_rec, tl_ch + 7); tl_ch += 8;)
     }
+    TL(tl_mark(tl_rec, 7); tl_pin(acc[NF - 1][CT - 1][15]); tl_mark(tl_rec, 8);)  // [7] loop left, [8] accumulators in
     // acc[a][t] register r, lane (kcol, h) = T[row NF*item + a][cbase + 32*(CT*wv + t) + acc_row(r,h)][kcol]
 #pragma unroll
     for (int a = 0; a < NF; ++a)
@@ -410,6 +467,232 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
       }
     if (cbase + 64 * CT < C) __syncthreads();  // the next pass reuses the phi buffers from their start
   }
+  TL(tl_mark(tl_rec, 9); __builtin_amdgcn_s_waitcnt(0); tl_mark(tl_rec, 10);   // [9] stores issued, [10] stores retired
+     tl_rec[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tl_rec[12] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+     tl_rec[13] = (uint32_t)item; tl_rec[14] = (uint32_t)((tl_ch - 16) >> 3); tl_flush(TR == 1 ? 1 : 0, (uint32_t)(item - item_lo) * 2 + wv, tl_rec);)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chunk-stream form of the wave-pair kernel (round 6; 64-channel rows, two frames per item, power-of-two neighbour
+// frame count, 3-byte rows).  The timeline of the form above (profiles/r06_edge_timeline.txt) shows what a workgroup that
+// lives for one item -- two to three chunks -- spends outside its chunks: 37 % of a wavefront's life is the chain of
+// exposed round trips in front of the first chunk (kernel arguments and MLP weights, the row's extents, its first ids,
+// its first record), and a wavefront slot then idles ~2 300 cycles until the dispatcher has placed the next workgroup.
+// Here a workgroup is resident for the whole launch and walks the chunks of its items as ONE stream: the software
+// pipeline of the chunk loop (ids two chunks ahead, records one chunk ahead) runs across item boundaries, the row extents
+// of 64 items at a time sit in two registers (lane j = the workgroup's j-th item, read with v_readlane: no memory round
+// trip per item), and the centre's record is wave-uniform and comes through the scalar cache into SGPRs one chunk ahead
+// (12 VGPRs less, no vector-memory instruction).  An item boundary costs the pack + stores of the two finished rows and
+// nothing else.  Items go to workgroups round-robin (item_lo + blockIdx.x + j * gridDim.x): neighbouring workgroups read
+// neighbouring extents and write neighbouring rows, and a cloud's dense regions are spread over all of them.
+// Rows without neighbours are one chunk of zero frame-edges (every lane reads out of bounds: zero rows are stored).
+// ------------------------------------------------------------------------------------------------
+struct ChunkCursor {
+  int j;        // local item index; n_mine = past the end
+  int c0;       // first frame-edge of the chunk
+  int start;    // first edge of the item's centre point
+  int n_total;  // frame-edges of the item
+  int crow;     // this wavefront's centre row (record index)
+  uint32_t item;
+};
+
+template <int TR>
+__global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel(
+    EdgeGeom g, const uint32_t* __restrict__ feat, int64_t feat_rows, const float* __restrict__ axes_ext,
+    const float* __restrict__ rho_p, char* __restrict__ t_out, uint32_t item_lo, uint32_t item_hi, int fnb_shift) {
+  constexpr int C = 64, row_bytes = C * 4;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kcol = lane & 31, h = lane >> 5;
+  if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
+  __syncthreads();
+  const float rho = *rho_p;
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const __amdgpu_buffer_rsrc_t nbr_rs = buffer_of(g.nbr, g.n_edges * g.nbr_stride * 4);  // ids past the list read 0
+  const uint32_t groups = (uint32_t)g.f_ctr / 2u;
+  const uint32_t item0 = item_lo + blockIdx.x;
+  const int n_mine = (int)((item_hi - item0 + gridDim.x - 1) / gridDim.x);  // >= 1: the grid has at most one workgroup per item
+  const int fmask = (1 << fnb_shift) - 1;
+  const int hb = 16 * h;
+
+  // row extents of this workgroup's items (at most 64: the launcher sizes the grid): lane l holds the extents of local item l
+  int v_lo, v_hi;
+  {
+    const uint32_t item = item0 + (uint32_t)min(lane, n_mine - 1) * gridDim.x;
+    const uint32_t ctr = item / groups;
+    v_hi = g.ends[ctr];
+    v_lo = g.ends[max((int)ctr - 1, 0)];
+    if (ctr == 0) v_lo = 0;
+  }
+  // (every cursor field is wave-uniform; readfirstlane says so to the compiler: scalar registers, scalar branches)
+  auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  auto enter = [&](int j, int crow_keep, uint32_t item_keep) {  // first chunk of local item j, or the end mark
+    ChunkCursor c;
+    c.j = j, c.c0 = 0, c.start = 0, c.n_total = 0;
+    c.crow = crow_keep, c.item = item_keep;  // end mark: the last item's record stays the (valid) prefetch target
+    if (j < n_mine) {
+      const int lo = __builtin_amdgcn_readlane(v_lo, j), hi = __builtin_amdgcn_readlane(v_hi, j);
+      c.start = lo, c.n_total = (hi - lo) << fnb_shift;
+      c.item = item0 + (uint32_t)j * gridDim.x;
+      const uint32_t ctr = c.item / groups;
+      c.crow = uni((int)(ctr * (uint32_t)g.f_ctr + (c.item - ctr * groups) * 2u) + wv);
+    }
+    return c;
+  };
+  auto advance = [&](const ChunkCursor& c) {
+    ChunkCursor r = c;
+    if (c.c0 + 32 < c.n_total) r.c0 = c.c0 + 32;
+    else if (c.j < n_mine) r = enter(c.j + 1, c.crow, c.item);
+    r.j = uni(r.j), r.c0 = uni(r.c0), r.start = uni(r.start), r.n_total = uni(r.n_total), r.item = (uint32_t)uni((int)r.item);
+    return r;
+  };
+  auto fe_of = [&](const ChunkCursor& c) { return max(min(c.c0 + kcol, c.n_total - 1), 0); };
+  auto nbr_of = [&](const ChunkCursor& c) {
+    const int e = c.start + (fe_of(c) >> fnb_shift);
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(nbr_rs, (e * g.nbr_stride + g.nbr_offset) * 4, 0, 0);
+  };
+  auto row_of = [&](int nb, const ChunkCursor& c) { return (nb << fnb_shift) + (fe_of(c) & fmask); };
+  // the centre's record is wave-uniform: read through the scalar cache (constant address space + a uniform index = s_load)
+  typedef const f32x4 __attribute__((address_space(4))) * crec_t;
+  const crec_t ctr_rec = (crec_t)(uintptr_t)g.ctr_geom;
+  auto centre = [&](const ChunkCursor& c, float yc[3], float rc[9]) {
+    const int row = c.crow;
+    const f32x4 v0 = ctr_rec[row * 4], v1 = ctr_rec[row * 4 + 1], v2 = ctr_rec[row * 4 + 2];
+    yc[0] = v0[0], yc[1] = v0[1], yc[2] = v0[2], rc[8] = v0[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rc[i] = v1[i], rc[4 + i] = v2[i];
+  };
+
+  ChunkCursor cur, n1, n2;
+  cur = enter(0, 0, 0u);
+  n1 = advance(cur);
+  n2 = advance(n1);
+  // carried from chunk to chunk: the source rows of this chunk and of the next (ids consumed), this chunk's record
+  int q_cur, q_n1;
+  float xn_nx[3], rn_nx[9];
+  {
+    const int nb_cur = nbr_of(cur);
+    const int nb_n1 = nbr_of(n1);
+    q_cur = row_of(nb_cur, cur);
+    load_geom_record(nbg_rs, q_cur, xn_nx, rn_nx);
+    q_n1 = row_of(nb_n1, n1);
+    // (consumed in front of the loop like every chunk's loads are at its end, see below: the loop is entered with no load in flight)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(xn_nx[i]));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(rn_nx[i]));
+  }
+  float yc[3], rc[9];
+  centre(cur, yc, rc);
+  f32x16 acc[2] = {zero16(), zero16()};
+  int buf = 0;
+
+  while (cur.j < n_mine) {
+    const int cnt = min(32, cur.n_total - cur.c0);  // <= 0: a row without neighbours
+    // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
+    const int qoff = cur.c0 + kcol < cur.n_total ? q_cur * row_bytes : kOobOffset;
+    float xn[3], rn[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+    const int nb_n2 = nbr_of(n2);  // ids two chunks ahead
+
+    // gathered feature words for this wavefront's channels (shared by both frames): all loads go out now and are only
+    // turned into MFMA fragments after the barrier below
+    uint32_t fw[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+        fw[s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + (32 * wv + kcol) * 4, 0, 0);
+      }
+    load_geom_record(nbg_rs, q_n1, xn_nx, rn_nx);  // record one chunk ahead
+    float yn[3], rnc[9];
+    centre(n1, yn, rnc);  // the next chunk's centre (the same record until the item changes)
+
+    if (TR == 0)
+      edge_descriptor(xn, rn, yc, rc, rho, d);
+    else
+      edge_descriptor(yc, rc, xn, rn, rho, d);
+
+    // kernel MLP + GELU for this wavefront's frame; both lane halves hold the same descriptor: half 0 feeds dims 0..7,
+    // half 1 dims 8, 9
+    {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = h ? (j == 0 ? d[8] : (j == 1 ? 1.0f : 0.f)) : d[j];
+      u32x4 a_hi, a_lo;
+      frags_from_floats(v, a_hi, a_lo);
+      const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[0][0][lane][0]);
+      const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[0][1][lane][0]);
+      const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s * 16 < cnt) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
+          u32x4 b_hi, b_lo;
+          frags_from_floats(pv, b_hi, b_lo);
+          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][0][lane][0]) = b_hi;
+          *reinterpret_cast<u32x4*>(&lds_phi[buf][wv][s][1][lane][0]) = b_lo;
+        }
+      }
+    }
+    __syncthreads();  // both frames' fragments of this chunk are published (the other buffer is used by the next chunk)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s * 16 < cnt) {
+        u32x4 b_hi[2], b_lo[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          b_hi[a] = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][0][lane][0]);
+          b_lo[a] = *reinterpret_cast<const u32x4*>(&lds_phi[buf][a][s][1][lane][0]);
+        }
+        u32x4 fa_hi, fa_lo;
+        frags_from_words(fw[s], fa_hi, fa_lo);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) acc[a] = mfma_bf16x3(fa_hi, fa_lo, b_hi[a], b_lo[a], acc[a]);
+      }
+    }
+    // Every load this chunk issued is consumed HERE, in front of the stores: gfx9 counts loads and stores in one in-order
+    // counter, so a wait behind the stores for a load issued before them would be a wait for the stores (and the
+    // compiler's counts at the loop top must hold for the path without stores: they would drain them).  The next wait
+    // behind the stores is for the next chunk's feature words, a few thousand cycles away.
+    q_cur = q_n1;
+    q_n1 = row_of(nb_n2, n2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(xn_nx[i]));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(rn_nx[i]));
+    if (n1.j != cur.j) {
+      // the item's last chunk: acc[a] register r, lane (kcol, h) = T[row 2 item + a][32 wv + acc_row(r, h)][kcol] leaves
+      // as 3-byte rows (channels c, c + 1 of this lane = one hi word + one lo half-word), non-temporal
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        char* row = t_out + ((int64_t)cur.item * 2 + a) * t24_row_bytes(C);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          uint32_t hp, lp;
+          t24_pack2(acc[a][r], acc[a][r + 1], hp, lp);
+          const int idx = ((32 * wv + acc_row(r, h)) >> 1) * kBasis + kcol;
+          __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
+          __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2) + idx);
+        }
+        acc[a] = zero16();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yc[i] = yn[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rc[i] = rnc[i];
+    cur = n1, n1 = n2, n2 = advance(n2);
+    buf ^= 1;
   }
 }
 
@@ -581,6 +864,8 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
   // the final block reduction reuses the gT image (NW * 10 * 32 floats <= NIMG * NFR * CH16 * 512 words)
   float(*lds_red)[kDescExt][kBasis] = reinterpret_cast<float(*)[kDescExt][kBasis]>(&lds_gt[0][0][0][0][0][0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (parameter-gradient timeline: segment sums, words 0 .. 15 as named at the stamps; [16] items, [17] chunks, [18] first stamp, [19] last)
+  TL(__shared__ uint32_t tl_lds[NW][kTlWords]; uint32_t* tl_rec = tl_lds[wave]; tl_rec[lane] = 0u; uint32_t tl_prev = tl_now(); tl_rec[18] = tl_prev;)
   const int img = PAIR ? 0 : wave;  // which grad_T image this wavefront reads
   const int kcol = lane & 31, h = lane >> 5;
   // MLP weights [A; beta] as the MFMA B operand.  LEAN: arrangement 0 (lane half 0 holds descriptor dims 0..7, half 1
@@ -597,6 +882,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
   const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
   const __amdgpu_buffer_rsrc_t ctrg_rs = buffer_of(g.ctr_geom, g.n_ctr * g.f_ctr * 64);
   f32x16 dacc = zero16();  // lane (j = kcol, h), register r: d[A;beta][j][k = acc_row(r,h)]
+  TL(tl_seg(tl_rec, tl_prev, 0);)  // 0: arguments, MLP weights into LDS, barrier
 
   // Items are taken last-to-first: grad_T was written front-to-back by the GEMM just before this kernel, so its tail
   // (what fits the memory-side cache) is still on chip -- reading it first turns those rows into cache hits instead of
@@ -613,6 +899,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NFR;
     const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
     const int n_total = (g.ends[ctr] - start) * g.f_nb;
+    TL(tl_seg(tl_rec, tl_prev, 1); asm volatile("" ::"s"(n_total)); tl_seg(tl_rec, tl_prev, 2); tl_rec[16] += 1;)  // 1: item set-up issued, 2: row extents in
     if (n_total == 0) continue;  // uniform over the workgroup in the pair form: both wavefronts skip the item's barriers
     const int c_first = PAIR ? 32 * wave : 0;  // this wavefront's first chunk
     float yc[3], rc[9];
@@ -675,9 +962,11 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
           gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
                           : __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0);
     }
+    TL(tl_seg(tl_rec, tl_prev, 3); tl_pin(nb_a); tl_seg(tl_rec, tl_prev, 4);)  // 3: centre record, ids, grad_T row loads issued, 4: ids in
     int q_a = row_of(nb_a, c_first);
     float xn_nx[3], rn_nx[9];
     if (!(SE3_PG_ABLATE & 16)) load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
+    TL(tl_pin(gw[NBUILD - 1][CH16 - 1][7]); tl_seg(tl_rec, tl_prev, 5);)  // 5: grad_T words in
 #pragma unroll
     for (int ab = 0; ab < NBUILD; ++ab)
 #pragma unroll
@@ -696,7 +985,9 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         *reinterpret_cast<u32x4*>(&lds_gt[img][a][st][0][lane][0]) = f_hi;
         *reinterpret_cast<u32x4*>(&lds_gt[img][a][st][1][lane][0]) = f_lo;
       }
+    TL(tl_seg(tl_rec, tl_prev, 6);)  // 6: grad_T fragments built and parked
     if (PAIR) __syncthreads();  // both frames' images are in place
+    TL(tl_seg(tl_rec, tl_prev, 7);)  // 7: barrier (image complete)
 
     for (int c0 = c_first; c0 < n_total; c0 += CSTEP) {
       const int cnt = min(32, n_total - c0);
@@ -724,6 +1015,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       }
       if (LEAN) load_geom_record(ctrg_rs, ctr_row, yc, rc);
       q_a = q_b;
+      TL(tl_seg(tl_rec, tl_prev, 8); tl_pin(xn_nx[0]); tl_pin(rn_nx[7]); tl_pin(rn_nx[8]); tl_seg(tl_rec, tl_prev, 9); tl_rec[17] += 1;)  // 8: gathers issued, 9: this chunk's record in
 
       if (SE3_PG_ABLATE & 16) {
 #pragma unroll
@@ -874,9 +1166,11 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         continue;
       }
       // GELU' of both frames first (pure VALU, covers the gather latency) ...
+      TL(tl_seg(tl_rec, tl_prev, 10);)  // 10: descriptor, splits, descriptor image
       float dyv[NFR][16];
 #pragma unroll
       for (int a = 0; a < NFR; ++a) gelu_grad_of_frame(a, dyv[a]);
+      TL(tl_pin(dyv[NFR - 1][15]); tl_seg(tl_rec, tl_prev, 11); tl_pin(fw[CH16 - 1][7]); tl_seg(tl_rec, tl_prev, 12);)  // 11: kernel MLP + GELU', 12: feature words in
       // ... then the gathered words become fragments and both frames are accumulated
 #pragma unroll
       for (int st = 0; st < CH16; ++st) frags_from_words(fw[st], fa_hi[st], fa_lo[st]);
@@ -884,8 +1178,10 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       for (int a = 0; a < NFR; ++a) accumulate_frame(a, fa_hi, fa_lo, dyv[a]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      TL(tl_seg(tl_rec, tl_prev, 13);)  // 13: gphi, gpre, d[A;beta] products issued
     }
     if (PAIR) __syncthreads();  // both wavefronts are done with the images before the next item overwrites them
+    TL(tl_seg(tl_rec, tl_prev, 14);)  // 14: barrier (item done)
   }
 
   // dacc: rows = k (acc_row(r,h)), columns = descriptor dim j = kcol (only j < 10 are meaningful)
@@ -902,6 +1198,9 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     for (int w = 0; w < NW; ++w) sum += lds_red[w][j][k];
     partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kDescExt * kBasis + i] = sum;
   }
+  TL(tl_seg(tl_rec, tl_prev, 15); tl_rec[19] = tl_prev;  // 15: accumulator drain + workgroup reduction
+     tl_rec[20] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tl_rec[21] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+     tl_flush(2, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave, tl_rec);)
 }
 
 // [N,3] points + [N,F,9] frames -> one 64-byte record per (point, frame) row, see load_geom_record
@@ -1008,6 +1307,37 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
     const int64_t n_range = item_hi - item_lo;
     if (n_range <= 0) return SE3_OK;
+    // chunk-stream form (resident workgroups, the chunk pipeline running across item boundaries): 64-channel rows, two
+    // frames per item, power-of-two neighbour frame count, 3-byte rows; SE3_EDGE_STREAM=0 keeps the one-item workgroups
+    static const int stream_min_items = [] {
+      const char* e = getenv("SE3_EDGE_STREAM");
+      return e ? (atoi(e) > 0 ? atoi(e) : INT32_MAX) : 4096;
+    }();
+    if (channels == 64 && two && shift >= 0 && rowfmt == 1 && n_range >= stream_min_items && g.n_edges > 0 &&
+        g.n_edges * g.nbr_stride * 4 < (int64_t)kOobOffset && item_hi < (1ll << 31)) {
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      static const int per_cu = [] {
+        const char* e = getenv("SE3_EDGE_STREAM_WGS");
+        return e ? atoi(e) : 2 * SE3_PAIR_WAVES;  // 18 KB of LDS and <= 128 VGPRs: eight two-wavefront workgroups per CU
+      }();
+      int64_t wgs = (int64_t)n_cu * per_cu;
+      if (wgs < (n_range + 63) / 64) wgs = (n_range + 63) / 64;  // a workgroup keeps the extents of <= 64 items (one per lane)
+      if (wgs > n_range) wgs = n_range;
+      const dim3 sgrid((unsigned)wgs), sblock(128);
+      if (g.transposed)
+        hipLaunchKernelGGL((edge_t_stream_bf16_kernel<1>), sgrid, sblock, 0, stream, g, feat, feat_rows, axes_ext, rho,
+                           reinterpret_cast<char*>(t_out), (uint32_t)item_lo, (uint32_t)item_hi, shift);
+      else
+        hipLaunchKernelGGL((edge_t_stream_bf16_kernel<0>), sgrid, sblock, 0, stream, g, feat, feat_rows, axes_ext, rho,
+                           reinterpret_cast<char*>(t_out), (uint32_t)item_lo, (uint32_t)item_hi, shift);
+      return check_launch();
+    }
     const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
     const dim3 pgrid((unsigned)pblocks), pblock(128);
     // diagnostic knob (profiles/r05_fused_tile_ab.txt): SE3_PAIR_OCC=n caps the kernel at n wavefronts per SIMD by padding
