@@ -843,7 +843,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
                                                                          const float* __restrict__ rho_p,
                                                                          const uint32_t* __restrict__ grad_t,
                                                                          float* __restrict__ partials, int64_t n_items,
-                                                                         int fnb_shift, int64_t item_lo = 0) {
+                                                                         int fnb_shift, int64_t item_lo = 0, int pipe = 0) {
   // Rows wider than 64 channels are covered by blockIdx.y: block row y handles channels 64y .. 64y+63 (gphi, hence
   // d[A;beta], is linear in the channel sum, so every channel block contributes an independent partial; each block
   // row recomputes the descriptors and GELU').  row_ch = channels per row (a multiple of 16).
@@ -890,79 +890,119 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
 #ifndef SE3_PG_REVERSE
 #define SE3_PG_REVERSE 1
 #endif
-  for (int64_t item_f = PAIR ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * NW + wave; item_f < n_items;
-       item_f += PAIR ? (int64_t)gridDim.x : (int64_t)gridDim.x * NW) {
-    const int64_t item = item_lo + (SE3_PG_REVERSE ? n_items - 1 - item_f : item_f);  // items item_lo .. item_lo + n_items - 1
-    const int groups = g.f_ctr / NFR;
-    // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
-    const int64_t ctr = (uint32_t)item / (uint32_t)groups;
-    const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NFR;
-    const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
-    const int n_total = (g.ends[ctr] - start) * g.f_nb;
-    TL(tl_seg(tl_rec, tl_prev, 1); asm volatile("" ::"s"(n_total)); tl_seg(tl_rec, tl_prev, 2); tl_rec[16] += 1;)  // 1: item set-up issued, 2: row extents in
-    if (n_total == 0) continue;  // uniform over the workgroup in the pair form: both wavefronts skip the item's barriers
-    const int c_first = PAIR ? 32 * wave : 0;  // this wavefront's first chunk
-    float yc[3], rc[9];
-    const int ctr_row = (int)(ctr * g.f_ctr + a0 + (NFR == 2 ? h : 0));
-    if (!LEAN && !(SE3_PG_ABLATE & 16)) load_geom_record(ctrg_rs, ctr_row, yc, rc);  // LEAN: fetched again per chunk (a cache hit; 12 registers)
-
-    // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
-    auto nbr_of = [&](int c0) {
-      const int fe = min(c0 + kcol, n_total - 1);
-      const int e = start + (POW2 || fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
-      return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
-    };
-    auto row_of = [&](int nb, int c0) {
-      const int fe = min(c0 + kcol, n_total - 1);
-      return (POW2 ? nb << fnb_shift : nb * g.f_nb) + (POW2 || fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
-    };
-    const int nb_a = nbr_of(c_first);
-    int nb_b = nbr_of(c_first + CSTEP);
-
-    // gT fragments (MFMA B operand) of the item's two rows: lane (k = kcol, h) holds channels 16*st + 8h + j
-    // (pair form: this wavefront fetches and builds the image of frame `wave` only)
-    constexpr int NBUILD = PAIR ? 1 : NFR;
-    uint32_t gw[NBUILD][CH16][8];
-    if constexpr (GT16) {
-      // row `wave` of the item: mantissas of channel quad cq = c_off / 4 + 4 st + 2 h + jj at (cq * 32 + kcol) * 8; the
-      // exponents of both jj sit in one 8-byte group of the row's exponent plane (t16_exp_pos: mega tile = cq >> 1, piece
-      // = (kcol >> 1) & 7; byte (2 jj + (kcol >> 4)) * 2 + (kcol & 1))
-      const int64_t rbytes = t16_row_bytes(row_ch);
-      const uint64_t gt_addr = reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(grad_t) + (item * NFR + wave) * rbytes);
-      const uint64_t gt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gt_addr >> 32)) << 32) |
-                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gt_addr);
-      const __amdgpu_buffer_rsrc_t gt_rs = buffer_of(reinterpret_cast<const void*>(gt_base), rbytes);
-      const int cq0 = (c_off >> 2) + 2 * h;
-      const int e_off = row_ch * 64 + ((kcol >> 1) & 7) * 8, e_sh = 8 * ((kcol >> 4) * 2 + (kcol & 1));
-#pragma unroll
-      for (int st = 0; st < CH16; ++st) {
-        const auto m0 = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, ((cq0 + 4 * st) * kBasis + kcol) * 8, 0, 0);
-        const auto m1 = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, ((cq0 + 4 * st + 1) * kBasis + kcol) * 8, 0, 0);
-        const auto eg = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, e_off + ((cq0 + 4 * st) >> 1) * 64, 0, 0);
-        gw[0][st][0] = m0[0], gw[0][st][1] = m0[1], gw[0][st][2] = m1[0], gw[0][st][3] = m1[1];
-        gw[0][st][4] = (eg[0] >> e_sh) & 0xffu, gw[0][st][5] = (eg[1] >> e_sh) & 0xffu;
+  // Software pipeline over the items (round 6): the centre's record and the ids of an item's first two chunks are issued
+  // when this wavefront has finished its last chunk of the PREVIOUS item, i.e. in front of the barrier that frees the
+  // image, into registers that item no longer uses: the barrier wait (the partner wavefront still on its chunk: 12 % of a
+  // wavefront's life in profiles/r06_edge_timeline.txt) and those round trips overlap.  pipe: the row extents of the workgroup's items (at most
+  // 64, one per lane) are read once at the start and taken from there with v_readlane -- no extent -> ids -> rows chain
+  // per item.
+  const int64_t item_stride = PAIR ? (int64_t)gridDim.x : (int64_t)gridDim.x * NW;
+  const int groups = g.f_ctr / NFR;
+  int v_lo = 0, v_hi = 0;  // pipe: extents of local item `lane`
+  if (pipe) {
+    const int64_t item_f = min((int64_t)blockIdx.x + (int64_t)lane * item_stride, n_items - 1);
+    const uint32_t ctr = (uint32_t)(item_lo + (SE3_PG_REVERSE ? n_items - 1 - item_f : item_f)) / (uint32_t)groups;
+    v_hi = g.ends[ctr];
+    v_lo = g.ends[max((int)ctr - 1, 0)];
+    if (ctr == 0) v_lo = 0;
+  }
+  int64_t item_f = PAIR ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * NW + wave;
+  int64_t item = 0;
+  int start = 0, n_total = 0, ctr_row = 0, local_j = 0;
+  float yc[3], rc[9];
+  constexpr int NBUILD = PAIR ? 1 : NFR;
+  uint32_t gw[NBUILD][CH16][8];
+  int nb_a = 0, nb_b = 0;
+  const int c_first = PAIR ? 32 * wave : 0;  // this wavefront's first chunk
+  // ids two chunks ahead, geometry one chunk ahead (see edge_t_pair_bf16_kernel); indices past the end clamp
+  auto nbr_of = [&](int c0) {
+    const int fe = min(c0 + kcol, n_total - 1);
+    const int e = start + (POW2 || fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
+    return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
+  };
+  auto row_of = [&](int nb, int c0) {
+    const int fe = min(c0 + kcol, n_total - 1);
+    return (POW2 ? nb << fnb_shift : nb * g.f_nb) + (POW2 || fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
+  };
+  // the next item with neighbours at or behind item_f (items without any are skipped: uniform over the workgroup in the
+  // pair form, both wavefronts skip their barriers); false: none left
+  auto find_item = [&]() {
+    for (; item_f < n_items; item_f += item_stride, ++local_j) {
+      item = item_lo + (SE3_PG_REVERSE ? n_items - 1 - item_f : item_f);  // items item_lo .. item_lo + n_items - 1
+      // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
+      const int64_t ctr = (uint32_t)item / (uint32_t)groups;
+      const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NFR;
+      if (pipe) {
+        start = __builtin_amdgcn_readlane(v_lo, local_j);
+        n_total = (__builtin_amdgcn_readlane(v_hi, local_j) - start) * g.f_nb;
+      } else {
+        start = ctr > 0 ? g.ends[ctr - 1] : 0;
+        n_total = (g.ends[ctr] - start) * g.f_nb;
       }
-    } else
-#pragma unroll
-    for (int ab = 0; ab < NBUILD; ++ab) {
-      const int a = PAIR ? wave : ab;
-      const uint32_t* gt_row = grad_t + ((item * NFR + a) * (int64_t)row_ch + c_off) * kBasis;
-      // one buffer per row (its base is wave-uniform): channels past the row read as zeros through the bounds check of
-      // the buffer load -- a guarded global load per element compiled into a branch per load
-      const int row_left = min(row_ch - c_off, 16 * CH16);
-      // (`wave` is uniform but the compiler cannot know: without readfirstlane every load becomes a waterfall loop)
-      const uint64_t gt_addr = reinterpret_cast<uint64_t>(gt_row);
-      const uint64_t gt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gt_addr >> 32)) << 32) |
-                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gt_addr);  // (the builtin returns int)
-      const __amdgpu_buffer_rsrc_t gt_rs = buffer_of(reinterpret_cast<const void*>(gt_base), (int64_t)row_left * kBasis * 4);
-#pragma unroll
-      for (int st = 0; st < CH16; ++st)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
-                          : __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0);
+      ctr_row = (int)(ctr * g.f_ctr + a0 + (NFR == 2 ? h : 0));
+      TL(tl_rec[16] += 1;)
+      if (n_total != 0) return true;
     }
-    TL(tl_seg(tl_rec, tl_prev, 3); tl_pin(nb_a); tl_seg(tl_rec, tl_prev, 4);)  // 3: centre record, ids, grad_T row loads issued, 4: ids in
+    return false;
+  };
+  auto issue_item_loads = [&]() {
+    if (!LEAN && !(SE3_PG_ABLATE & 16)) load_geom_record(ctrg_rs, ctr_row, yc, rc);  // LEAN: fetched again per chunk (a cache hit; 12 registers)
+    nb_a = nbr_of(c_first);
+    nb_b = nbr_of(c_first + CSTEP);
+  };
+  // (the grad_T rows stay behind the barrier: their 32 registers in flight across it made the compiler spill 16 values
+  // around the chunk loop and reload them through the vector-memory queue in the middle of this very issue sequence --
+  // 0.41 -> 0.475 ms)
+  auto issue_image_loads = [&]() {
+    // gT fragments (MFMA B operand) of the item's two rows: lane (k = kcol, h) holds channels 16*st + 8h + j
+      // (pair form: this wavefront fetches and builds the image of frame `wave` only)
+      if constexpr (GT16) {
+        // row `wave` of the item: mantissas of channel quad cq = c_off / 4 + 4 st + 2 h + jj at (cq * 32 + kcol) * 8; the
+        // exponents of both jj sit in one 8-byte group of the row's exponent plane (t16_exp_pos: mega tile = cq >> 1, piece
+        // = (kcol >> 1) & 7; byte (2 jj + (kcol >> 4)) * 2 + (kcol & 1))
+        const int64_t rbytes = t16_row_bytes(row_ch);
+        const uint64_t gt_addr = reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(grad_t) + (item * NFR + wave) * rbytes);
+        const uint64_t gt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gt_addr >> 32)) << 32) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gt_addr);
+        const __amdgpu_buffer_rsrc_t gt_rs = buffer_of(reinterpret_cast<const void*>(gt_base), rbytes);
+        const int cq0 = (c_off >> 2) + 2 * h;
+        const int e_off = row_ch * 64 + ((kcol >> 1) & 7) * 8, e_sh = 8 * ((kcol >> 4) * 2 + (kcol & 1));
+#pragma unroll
+        for (int st = 0; st < CH16; ++st) {
+          const auto m0 = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, ((cq0 + 4 * st) * kBasis + kcol) * 8, 0, 0);
+          const auto m1 = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, ((cq0 + 4 * st + 1) * kBasis + kcol) * 8, 0, 0);
+          const auto eg = __builtin_amdgcn_raw_buffer_load_b64(gt_rs, e_off + ((cq0 + 4 * st) >> 1) * 64, 0, 0);
+          gw[0][st][0] = m0[0], gw[0][st][1] = m0[1], gw[0][st][2] = m1[0], gw[0][st][3] = m1[1];
+          gw[0][st][4] = (eg[0] >> e_sh) & 0xffu, gw[0][st][5] = (eg[1] >> e_sh) & 0xffu;
+        }
+      } else
+#pragma unroll
+      for (int ab = 0; ab < NBUILD; ++ab) {
+        const int a = PAIR ? wave : ab;
+        const uint32_t* gt_row = grad_t + ((item * NFR + a) * (int64_t)row_ch + c_off) * kBasis;
+        // one buffer per row (its base is wave-uniform): channels past the row read as zeros through the bounds check of
+        // the buffer load -- a guarded global load per element compiled into a branch per load
+        const int row_left = min(row_ch - c_off, 16 * CH16);
+        // (`wave` is uniform but the compiler cannot know: without readfirstlane every load becomes a waterfall loop)
+        const uint64_t gt_addr = reinterpret_cast<uint64_t>(gt_row);
+        const uint64_t gt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gt_addr >> 32)) << 32) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gt_addr);  // (the builtin returns int)
+        const __amdgpu_buffer_rsrc_t gt_rs = buffer_of(reinterpret_cast<const void*>(gt_base), (int64_t)row_left * kBasis * 4);
+#pragma unroll
+        for (int st = 0; st < CH16; ++st)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
+                            : __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0);
+      }
+  };
+  bool have = find_item();
+  TL(tl_seg(tl_rec, tl_prev, 1);)  // 1: item set-up (extents, rows)
+  if (have) issue_item_loads();
+  TL(tl_seg(tl_rec, tl_prev, 3);)  // 3: centre record, ids, grad_T row loads issued
+  while (have) {
+    issue_image_loads();
+    TL(tl_pin(nb_a); tl_seg(tl_rec, tl_prev, 4);)  // 4: ids in
     int q_a = row_of(nb_a, c_first);
     float xn_nx[3], rn_nx[9];
     if (!(SE3_PG_ABLATE & 16)) load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
@@ -1180,6 +1220,12 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       __builtin_amdgcn_wave_barrier();
       TL(tl_seg(tl_rec, tl_prev, 13);)  // 13: gphi, gpre, d[A;beta] products issued
     }
+    // this wavefront's chunks of the item are done: the next item's loads go out in front of the barrier
+    item_f += item_stride, ++local_j;
+    have = find_item();
+    TL(tl_seg(tl_rec, tl_prev, 1);)
+    if (have) issue_item_loads();
+    TL(tl_seg(tl_rec, tl_prev, 3);)
     if (PAIR) __syncthreads();  // both wavefronts are done with the images before the next item overwrites them
     TL(tl_seg(tl_rec, tl_prev, 14);)  // 14: barrier (item done)
   }
@@ -1475,29 +1521,34 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
         return e ? atoi(e) : (SE3_PG_PAIR_LEAN ? 8 : 6);  // 19 KB / 26 KB of LDS per workgroup
       }();
       int64_t wgs = (int64_t)n_cu * per_cu;
+      // extents in lane registers (pipe): a workgroup walks at most 64 items -- more workgroups than resident ones where
+      // the partial-sum slots allow it, the per-item extent loads otherwise
+      static const bool pipe_on = getenv("SE3_PG_PIPE") == nullptr || atoi(getenv("SE3_PG_PIPE")) != 0;
+      if (pipe_on && wgs < (n_range + 63) / 64) wgs = (n_range + 63) / 64;
       if (wgs > n_partials) wgs = n_partials;
       if (wgs > n_range) wgs = n_range;
       if (wgs < 1) wgs = 1;
+      const int pipe = pipe_on && (n_range + wgs - 1) / wgs <= 64 && item_lo + n_range < (1ll << 31) ? 1 : 0;
       *n_used = (int)wgs * blocks_y;
       const dim3 pgrid((unsigned)wgs, (unsigned)blocks_y);
       if (channels == 32 && shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<2, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo, pipe);
       else if (channels == 32)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<2, 2, true, false>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo, pipe);
       else if (gt16 && shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo, pipe);
       else if (gt16)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, false, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo, pipe);
       else if (shift >= 0)
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, true>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo, pipe);
       else
         hipLaunchKernelGGL((edge_param_grad_bf16_v2_kernel<4, 2, true, false>), pgrid, dim3(128), 0, stream, g, feat, channels,
-                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo);
+                           feat_rows, axes_ext, rho, grad_t, partials, n_range, shift, item_lo, pipe);
       return check_launch();
     }
     const int n_blocks = n_partials < 512 ? n_partials : 512;  // the 512-thread form: one workgroup per CU and round
