@@ -29,15 +29,8 @@
  *     caller streams per device own a set at a time: past that the least recently used set goes back to the spares
  *     and serves the next new caller stream (never rearranged while a capture is involved), so a process that makes
  *     a stream per request does not grow the table; (3) kernel-variant switches read ONCE from the environment at first
- *     use (A/B knobs, none changes results beyond rounding): SE3_NO_T24, SE3_OVERLAP, SE3_OVERLAP_ROWS,
- *     SE3_BWD_BRANCH_ORDER, SE3_NO_PAIR, SE3_FC1, SE3_PAIR_PERSIST, SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32),
- *     SE3_NN_SPLITS, SE3_T16_GT (SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too; slower),
- *     SE3_TR_MERGE_SORT (se3_csr_transpose*: the merge-sort form for every graph, same result), SE3_DX_PATH (feature
- *     gradient edge-major: 1 wherever implemented, 0 never; default: where it moves less than half the bytes),
- *     SE3_SLICE_MB (+ _STREAMS) (row-sliced schedule: every producer -> consumer pair of a row-sized intermediate per
- *     slice of at most that many MB, consumers on the side stream with SE3_SLICE_STREAMS=2; se3conv_fwd then uses the
- *     side-stream set of (2) too), SE3_PAIR_OCC (diagnostic: caps the wave-pair edge kernel at 1 - 3 wavefronts per
- *     SIMD by padding its LDS), SE3_NN_KG (=2: the dense products over 3-byte rows of under-filled levels run two k groups per workgroup; lost its A/B).  A side-stream set in use by a call is pinned: the cap never hands it to another caller.
+ *     use (A/B knobs, none changes results beyond rounding): listed in the appendix at the end of this header.  A
+ *     side-stream set in use by a call is pinned: the cap never hands it to another caller.
  *     `t_save` written by se3conv_fwd must be consumed by se3conv_bwd in the same process (same switches);
  *   - graph capture: every entry point that takes a stream can be captured into a HIP graph (no host synchronisation,
  *     nothing allocated) except the two-phase se3_ball_query_count / _store pair.  The library issues NO hipMemsetAsync
@@ -496,3 +489,27 @@ int se3_profile_tags(char* buf, size_t len);
 }
 #endif
 #endif /* SE3CONV_H_ */
+
+/*
+ * Appendix: environment switches (process-wide state (3) above).  Each is read once, at first use; none changes results
+ * beyond rounding; each is exercised by tests/test_gpu_variants.py.  What every switch measured: profiles/README.md,
+ * "Ledger of lost A/Bs".
+ *   SE3_NO_T24            T and U as packed hi/lo words instead of 3-byte rows
+ *   SE3_OVERLAP, SE3_OVERLAP_ROWS   two-stream backward pass (see se3_set_overlap_rows; opt-in since round 5)
+ *   SE3_BWD_BRANCH_ORDER  backward kernels branch by branch instead of writers first
+ *   SE3_NO_PAIR, SE3_FC1  single-wavefront edge kernel instead of the wave pair / one frame per wavefront
+ *   SE3_EDGE_STREAM       chunk-stream form of the wave-pair edge kernel (round 6): n > 0 = from n items up (default 4096,
+ *                         1 = every size), 0 = never
+ *   SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32)   forms of the parameter-gradient kernel
+ *   SE3_NN_SPLITS         split-K count of the dense products (default: cost model)
+ *   SE3_NN_KG             =2: two k groups per workgroup in the dense products over 3-byte rows of under-filled levels
+ *   SE3_T16_GT            SE3_PRECISION_BF16X3_T16 only: grad_T in the block format too
+ *   SE3_TR_MERGE_SORT     se3_csr_transpose*: the merge-sort form for every graph, same result
+ *   SE3_DX_PATH           feature gradient edge-major: 1 wherever implemented, 0 never; default: the two-term cost model of
+ *                         DESIGN.md section 4.11 (microseconds of either form; never above 20 edges per source row)
+ *   SE3_SLICE_MB (+ _STREAMS)   row-sliced schedule: every producer -> consumer pair of a row-sized intermediate per slice of
+ *                         at most that many MB, consumers on the side stream with SE3_SLICE_STREAMS=2 (se3conv_fwd then uses
+ *                         the side-stream set of (2) too).  SE3_SLICE_STREAMS=2 forks from the caller's stream: do NOT use it
+ *                         on a stream that is itself a forked branch of a graph capture (hipStreamEndCapture of this HIP
+ *                         runtime segfaults on nested forks, tools/probes/nested_fork_capture.py)
+ */

@@ -245,11 +245,9 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
   const int groups = g.f_ctr / NF;
   const int hb = 16 * h;
   int buf = 0;
-  // Persistent workgroups (SE3_PAIR_PERSIST): the block walks items blockIdx.x, blockIdx.x + gridDim.x, ... so that
-  // the kernel prologue (arguments, descriptors, MLP weights into LDS) is paid once per block, not once per item.
+  // One item per workgroup (the grid-stride loop runs once; resident workgroups are the chunk-stream kernel below).
   // (claiming the next item from a device counter instead of striding was measured in round 4: 65 536 returning atomics on
-  // one word take 0.74 ms by themselves, profiles/r04_vmem_diet_ab.txt; one item per workgroup lets the hardware dispatcher
-  // do the balancing)
+  // one word take 0.74 ms by themselves, profiles/r04_vmem_diet_ab.txt)
   for (int64_t item = item_lo + blockIdx.x; item < n_items; item += gridDim.x) {  // items item_lo .. n_items-1
   // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
   const int64_t ctr = (uint32_t)item / (uint32_t)groups;
@@ -1343,11 +1341,6 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     // a 128-thread workgroup per two frames of a point (even F) or per single row (odd F)
     const bool two = g.f_ctr % 2 == 0;
     const int64_t pair_items = two ? rows / 2 : rows;
-    // persistent blocks: enough to fill every CU at the kernel's occupancy, each walking a strided set of items
-    static const int persist = [] {
-      const char* e = getenv("SE3_PAIR_PERSIST");
-      return e ? atoi(e) : 0;
-    }();
     const int per = two ? 2 : 1;
     const int64_t item_lo = row_lo >= 0 ? row_lo / per : 0;
     const int64_t item_hi = row_lo >= 0 ? row_hi / per : pair_items;
@@ -1368,10 +1361,7 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
       }
-      static const int per_cu = [] {
-        const char* e = getenv("SE3_EDGE_STREAM_WGS");
-        return e ? atoi(e) : 2 * SE3_PAIR_WAVES;  // 18 KB of LDS and <= 128 VGPRs: eight two-wavefront workgroups per CU
-      }();
+      constexpr int per_cu = 2 * SE3_PAIR_WAVES;  // 18 KB of LDS and <= 128 VGPRs: eight two-wavefront workgroups per CU
       int64_t wgs = (int64_t)n_cu * per_cu;
       if (wgs < (n_range + 63) / 64) wgs = (n_range + 63) / 64;  // a workgroup keeps the extents of <= 64 items (one per lane)
       if (wgs > n_range) wgs = n_range;
@@ -1384,20 +1374,9 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
                            reinterpret_cast<char*>(t_out), (uint32_t)item_lo, (uint32_t)item_hi, shift);
       return check_launch();
     }
-    const int64_t pblocks = persist > 0 && n_range > persist ? persist : n_range;
-    const dim3 pgrid((unsigned)pblocks), pblock(128);
-    // diagnostic knob (profiles/r05_fused_tile_ab.txt): SE3_PAIR_OCC=n caps the kernel at n wavefronts per SIMD by padding
-    // every workgroup's LDS (dynamic shared memory nobody touches) -- what the edge phase of a register-resident fused
-    // tile would run at.  Same results at any n.
-    static const unsigned occ_pad = [] {
-      const char* e = getenv("SE3_PAIR_OCC");
-      const int n = e ? atoi(e) : 0;
-      if (n < 1 || n > 3) return 0u;
-      // 2n workgroups per CU on top of the kernel's 18 KB of static LDS: 64 / 36 / 25 KB per workgroup
-      return n == 1 ? 46u * 1024u : (n == 2 ? 18u * 1024u : 7u * 1024u);
-    }();
+    const dim3 pgrid((unsigned)n_range), pblock(128);
 #define SE3_PAIR_T(CT, FULL, NF, P2, TR)                                                                                \
-  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, occ_pad, stream, g, feat, channels, feat_rows, \
+  hipLaunchKernelGGL((edge_t_pair_bf16_kernel<CT, FULL, NF, P2, TR>), pgrid, pblock, 0, stream, g, feat, channels, feat_rows, \
                      axes_ext, rho, t_out, item_lo, item_hi, shift, rowfmt)
 #define SE3_PAIR_L(CT, FULL, NF, P2)                 \
   do {                                               \
@@ -1523,12 +1502,12 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       int64_t wgs = (int64_t)n_cu * per_cu;
       // extents in lane registers (pipe): a workgroup walks at most 64 items -- more workgroups than resident ones where
       // the partial-sum slots allow it, the per-item extent loads otherwise
-      static const bool pipe_on = getenv("SE3_PG_PIPE") == nullptr || atoi(getenv("SE3_PG_PIPE")) != 0;
-      if (pipe_on && wgs < (n_range + 63) / 64) wgs = (n_range + 63) / 64;
+      // (measured: profiles/r06_param_grad_pipeline_ab.txt -- the extent loads were never what the kernel waited on)
+      if (wgs < (n_range + 63) / 64) wgs = (n_range + 63) / 64;
       if (wgs > n_partials) wgs = n_partials;
       if (wgs > n_range) wgs = n_range;
       if (wgs < 1) wgs = 1;
-      const int pipe = pipe_on && (n_range + wgs - 1) / wgs <= 64 && item_lo + n_range < (1ll << 31) ? 1 : 0;
+      const int pipe = (n_range + wgs - 1) / wgs <= 64 && item_lo + n_range < (1ll << 31) ? 1 : 0;
       *n_used = (int)wgs * blocks_y;
       const dim3 pgrid((unsigned)wgs, (unsigned)blocks_y);
       if (channels == 32 && shift >= 0)

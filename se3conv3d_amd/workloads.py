@@ -3,8 +3,9 @@
 the layer.  Shared by ``bench.py``, ``tools/`` and ``tests/``; nothing here depends on the checker.
 
   headline        one cloud of 65 536 points, F = 2 random frames, C = 64, k ~ 32  -- BASELINE.json's metric
-  scannet150k_f1  one ScanNet-like scene of 150 000 points, F = 1 frame about the fixed up axis, C = 64
-                  (tasks/SemSeg/confs/scannet/scannet20_rot_pca_SO2.yaml:5,26,40; one scene per GPU = config 5)
+  scannet150k_f1  one ScanNet-like scene of 150 000 points, F = 1 frame about the fixed up axis, five levels of the widths the
+                  ScanNet network runs, 64/128/192/256/320 (round 6; four levels of 64 before)
+                  (tasks/SemSeg/confs/scannet/scannet20_rot_pca_SO2.yaml:5,26,40, seg_models.py:49-50; one scene per GPU = config 5)
   dfaust_f2       32 bodies x 2 200 points (4096 sampled, 0.04 grid), F = 2 PCA frames from 16-NN, level widths
                   32/64/128/256 (tasks/SemSeg/confs/dfaust/dfaust_I_rot_pca_2F.yaml:4,17,37-38; seg_models.py:26-27)
   dfaust_f4       16 bodies x 6 900 points, F = 4 PCA frames (the four sign flips of the eigenbasis)
@@ -22,8 +23,8 @@ import torch
 WORKLOADS: Dict[str, dict] = {
     "headline": dict(points=65536, clouds=1, frames=2, widths=[64, 64, 64, 64], degree=32, fixed_axis=False, pca=False,
                      note="4-level PNEConvLayerRotEquiv stack, N=65536, k=32, F=2, C=64"),
-    "scannet150k_f1": dict(points=150000, clouds=1, frames=1, widths=[64, 64, 64, 64], degree=32, fixed_axis=2, pca=False,
-                           note="4-level stack on one ScanNet-like scene of 150k points, F=1 about the fixed up axis, C=64"),
+    "scannet150k_f1": dict(points=150000, clouds=1, frames=1, widths=[64, 128, 192, 256, 320], degree=32, fixed_axis=2, pca=False,
+                           note="5-level stack on one ScanNet-like scene of 150k points, F=1 about the fixed up axis, C=64/128/192/256/320"),
     "dfaust_f2": dict(points=2200, clouds=32, frames=2, widths=[32, 64, 128, 256], degree=24, fixed_axis=False, pca=True,
                       note="4-level stack on a DFaust-like batch: 32 bodies x 2200 points, F=2 PCA frames, C=32/64/128/256"),
     "dfaust_f4": dict(points=6900, clouds=16, frames=4, widths=[32, 64, 128, 256], degree=24, fixed_axis=False, pca=True,
@@ -74,10 +75,13 @@ def build_cloud(spec: dict, device, seed: int, order: str = "random"):
     return _pc.PointcloudRotEquiv(pts, bid, frames_config(spec))
 
 
-def build_stack(spec: dict, device, seed: int, n_levels: int = 4, order: str = "random") -> List[dict]:
+def build_stack(spec: dict, device, seed: int, n_levels: int = 0, order: str = "random") -> List[dict]:
     """The stack of one rank: per level the cloud, its ball-query neighbourhood, a conv with converged EMA
-    buffers (rho = 1/r, nu = M/E), input features and an output gradient."""
+    buffers (rho = 1/r, nu = M/E), input features and an output gradient.  n_levels = 0: one level per entry of the
+    workload's widths."""
     from . import layers, pc as _pc
+
+    n_levels = n_levels or len(spec["widths"])
 
     r0 = radius_for_degree(spec["points"], spec["degree"])
     pc0 = build_cloud(spec, device, seed, order)
@@ -213,7 +217,7 @@ def stage_hbm_bytes(n: int, e: int, f: int, c: int, bytes_per_el=(3, 3, 4), kb: 
             for t, v in moved.items()}
 
 
-# ---- BASELINE config 2 at its own shapes: the 21 convolution calls of the reference's FAUST network -----------------------
+# ---- BASELINE configs 2 / 3 at their own shapes: the convolution calls of the reference's FAUST / ScanNet networks -----------
 def faust_network_calls(fixture_path: str) -> List[dict]:
     """The call list of the reference's FPNSegUNetMLPGeluRotEqFAUST as recorded from the reference itself
     (tests/golden/network_faust_calls.npz, tools/gen_golden.py `network_case`): per call the hierarchy level of the input
@@ -271,5 +275,64 @@ def build_faust_network_convs(device, fixture_path: str, bodies: int = 32, sampl
         g = torch.randn(n_out * 2, c["c_out"], device=device)
         recs.append(dict(name=f"call{i:02d}", pc_in=pc_in, pc_out=pc_out, nbh=nbh, conv=conv, x=x, g=g, n_in=n_in, n_out=n_out,
                          e=nbh.num_edges(), r=c["radius"], c_in=c["c_in"], c_out=c["c_out"], f=2, level_in=c["level_in"],
+                         level_out=c["level_out"]))
+    return recs
+
+
+def build_scannet_network_convs(device, fixture_path: str, scenes: int = 6, raw_points: int = 120000, seed: int = 0) -> List[dict]:
+    """BASELINE config 3 at the network's own shapes: the hierarchy the task script builds for a ScanNet batch
+    (tasks/SemSeg/train_scannet_rot.py:142-186 with confs/scannet/scannet20_rot_pca_SO2.yaml: scenes of up to 120 000 points,
+    init / output sub-sample 0.1, grid sub-samples 0.2 .. 1.6, PCA frames from 16-NN about the fixed axis 2, F = 1) on
+    synthetic rooms -- floor, ceiling, four walls and a few boxes of furniture, points on the surfaces with scanner noise --
+    and one bench record per convolution call of FPNSegUNetMLPGeluRotEqScanNet (call list recorded from the reference,
+    tests/golden/network_scannet_calls.npz: 32 calls, widths 64 .. 320, FPN laterals of width 128 onto level 0)."""
+    from . import layers, pc as _pc
+
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    parts, bids = [], []
+    for sc in range(scenes):
+        w, d, hgt = (float(v) for v in (torch.rand(3, generator=gen) * torch.tensor([4.0, 3.0, 0.6]) + torch.tensor([5.0, 4.0, 2.4])))
+        surf = [([0, 0, 0], [w, 0, 0], [0, d, 0]), ([0, 0, hgt], [w, 0, 0], [0, d, 0]),     # floor, ceiling
+                ([0, 0, 0], [w, 0, 0], [0, 0, hgt]), ([0, d, 0], [w, 0, 0], [0, 0, hgt]),     # walls
+                ([0, 0, 0], [0, d, 0], [0, 0, hgt]), ([w, 0, 0], [0, d, 0], [0, 0, hgt])]
+        for _ in range(6):  # furniture: top and two sides of a box
+            bx, by = (float(v) for v in torch.rand(2, generator=gen) * torch.tensor([w - 1.6, d - 1.2]))
+            bw, bd, bh = (float(v) for v in (torch.rand(3, generator=gen) * torch.tensor([1.0, 0.7, 0.6]) + torch.tensor([0.5, 0.4, 0.4])))
+            surf += [([bx, by, bh], [bw, 0, 0], [0, bd, 0]), ([bx, by, 0], [bw, 0, 0], [0, 0, bh]), ([bx, by, 0], [0, bd, 0], [0, 0, bh])]
+        area = torch.tensor([torch.linalg.cross(torch.tensor(u, dtype=torch.float32), torch.tensor(v, dtype=torch.float32)).norm() for _, u, v in surf])
+        counts = torch.round(area / area.sum() * raw_points).long()
+        for (o, u, v), n in zip(surf, counts.tolist()):
+            ab = torch.rand(n, 2, generator=gen)
+            parts.append(torch.tensor(o, dtype=torch.float32) + ab[:, :1] * torch.tensor(u, dtype=torch.float32) + ab[:, 1:] * torch.tensor(v, dtype=torch.float32)
+                         + torch.tensor([12.0 * sc, 0.0, 0.0]))
+            bids.append(torch.full((n,), sc, dtype=torch.int32))
+    pts = torch.cat(parts)
+    pts = (pts + 0.004 * torch.randn(pts.shape, generator=gen)).to(device)
+    bid = torch.cat(bids).to(device)
+    cfg = {"pca": True, "n_frames": 1, "fixed_axis": 2, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
+    raw = _pc.Pointcloud(pts, bid)
+    samp = _pc.GridSubSample(raw, 0.1)
+    pc0 = _pc.PointcloudRotEquiv(samp.__subsample_tensor__(raw.pts_, "avg"), samp.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
+    hier = _pc.PointHierarchyRotEquiv(pc0, 4, "grid_avg", grid_radii=[0.2, 0.4, 0.8, 1.6])
+    samp_out = _pc.GridSubSample(raw, 0.1, p_rnd_sample=True)
+    out_pc = _pc.PointcloudRotEquiv(samp_out.__subsample_tensor__(raw.pts_, "avg"),
+                                    samp_out.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
+    clouds = list(hier.pcs_) + [out_pc]
+    factory = layers.PNEConvLayerRotEquivFactory(9, NUM_BASIS, "mlp_gelu")
+    recs, nbhs = [], {}
+    for i, c in enumerate(faust_network_calls(fixture_path)):  # (the call-list reader is the same for both fixtures)
+        pc_in, pc_out = clouds[c["level_in"]], clouds[c["level_out"]]
+        key = (c["level_in"], c["level_out"], c["radius"])
+        if key not in nbhs:
+            nbhs[key] = _pc.BQNeighborhood(pc_in, pc_out, c["radius"])
+        nbh = nbhs[key]
+        conv = factory.create_conv_layer(c["c_in"], c["c_out"]).to(device)
+        conv.norm_neigh_dist_.fill_(1.0 / c["radius"])
+        conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.num_edges(), 1))
+        n_in, n_out = pc_in.pts_.shape[0], pc_out.pts_.shape[0]
+        x = torch.randn(n_in, c["c_in"], device=device, requires_grad=True)  # the first convolution is fed by the input embedding
+        g = torch.randn(n_out, c["c_out"], device=device)
+        recs.append(dict(name=f"call{i:02d}", pc_in=pc_in, pc_out=pc_out, nbh=nbh, conv=conv, x=x, g=g, n_in=n_in, n_out=n_out,
+                         e=nbh.num_edges(), r=c["radius"], c_in=c["c_in"], c_out=c["c_out"], f=1, level_in=c["level_in"],
                          level_out=c["level_out"]))
     return recs

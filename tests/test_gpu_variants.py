@@ -3,7 +3,6 @@ re-running a slice of the parity suite in a child process with the variable set:
 
   SE3_NO_PAIR=1     single-wavefront edge kernel instead of the wave-pair kernel for C = 64
   SE3_PG_SINGLE=1   one row per wavefront in the parameter-gradient kernel (what odd frame counts use)
-  SE3_PAIR_PERSIST=n  wave-pair edge kernel with n persistent workgroups walking strided items
   SE3_NO_T24=1      T and U as packed hi/lo words instead of the 3-byte row format (what C < 64 always uses)
   SE3_OVERLAP=1     backward branches on two streams at every size (default since round 5: never -- the fork lost its A/B,
                     profiles/r05_no_fork_ab.txt)
@@ -37,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (round 5: eight children over all three modes were 318 s of the 547 s suite)
 SLICE = "(golden or random_shapes or headline_subset or features_only or empty_rows) and bf16x3 and not t16"
 # independent switches share a child
-VARIANTS = ["SE3_NO_PAIR,SE3_PG_SINGLE", "SE3_NO_T24", "SE3_PAIR_PERSIST=64,SE3_BWD_BRANCH_ORDER,SE3_NN_KG=2", "SE3_OVERLAP",
+VARIANTS = ["SE3_NO_PAIR,SE3_PG_SINGLE", "SE3_NO_T24", "SE3_BWD_BRANCH_ORDER,SE3_NN_KG=2", "SE3_OVERLAP",
             "SE3_DX_PATH=1,SE3_EDGE_STREAM=1", "SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2"]
 
 

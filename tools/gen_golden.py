@@ -465,24 +465,73 @@ def pne_case(pclib, seed, n_in, n_out, c_in, c_out, k_deg, batches):
 
 
 
-def _seeded_conv_params(index, dims, c_in, num_basis, c_out):
-    """Parameters of conv call `index` of the network fixture, from a seed alone (the 21 convolutions of the reference's
-    FAUST network hold 9.2 M weights = 37 MB: the fixture stores the seeds' results as checksums, tests/test_gpu_network_replay.py
-    re-draws them with the same calls).  Same distributions as the reference's init (PNEConvLayer.py:79-88), biases
-    moved off zero."""
-    g = torch.Generator().manual_seed(7000 + index)
-    ba, bw = float(np.sqrt(1.0 / dims)), float(np.sqrt(1.0 / (c_in * num_basis)))
-    axes = (torch.rand(dims, num_basis, generator=g) * 2 - 1) * ba
-    biases = (torch.rand(num_basis, generator=g) * 2 - 1) * 0.5
-    weights = (torch.rand(c_in, num_basis, c_out, generator=g) * 2 - 1) * bw
-    return axes, biases, weights
-
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from seeded_params import seeded_conv_params as _seeded_conv_params  # noqa: E402  (shared with the tests that replay the fixtures)
 
 NET_SAMPLE = 2048  # entries of a weight gradient with more than 4 096 entries that the fixture keeps (seeded positions)
+OUT_SAMPLE = 2048  # "scannet": entries of an output / feature gradient with more than 8 192 entries that the fixture keeps
 
 
-def network_case(pclib, seed):
-    """BASELINE.json config 2: the reference's own FPNSegUNetMLPGeluRotEqFAUST (models/FPNSegUNet.py:198-223,
+def _faust_bodies(seed):
+    """Two synthetic bodies (thin shells around ellipsoids of roughly a torso's proportions), one constant input channel."""
+    def body(n, scale, g):
+        u = torch.randn(n, 3, generator=g)
+        u = u / u.norm(dim=1, keepdim=True)
+        return u * torch.tensor([0.25, 0.85, 0.15]) * scale + 0.01 * torch.randn(n, 3, generator=g)
+
+    g = torch.Generator().manual_seed(seed + 1)
+    n_raw = 1100
+    pts = torch.cat([body(n_raw, 0.40, g), body(n_raw, 0.34, g) + torch.tensor([2.0, 0.0, 0.0])])
+    bid = torch.cat([torch.zeros(n_raw, dtype=torch.int32), torch.ones(n_raw, dtype=torch.int32)])
+    return pts, bid, torch.ones(2 * n_raw, 1), g
+
+
+def _scannet_rooms(seed):
+    """Two synthetic rooms: floor, two walls and a box of furniture each, points on the surfaces with scanner noise; six
+    input columns (position copy + colour) as the ScanNet loader hands over, of which create_hierarchy keeps the last three
+    (tasks/SemSeg/train_scannet_rot.py:151-156)."""
+    g = torch.Generator().manual_seed(seed + 1)
+
+    def plane(n, origin, u, v):
+        ab = torch.rand(n, 2, generator=g)
+        return torch.tensor(origin) + ab[:, :1] * torch.tensor(u) + ab[:, 1:] * torch.tensor(v)
+
+    def room(w, d, hgt, n):
+        parts = [plane(n, [0., 0., 0.], [w, 0., 0.], [0., d, 0.]),              # floor
+                 plane(n // 2, [0., 0., 0.], [w, 0., 0.], [0., 0., hgt]),        # wall y = 0
+                 plane(n // 2, [0., 0., 0.], [0., d, 0.], [0., 0., hgt]),        # wall x = 0
+                 plane(n // 4, [0.4, 0.3, 0.3], [0.4, 0., 0.], [0., 0.3, 0.]),   # table top
+                 plane(n // 6, [0.4, 0.3, 0.], [0.4, 0., 0.], [0., 0., 0.3])]    # table front
+        p = torch.cat(parts)
+        return p + 0.004 * torch.randn(p.shape, generator=g)
+
+    r0, r1 = room(1.1, 0.9, 0.6, 1100), room(0.9, 1.0, 0.55, 1000)
+    pts = torch.cat([r0, r1 + torch.tensor([6.0, 1.0, 0.0])])
+    bid = torch.cat([torch.zeros(r0.shape[0], dtype=torch.int32), torch.ones(r1.shape[0], dtype=torch.int32)])
+    colour = torch.rand(pts.shape[0], 3, generator=g)
+    return pts, bid, torch.cat([pts, colour], 1), g
+
+
+NETWORKS = {
+    # BASELINE.json config 2: confs/dfaust/dfaust_I_rot_pca_2F.yaml
+    "faust": dict(model="FPNSegUNetMLPGeluRotEqFAUST", ctor=(1, 8, 0.5, 0.0), n_convs=21, param_base=7000, scene=_faust_bodies,
+                  drop_cols=0,
+                  md={"init_subsample": 0.04, "output_subsample": 0.04, "grid_subsamples": [0.05, 0.1, 0.2, 0.4],
+                      "RefFrames": {"pca": True, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}, "fixed_axis": False,
+                                    "n_frames": 2}}),
+    # BASELINE.json config 3: confs/scannet/scannet20_rot_pca_SO2.yaml:26-41 (init 0.1, grids 0.2 ... 1.6, PCA frames about the
+    # fixed axis 2, train_n_frames = 1), tasks/SemSeg/seg_models.py:39-58,90-95 (blocks [2,3,4,6,4], widths [64 ... 320], FPN 128)
+    "scannet": dict(model="FPNSegUNetMLPGeluRotEqScanNet", ctor=(3, 20, 0.5), n_convs=32, param_base=7100, scene=_scannet_rooms,
+                    drop_cols=3,
+                    md={"init_subsample": 0.1, "output_subsample": 0.1, "grid_subsamples": [0.2, 0.4, 0.8, 1.6],
+                        "RefFrames": {"pca": True, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}, "fixed_axis": 2,
+                                      "n_frames": 1}}),
+}
+
+
+def network_case(pclib, seed, net="faust"):
+    """BASELINE.json config 2 (net = "faust") / config 3 (net = "scannet", the reference's FPNSegUNetMLPGeluRotEqScanNet fed as
+    tasks/SemSeg/train_scannet_rot.py:142-186,262-290 does: 32 convolution calls, F = 1 frames about the up axis).  FAUST: the reference's own FPNSegUNetMLPGeluRotEqFAUST (models/FPNSegUNet.py:198-223,
     Encoder.py:116-173, FPNDecoder.py:87-137, tasks/SemSeg/seg_models.py:16-108) built by the reference, fed through the
     call sequence of the task script (create_hierarchy, tasks/SemSeg/train_dfaust_rot.py:108-158, with the configuration
     confs/dfaust/dfaust_I_rot_pca_2F.yaml: init / output sub-sample 0.04, grid sub-samples 0.05 ... 0.4, PCA frames from
@@ -504,27 +553,17 @@ def network_case(pclib, seed):
         seg = importlib.import_module("seg_models")
     torch.manual_seed(seed)
     np.random.seed(seed)
-    model = seg.FPNSegUNetMLPGeluRotEqFAUST(1, 8, 0.5, 0.0)
+    cfg = NETWORKS[net]
+    model = getattr(seg, cfg["model"])(*cfg["ctor"])
     convs = [m for m in model.modules() if isinstance(m, pclib.layers.PNEConvLayerRotEquiv)]
-    md = {"init_subsample": 0.04, "output_subsample": 0.04, "grid_subsamples": [0.05, 0.1, 0.2, 0.4],
-          "RefFrames": {"pca": True, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}, "fixed_axis": False, "n_frames": 2}}
-
-    def body(n, scale, g):  # a thin shell around an ellipsoid of roughly a torso's proportions
-        u = torch.randn(n, 3, generator=g)
-        u = u / u.norm(dim=1, keepdim=True)
-        return u * torch.tensor([0.25, 0.85, 0.15]) * scale + 0.01 * torch.randn(n, 3, generator=g)
-
-    g = torch.Generator().manual_seed(seed + 1)
-    n_raw = 1100
-    pts = torch.cat([body(n_raw, 0.40, g), body(n_raw, 0.34, g) + torch.tensor([2.0, 0.0, 0.0])])
-    bid = torch.cat([torch.zeros(n_raw, dtype=torch.int32), torch.ones(n_raw, dtype=torch.int32)])
-    feats = torch.ones(2 * n_raw, 1)
+    md = cfg["md"]
+    pts, bid, feats, g = cfg["scene"](seed)
     with torch.no_grad():  # create_hierarchy(p_init_subsample=True) of the task script
         pc = pclib.pc.Pointcloud(pts, bid)
         samp = pclib.pc.GridSubSample(pc, md["init_subsample"])
         new_pts = samp.__subsample_tensor__(pc.pts_, "avg")
         new_bid = samp.__subsample_tensor__(pc.batch_ids_, "max")
-        new_f = samp.__subsample_tensor__(feats, "avg")
+        new_f = samp.__subsample_tensor__(feats, "avg")[:, cfg["drop_cols"]:]
         new_pc = pclib.pc.PointcloudRotEquiv(new_pts, new_bid, md["RefFrames"])
         hier = pclib.pc.PointHierarchyRotEquiv(new_pc, len(md["grid_subsamples"]), "grid_avg", grid_radii=md["grid_subsamples"])
         radii = [md["init_subsample"]] + md["grid_subsamples"]
@@ -535,7 +574,7 @@ def network_case(pclib, seed):
     # seeded parameters (see _seeded_conv_params), in the order model.modules() lists the convolutions
     with torch.no_grad():
         for i, c in enumerate(convs):
-            a, b, w = _seeded_conv_params(i, 9, c.conv_weights_.shape[0], 32, c.conv_weights_.shape[2])
+            a, b, w = _seeded_conv_params(i, 9, c.conv_weights_.shape[0], 32, c.conv_weights_.shape[2], cfg["param_base"])
             c.proj_axes_.copy_(a), c.proj_biases_.copy_(b), c.conv_weights_.copy_(w)
     model.eval()
     model.start_pre_process()
@@ -561,7 +600,7 @@ def network_case(pclib, seed):
     y.backward(gy)
     for h in handles:
         h.remove()
-    assert len(calls) == len(convs) == 21
+    assert len(calls) == len(convs) == cfg["n_convs"], (len(calls), len(convs))
 
     clouds, nbhs = [], []
 
@@ -589,10 +628,17 @@ def network_case(pclib, seed):
         data[p + "rho"], data[p + "nu"] = mod.norm_neigh_dist_.numpy(), mod.norm_num_neighs_.numpy()
         data[p + "param_sums"] = np.array([float(t.detach().double().sum()) for t in (mod.proj_axes_, mod.proj_biases_, w)] +
                                           [float(w.detach().double().abs().sum())])
-        data[p + "x"], data[p + "out"] = kw["p_in_features"].detach().numpy(), rec["out"].detach().numpy()
+        data[p + "x"] = kw["p_in_features"].detach().numpy()
         data[p + "grad_out"] = rec["grad_out"].numpy()
-        if rec["dx"] is not None:
-            data[p + "dx"] = rec["dx"].numpy()
+        for key, t in (("out", rec["out"].detach()), ("dx", rec["dx"])):
+            if t is None:
+                continue
+            if net == "faust" or t.numel() <= 2 * OUT_SAMPLE:
+                data[p + key] = t.numpy()
+            else:  # seeded positions + the norm, like the large weight gradients
+                pos = torch.randperm(t.numel(), generator=torch.Generator().manual_seed(9500 + 2 * i + (key == "dx")))[:OUT_SAMPLE]
+                data[p + key + "_pos"], data[p + key + "_at"] = pos.numpy().astype(np.int32), t.reshape(-1)[pos].numpy()
+                data[p + key + "_norm"], data[p + key + "_shape"] = np.float64(t.double().norm()), np.array(t.shape, dtype=np.int32)
         data[p + "dA"], data[p + "dbeta"] = mod.proj_axes_.grad.numpy(), mod.proj_biases_.grad.numpy()
         dw = w.grad
         if dw.numel() <= 4096:
@@ -669,6 +715,15 @@ def main():
         print(f"{path}: calls={int(data['n_calls'])} clouds={int(data['n_clouds'])} nbhs={int(data['n_nbhs'])} "
               f"size={os.path.getsize(path) / 1e6:.2f} MB")
     if only == "network":
+        return
+    if only in ("", "scannet"):
+        path = os.path.join(OUT, "network_scannet_calls.npz")
+        data = network_case(pclib, 29, "scannet")
+        np.savez_compressed(path, **data)
+        print("level points:", [int(data[f"cloud{i}/pts"].shape[0]) for i in range(int(data["n_clouds"]))])
+        print(f"{path}: calls={int(data['n_calls'])} clouds={int(data['n_clouds'])} nbhs={int(data['n_nbhs'])} "
+              f"size={os.path.getsize(path) / 1e6:.2f} MB")
+    if only == "scannet":
         return
     if only in ("", "block"):
         path = os.path.join(OUT, "resnetformer_block.npz")
