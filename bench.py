@@ -91,7 +91,12 @@ def launch_ranks(args, argv) -> int:
 
 # ------------------------------------------------------------------------------------------ the step
 def step(levels):
+    from se3conv3d_amd import ops as _ops
+
     for lv in levels:
+        # a training step builds its clouds anew (the task scripts' create_hierarchy): the geometry records a cloud's
+        # convolutions share are rebuilt once per step here too, inside the timed region
+        _ops.invalidate_prepared(lv["pc"])
         lv["x"].grad = None
         for p in lv["conv"].parameters():
             p.grad = None
@@ -125,6 +130,11 @@ class GraphedStep:
 
 def step_two_clouds(rec, nbh=None):
     """Forward + backward of one level-to-level convolution (workloads.build_down_up)."""
+    from se3conv3d_amd import ops as _ops
+
+    if rec.get("own_clouds", True):  # (a network's call list shares its clouds between calls: its driver invalidates them once per step)
+        _ops.invalidate_prepared(rec["pc_in"])
+        _ops.invalidate_prepared(rec["pc_out"])
     rec["x"].grad = None
     for p in rec["conv"].parameters():
         p.grad = None

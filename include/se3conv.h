@@ -113,7 +113,10 @@ typedef struct se3conv_shape {
  * se3conv_intermediate_row_bytes added. */
 /* 4 = round 4: se3_csr_transpose / _bounded and se3conv_bwd take `t_edge_ids` (optional).
  * (round 5 added se3_set_overlap_rows and se3conv_bwd_needs_t; no signature changed.) */
-#define SE3_ABI_VERSION 4
+/* 5 = round 6: se3conv_fwd_prepared / se3conv_bwd_prepared (operands prepared once per step and shared between calls:
+ * struct se3conv_prepared) added; the version also covers round 5's two additions, so that a binding that needs them
+ * and meets an older library fails with the "rebuild" message instead of a missing symbol. */
+#define SE3_ABI_VERSION 5
 int se3_abi_version(void);
 const char* se3_error_string(int code);
 /* Bytes per element of the row-sized intermediates [rows, C, K] the operator moves through memory for this shape --
@@ -368,6 +371,42 @@ int se3conv_bwd(const float* pts_in, const float* pts_out, const float* frames_i
                 const se3conv_shape* shape, float* grad_feat, float* grad_axes,
                 float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
                 void* stream);
+
+/* Operands the library derives from a call's inputs before its first kernel can run, kept by the CALLER across calls
+ * (round 6; the reference has no counterpart: its get_rot_tenors memo, PNEConvLayerRotEquiv.py:53,71-126, is the closest
+ * thing -- a per-neighbourhood cache of the descriptors -- and costs a device-to-host copy and a SHA-256 per call):
+ *   geom_in / geom_out   packed 64-byte geometry records of the input / output cloud, [rows, 16] fp32 with rows = points x
+ *                        frames: a function of the cloud alone, so every convolution that touches the cloud in a step --
+ *                        forward and backward, every layer of a level -- can share one image (same cloud on both sides:
+ *                        pass the same pointer twice);
+ *   feat_words           packed hi | lo words of the input features, [N_in*F_in*C_in] uint32 (split-bf16 modes only):
+ *                        written by the forward call, read again by the backward call of the same layer.
+ * A pointer may be NULL (the call then builds that operand in its workspace as se3conv_fwd / se3conv_bwd do).  `*_valid`
+ * = 0: the buffer is filled by THIS call, inside its one preparation launch (no extra launch), and may be handed to later
+ * calls with `*_valid` = 1; the struct itself is never written.  The caller owns validity: records follow their cloud's
+ * points and frames, feature words the features.  Inside a captured graph the call that fills a buffer and the calls
+ * that read it must be captured together (a replay re-runs the fill). */
+typedef struct se3conv_prepared {
+  float* geom_in;
+  float* geom_out;
+  uint32_t* feat_words;
+  int32_t geom_in_valid, geom_out_valid, feat_words_valid;
+} se3conv_prepared;
+/* se3conv_fwd / se3conv_bwd with `prepared` (NULL = exactly those calls).  K != 32 ignores it. */
+int se3conv_fwd_prepared(const float* pts_in, const float* pts_out, const float* frames_in,
+                         const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                         const float* feat, const float* proj_axes, const float* proj_biases,
+                         const float* conv_weights, const float* rho, const float* nu,
+                         const se3conv_shape* shape, float* out, float* t_save, void* workspace,
+                         size_t workspace_bytes, void* stream, const se3conv_prepared* prepared);
+int se3conv_bwd_prepared(const float* pts_in, const float* pts_out, const float* frames_in,
+                         const float* frames_out, const int32_t* neighbors, const int32_t* ends,
+                         const int32_t* t_samples, const int32_t* t_ends, const int32_t* t_edge_ids, const float* feat,
+                         const float* proj_axes, const float* proj_biases, const float* conv_weights,
+                         const float* rho, const float* nu, const float* t_save, const float* grad_out,
+                         const se3conv_shape* shape, float* grad_feat, float* grad_axes,
+                         float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
+                         void* stream, const se3conv_prepared* prepared);
 
 /* ---------------------------------------------------------------------------------------------
  * reference frames (scope row f-1: upstream of the operator, frames are an input of the hot path)

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", f"libse3conv_hip{os.environ.get('SE3_LIB_SUFFIX', '')}.so")  # suffix: variant builds, see build.py
 
 SE3_OK = 0
-ABI_VERSION = 4  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
+ABI_VERSION = 5  # SE3_ABI_VERSION of include/se3conv.h these signatures were written against
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x3_t16": 2}
 REL_ROT = {"6D": (0, 9), "matrix": (1, 12), "quaternion": (2, 7)}  # p_rel_rot -> (SE3_REL_ROT_*, descriptor dims)
 
@@ -24,6 +24,13 @@ class Se3Shape(C.Structure):
         ("f_in", C.c_int32), ("f_out", C.c_int32), ("c_in", C.c_int32), ("c_out", C.c_int32),
         ("num_basis", C.c_int32), ("precision", C.c_int32),
     ]
+
+
+class Se3Prepared(C.Structure):
+    """struct se3conv_prepared (include/se3conv.h): operands kept by the caller across calls."""
+
+    _fields_ = [("geom_in", C.c_void_p), ("geom_out", C.c_void_p), ("feat_words", C.c_void_p),
+                ("geom_in_valid", C.c_int32), ("geom_out_valid", C.c_int32), ("feat_words_valid", C.c_int32)]
 
 
 class Se3LibraryError(RuntimeError):
@@ -70,6 +77,8 @@ SIGNATURES = {
     "se3conv_bwd_workspace_bytes": (_SZ, [_SHP, C.c_int, C.c_int, C.c_int]),
     "se3conv_bwd_needs_t": (C.c_int, [_SHP, C.c_int]),
     "se3conv_bwd": (C.c_int, [_P] * 17 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P]),
+    "se3conv_fwd_prepared": (C.c_int, [_P] * 12 + [_SHP, _P, _P, _P, _SZ, _P, C.POINTER(Se3Prepared)]),
+    "se3conv_bwd_prepared": (C.c_int, [_P] * 17 + [_SHP, _P, _P, _P, _P, _P, _SZ, _P, C.POINTER(Se3Prepared)]),
     "se3_knn_query": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "se3_knn_query_pair": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I32, _P, _P]),
     "se3_grid_pick": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
@@ -109,13 +118,14 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -m se3conv3d_amd.build` "
             "(there is deliberately no CPU fallback for the HIP path)")
     lib = C.CDLL(LIB_PATH)
+    lib.se3_abi_version.restype = C.c_int
+    if lib.se3_abi_version() != ABI_VERSION:  # (checked before the symbols: an older library lacks some of them)
+        raise Se3LibraryError(f"{LIB_PATH} has ABI version {lib.se3_abi_version()}, this binding expects {ABI_VERSION}: "
+                              "rebuild it (`python -m se3conv3d_amd.build`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.se3_abi_version() != ABI_VERSION:
-        raise Se3LibraryError(f"{LIB_PATH} has ABI version {lib.se3_abi_version()}, this binding expects {ABI_VERSION}: "
-                              "rebuild it (`python -m se3conv3d_amd.build`)")
     _lib = lib
     return lib
 

@@ -716,6 +716,23 @@ se3conv_shape with_32_basis(const se3conv_shape* s) {
   return t;
 }
 
+// Where a call's geometry records live and which of them it has to build: the caller's buffers (se3conv_prepared) where it
+// keeps them, the workspace otherwise; a cloud against itself has one set of records for both sides.
+struct PreparedGeometry {
+  float *in, *out;
+  bool need_in, need_out;
+};
+PreparedGeometry prepared_geometry(const se3conv_prepared* prep, bool same_cloud, float* ws_in, float* ws_out) {
+  PreparedGeometry g{ws_in, ws_out, true, true};
+  if (prep && prep->geom_in) g.in = prep->geom_in, g.need_in = !prep->geom_in_valid;
+  if (same_cloud) {
+    g.out = g.in, g.need_out = false;
+    return g;
+  }
+  if (prep && prep->geom_out) g.out = prep->geom_out, g.need_out = !prep->geom_out_valid;
+  return g;
+}
+
 EdgeGeom forward_geom(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
                       const int32_t* neighbors, const int32_t* ends, const se3conv_shape* s) {
   EdgeGeom g{};
@@ -881,6 +898,15 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
                            const float* proj_biases, const float* conv_weights, const float* rho, const float* nu,
                            const se3conv_shape* s, float* out, float* t_save, void* workspace, size_t workspace_bytes,
                            void* stream_) {
+  return se3conv_fwd_prepared(pts_in, pts_out, frames_in, frames_out, neighbors, ends, feat, proj_axes, proj_biases, conv_weights,
+                              rho, nu, s, out, t_save, workspace, workspace_bytes, stream_, nullptr);
+}
+
+extern "C" int se3conv_fwd_prepared(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
+                                    const int32_t* neighbors, const int32_t* ends, const float* feat, const float* proj_axes,
+                                    const float* proj_biases, const float* conv_weights, const float* rho, const float* nu,
+                                    const se3conv_shape* s, float* out, float* t_save, void* workspace, size_t workspace_bytes,
+                                    void* stream_, const se3conv_prepared* prep) {
   if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
   if (s->num_basis != kBasis) {
     // slices of 32 basis functions on the K = 32 operator (see slice_params_kernel); t_save is not written
@@ -924,21 +950,24 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   const int ck = s->c_in * s->num_basis;
   const float inv_fin = 1.0f / (float)s->f_in;
   // einsum('nik,iko->no') :210, /F_in :213, *norm_num_neighs_ :216 are the GEMM + its alpha
-  float* geom_in = (float*)(ws + l.geom_in);
-  float* geom_out = (float*)(ws + l.geom_out);
   const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
-  if (same_cloud) geom_out = geom_in;  // a cloud against itself: one set of records serves both sides
+  // the caller's records where it keeps them (se3conv_prepared), the workspace otherwise; `need_*`: built by this call
+  const PreparedGeometry pg = prepared_geometry(prep, same_cloud, (float*)(ws + l.geom_in), (float*)(ws + l.geom_out));
+  float* geom_in = pg.in;
+  float* geom_out = pg.out;
   if (s->precision == SE3_PRECISION_FP32) {
     PrepBatch pb;  // one launch: [A; beta] table and the packed geometry records
     pb.axes(proj_axes, proj_biases, axes_ext);
-    pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
-    if (!same_cloud) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    if (pg.need_in) pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+    if (pg.need_out) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
     if (int rc = launch_edge_t("edge_t_fwd", g, feat, s->c_in, s->n_in * s->f_in, axes_ext, rho, t, stream)) return rc;
     return launch_gemm_nn("gemm_out", t, conv_weights, out, rows_out, s->c_out, ck, nu, inv_fin, stream, (float*)(ws + l.split));
   }
-  uint32_t* featpk = (uint32_t*)(ws + l.featpk);
+  // (packed feature words: into the caller's buffer where backward will want them again)
+  uint32_t* featpk = prep && prep->feat_words ? prep->feat_words : (uint32_t*)(ws + l.featpk);
+  const bool need_featpk = !(prep && prep->feat_words && prep->feat_words_valid);
   uint16_t* bt_hi = (uint16_t*)(ws + l.bt_hi);
   uint16_t* bt_lo = (uint16_t*)(ws + l.bt_lo);
   const float inv_phi = inv_fin / kGeluOut;  // the bf16 edge kernels produce kGeluOut * phi (gelu_scaled)
@@ -946,9 +975,9 @@ extern "C" int se3conv_fwd(const float* pts_in, const float* pts_out, const floa
   {  // one launch: [A; beta] table, packed geometry records, packed feature words, weight planes
     PrepBatch pb;
     pb.axes(proj_axes, proj_biases, axes_ext);
-    pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
-    if (!same_cloud) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
-    pb.split(feat, featpk, s->n_in * s->f_in * s->c_in);
+    if (pg.need_in) pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+    if (pg.need_out) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    if (need_featpk) pb.split(feat, featpk, s->n_in * s->f_in * s->c_in);
     pb.weights(conv_weights, s->c_in, s->num_basis, s->c_out, 0, bt_hi, bt_lo, nullptr, 1.0f, false, t24);
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
@@ -1010,6 +1039,18 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
                            const float* grad_out, const se3conv_shape* s, float* grad_feat, float* grad_axes,
                            float* grad_biases, float* grad_weights, void* workspace, size_t workspace_bytes,
                            void* stream_) {
+  return se3conv_bwd_prepared(pts_in, pts_out, frames_in, frames_out, neighbors, ends, t_samples, t_ends, t_edge_ids, feat, proj_axes,
+                              proj_biases, conv_weights, rho, nu, t_save, grad_out, s, grad_feat, grad_axes, grad_biases, grad_weights,
+                              workspace, workspace_bytes, stream_, nullptr);
+}
+
+extern "C" int se3conv_bwd_prepared(const float* pts_in, const float* pts_out, const float* frames_in, const float* frames_out,
+                                    const int32_t* neighbors, const int32_t* ends, const int32_t* t_samples,
+                                    const int32_t* t_ends, const int32_t* t_edge_ids, const float* feat, const float* proj_axes,
+                                    const float* proj_biases, const float* conv_weights, const float* rho, const float* nu,
+                                    const float* t_save, const float* grad_out, const se3conv_shape* s, float* grad_feat,
+                                    float* grad_axes, float* grad_biases, float* grad_weights, void* workspace,
+                                    size_t workspace_bytes, void* stream_, const se3conv_prepared* prep) {
   if (!shape_ok(s)) return SE3_ERR_INVALID_ARGUMENT;
   if (s->num_basis != kBasis) {
     // slices of 32 basis functions (see slice_params_kernel): T is recomputed per slice (t_save ignored), dX is the sum of
@@ -1077,14 +1118,14 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
 
   if (s->precision == SE3_PRECISION_FP32) {
     {  // one launch: [A; beta] table and the packed geometry records of both sides
-      float* geom_in = (float*)(ws + l.geom_in);
-      float* geom_out = (float*)(ws + l.geom_out);
       const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
+      const PreparedGeometry pg = prepared_geometry(prep, same_cloud, (float*)(ws + l.geom_in), (float*)(ws + l.geom_out));
+      float* geom_in = pg.in;
+      float* geom_out = pg.out;
       PrepBatch pb;
       pb.axes(proj_axes, proj_biases, axes_ext);
-      pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
-      if (same_cloud) geom_out = geom_in;
-      else pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+      if (pg.need_in) pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+      if (pg.need_out) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
       if (int rc = pb.launch(stream)) return rc;
       g.ctr_geom = geom_out, g.nb_geom = geom_in;
       gt.ctr_geom = geom_in, gt.nb_geom = geom_out;
@@ -1136,7 +1177,9 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   uint16_t* bx_hi = (uint16_t*)(ws + l.bt2_hi);   // feature branch: grad_X weights
   uint16_t* bx_lo = (uint16_t*)(ws + l.bt2_lo);
   uint32_t* gpk = (uint32_t*)(ws + l.gpk);
-  uint32_t* featpk = (uint32_t*)(ws + l.featpk);
+  // (the packed feature words the forward call left with the caller, se3conv_prepared, or this call's own)
+  const bool have_featpk = prep && prep->feat_words && prep->feat_words_valid;
+  uint32_t* featpk = prep && prep->feat_words ? prep->feat_words : (uint32_t*)(ws + l.featpk);
   uint32_t* bigw = (uint32_t*)big;
   const float inv_phi = inv_fin / kGeluOut;  // T and U hold kGeluOut * (the reference's values), see gelu_scaled
   const bool feat_branch = want_feat && rows_in > 0;
@@ -1146,17 +1189,17 @@ extern "C" int se3conv_bwd(const float* pts_in, const float* pts_out, const floa
   const bool edge_dx = use_edge_dx(s, want_feat, want_params) && feat_branch;         // feature gradient edge-major (edge_dx.hip)
   const bool gt16 = strip_t && !edge_dx && grad_t_t16(s, g);                          // ... written as T16 rows
   {  // one launch: [A; beta] table, packed geometry records, packed words of g and f, weight planes
-    float* geom_in = (float*)(ws + l.geom_in);
-    float* geom_out = (float*)(ws + l.geom_out);
     const bool same_cloud = pts_in == pts_out && frames_in == frames_out && s->n_in == s->n_out && s->f_in == s->f_out;
+    const PreparedGeometry pg = prepared_geometry(prep, same_cloud, (float*)(ws + l.geom_in), (float*)(ws + l.geom_out));
+    float* geom_in = pg.in;
+    float* geom_out = pg.out;
     PrepBatch pb;
     pb.axes(proj_axes, proj_biases, axes_ext);
-    pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
-    if (same_cloud) geom_out = geom_in;
-    else pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
+    if (pg.need_in) pb.geometry(pts_in, frames_in, s->n_in, s->f_in, geom_in);
+    if (pg.need_out) pb.geometry(pts_out, frames_out, s->n_out, s->f_out, geom_out);
     pb.split(grad_out, gpk, rows_out * s->c_out);
     if (feat_branch && !edge_dx) pb.weights(conv_weights, s->c_in, kb, s->c_out, 2, bx_hi, bx_lo, nullptr, 1.0f, false, t24_u);
-    if (want_params) pb.split(feat, featpk, rows_in * s->c_in);
+    if (want_params && !have_featpk) pb.split(feat, featpk, rows_in * s->c_in);
     if (want_params || edge_dx)
       // alpha = nu/F_in is folded into these weights (one multiply per weight instead of one per grad_T element)
       pb.weights(conv_weights, s->c_in, kb, s->c_out, 1, bt_hi, bt_lo, nu, inv_fin, strip_t, 0, gt16);

@@ -121,6 +121,9 @@ def _geometry_of(p_pc_in, p_pc_out, p_neighborhood) -> ops.ConvGeometry:
     if geom.symmetric:
         geom.sources = getattr(p_neighborhood, "sources_i32_", None)
     geom.source_major_fn = getattr(p_neighborhood, "source_major", None)
+    # the clouds' packed geometry records: built once per cloud by whichever call meets them first, shared by every other
+    geom.records_in = ops.prepared_records(p_pc_in)
+    geom.records_out = geom.records_in if p_pc_out is p_pc_in else ops.prepared_records(p_pc_out)
     try:
         p_neighborhood._se3_geom = (key, geom)
     except AttributeError:

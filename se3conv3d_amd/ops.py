@@ -602,6 +602,48 @@ def pca_frames(pts, knn_ids, axis_fixed=None) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------- the operator's geometry bundle
+class PreparedRecords:
+    """The packed 64-byte geometry records of one cloud (include/se3conv.h, struct se3conv_prepared): a function of the
+    cloud's points and frames alone, so every convolution that touches the cloud -- forward and backward, every layer of a
+    level -- shares one image.  The first call that meets an invalid holder fills it inside its own preparation launch.
+    Kept on the cloud object (``prepared_records``); re-validated against the tensors' storage and version counters."""
+
+    __slots__ = ("tensor", "valid", "key")
+
+    def __init__(self):
+        self.tensor, self.valid, self.key = None, False, None
+
+    def bind(self, pts: torch.Tensor, frames: torch.Tensor) -> "PreparedRecords":
+        key = (pts.data_ptr(), pts._version, frames.data_ptr(), frames._version, tuple(frames.shape), str(pts.device))
+        if key != self.key:
+            rows = frames.shape[0] * frames.shape[1]
+            if self.tensor is None or self.tensor.shape[0] != rows or self.tensor.device != pts.device:
+                self.tensor = torch.empty((rows, 16), dtype=torch.float32, device=pts.device)
+            self.key, self.valid = key, False
+        return self
+
+
+def prepared_records(cloud) -> Optional["PreparedRecords"]:
+    """The holder of ``cloud``'s geometry records, created on first use and kept on the object (any object that takes an
+    attribute: the reference's own containers and plain namespaces too); None when it cannot be attached."""
+    holder = getattr(cloud, "_se3_records_", None)
+    if holder is None:
+        holder = PreparedRecords()
+        try:
+            cloud._se3_records_ = holder
+        except (AttributeError, TypeError):
+            return None
+    return holder
+
+
+def invalidate_prepared(cloud) -> None:
+    """Forget the cloud's prepared records (the next convolution that touches the cloud rebuilds them): what a new step
+    does implicitly by building new cloud objects; a benchmark that re-uses its clouds calls this once per step."""
+    holder = getattr(cloud, "_se3_records_", None)
+    if holder is not None:
+        holder.valid = False
+
+
 @dataclass
 class ConvGeometry:
     """Everything the operator reads besides features and parameters (all fp32 / int32, GPU)."""
@@ -622,6 +664,9 @@ class ConvGeometry:
     # the neighbourhood's own way to the source-major list (pc.BQNeighborhood.source_major), or None
     source_major_fn: Optional[Callable[[], Optional[Tuple[torch.Tensor, torch.Tensor]]]] = field(default=None, repr=False)
     _edge_ids: Optional[torch.Tensor] = field(default=None, repr=False)  # third result of the library's transposition, if it built the list
+    # holders of the clouds' packed geometry records (the same object for a cloud against itself), or None
+    records_in: Optional[PreparedRecords] = field(default=None, repr=False)
+    records_out: Optional[PreparedRecords] = field(default=None, repr=False)
 
     @staticmethod
     def build(pts_in, pts_out, frames_in, frames_out, neighbors, ends, symmetric: bool = False) -> "ConvGeometry":
@@ -671,15 +716,38 @@ def _geom_ptrs(g: ConvGeometry):
             _ptr(g.neighbors, i32, "neighbors", dev), _ptr(g.ends, i32, "ends", dev)]
 
 
+def _prepared(geom: ConvGeometry, feat_words: Optional[torch.Tensor], feat_words_valid: bool):
+    """struct se3conv_prepared of a call (or None) + what to mark valid once the call has been enqueued."""
+    r_in, r_out = geom.records_in, geom.records_out
+    if r_in is None and r_out is None and feat_words is None:
+        return None, ()
+    p = _lib.Se3Prepared()
+    filled = []
+    if r_in is not None:
+        r_in.bind(geom.pts_in, geom.frames_in)
+        p.geom_in, p.geom_in_valid = r_in.tensor.data_ptr(), int(r_in.valid)
+        filled.append(r_in)
+    if r_out is not None and r_out is not r_in:
+        r_out.bind(geom.pts_out, geom.frames_out)
+        p.geom_out, p.geom_out_valid = r_out.tensor.data_ptr(), int(r_out.valid)
+        filled.append(r_out)
+    elif r_out is r_in and r_in is not None:
+        p.geom_out, p.geom_out_valid = p.geom_in, 1  # (ignored for a cloud against itself; valid by the time it is read otherwise)
+    if feat_words is not None:
+        p.feat_words, p.feat_words_valid = feat_words.data_ptr(), int(feat_words_valid)
+    return p, tuple(filled)
+
+
 def _scalar(t, name, dev) -> torch.Tensor:
     t = torch.as_tensor(t, dtype=torch.float32)
     return t.detach().to(device=dev, dtype=torch.float32).reshape(()).contiguous()
 
 
 def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weights, rho, nu, save_t: bool = True,
-                    precision: Optional[str] = None):
+                    precision: Optional[str] = None, feat_words: Optional[torch.Tensor] = None):
     """Raw forward: returns ``(out [N_out*F_out, C_out], T or None)``.  ``T`` is fp32 in "fp32" precision
-    and an opaque same-size buffer of packed hi/lo words in "bf16x3" (pass it back with the same precision)."""
+    and an opaque same-size buffer of packed hi/lo words in "bf16x3" (pass it back with the same precision).
+    ``feat_words`` (int32, one word per feature, split-bf16 modes): receives the packed feature words for ``se3conv_backward``."""
     lib = _lib.load()
     f32 = torch.float32
     dev = geom.pts_out.device
@@ -699,17 +767,23 @@ def se3conv_forward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weigh
     t_save = torch.empty((rows, c_in, kb), dtype=f32, device=dev) if (save_t and kb == 32) else None
     ws = _workspace(lib.se3conv_fwd_workspace_bytes(C.byref(shp), 1 if save_t else 0), dev)
     rho_t, nu_t = _scalar(rho, "rho", dev), _scalar(nu, "nu", dev)
-    _lib.check(lib.se3conv_fwd(*_geom_ptrs(geom), _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),
-                               _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
-                               _ptr(rho_t, f32, "norm_neigh_dist_"), _ptr(nu_t, f32, "norm_num_neighs_"),
-                               C.byref(shp), _ptr(out, f32, "out"), _ptr(t_save, f32, "t_save"),
-                               C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)), "se3conv_fwd")
+    prep, filled = _prepared(geom, feat_words, False)
+    _lib.check(lib.se3conv_fwd_prepared(*_geom_ptrs(geom), _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),
+                                        _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
+                                        _ptr(rho_t, f32, "norm_neigh_dist_"), _ptr(nu_t, f32, "norm_num_neighs_"),
+                                        C.byref(shp), _ptr(out, f32, "out"), _ptr(t_save, f32, "t_save"),
+                                        C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev),
+                                        C.byref(prep) if prep is not None else None), "se3conv_fwd")
+    for h in filled:
+        h.valid = True
     return out, t_save
 
 
 def se3conv_backward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weights, rho, nu, t_save, grad_out,
-                     want_feat=True, want_params=True, precision: Optional[str] = None):
-    """Raw backward: returns ``(dX, dA, dbeta, dW)`` (None where not requested)."""
+                     want_feat=True, want_params=True, precision: Optional[str] = None,
+                     feat_words: Optional[torch.Tensor] = None):
+    """Raw backward: returns ``(dX, dA, dbeta, dW)`` (None where not requested).  ``feat_words``: what the forward call of
+    the same features wrote (see ``se3conv_forward``), or None."""
     lib = _lib.load()
     f32, i32 = torch.float32, torch.int32
     dev = geom.pts_out.device
@@ -726,15 +800,18 @@ def se3conv_backward(geom: ConvGeometry, feat, proj_axes, proj_biases, conv_weig
     ws = _workspace(lib.se3conv_bwd_workspace_bytes(C.byref(shp), int(want_feat), int(want_params),
                                                     int(t_save is not None)), dev)
     rho_t, nu_t = _scalar(rho, "rho", dev), _scalar(nu, "nu", dev)
-    _lib.check(lib.se3conv_bwd(*_geom_ptrs(geom), _ptr(t_samples, i32, "t_samples"), _ptr(t_ends, i32, "t_ends"),
-                               _ptr(geom._edge_ids if want_feat else None, i32, "t_edge_ids"),
-                               _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),
-                               _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
-                               _ptr(rho_t, f32, "rho"), _ptr(nu_t, f32, "nu"), _ptr(t_save, f32, "t_save"),
-                               _ptr(g, f32, "grad_out", dev), C.byref(shp), _ptr(d_x, f32, "grad_feat"),
-                               _ptr(d_a, f32, "grad_axes"), _ptr(d_b, f32, "grad_biases"),
-                               _ptr(d_w, f32, "grad_weights"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)),
-               "se3conv_bwd")
+    prep, filled = _prepared(geom, feat_words, feat_words is not None)
+    _lib.check(lib.se3conv_bwd_prepared(*_geom_ptrs(geom), _ptr(t_samples, i32, "t_samples"), _ptr(t_ends, i32, "t_ends"),
+                                        _ptr(geom._edge_ids if want_feat else None, i32, "t_edge_ids"),
+                                        _ptr(feat, f32, "features", dev), _ptr(a, f32, "proj_axes_", dev),
+                                        _ptr(b, f32, "proj_biases_", dev), _ptr(w, f32, "conv_weights_", dev),
+                                        _ptr(rho_t, f32, "rho"), _ptr(nu_t, f32, "nu"), _ptr(t_save, f32, "t_save"),
+                                        _ptr(g, f32, "grad_out", dev), C.byref(shp), _ptr(d_x, f32, "grad_feat"),
+                                        _ptr(d_a, f32, "grad_axes"), _ptr(d_b, f32, "grad_biases"),
+                                        _ptr(d_w, f32, "grad_weights"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev),
+                                        C.byref(prep) if prep is not None else None), "se3conv_bwd")
+    for h in filled:
+        h.valid = True
     return d_x, d_a, d_b, d_w
 
 
@@ -755,22 +832,30 @@ class SE3ConvFunction(torch.autograd.Function):
             c_in, kb, c_out = conv_weights.shape
             shp = geom.shape(c_in, c_out, kb, ctx.precision)
             save_t = _lib.load().se3conv_bwd_needs_t(C.byref(shp), int(bool(ctx.needs_input_grad[0]))) != 0
+        # the packed feature words of the split-bf16 modes go to backward with the features (the parameter gradients gather
+        # them again): one split per step instead of two, for one more word per feature kept
+        fw = None
+        if need_params and ctx.precision != "fp32" and conv_weights.shape[1] == 32 and feat.is_cuda:
+            fw = torch.empty(feat.numel(), dtype=torch.int32, device=feat.device)
         out, t_save = se3conv_forward(geom, feat, proj_axes, proj_biases, conv_weights, rho, nu,
-                                      save_t=save_t, precision=ctx.precision)
+                                      save_t=save_t, precision=ctx.precision, feat_words=fw)
         ctx.geom = geom
         ctx.in_dtype = feat.dtype
         ctx.save_for_backward(feat, proj_axes, proj_biases, conv_weights, _scalar(rho, "rho", out.device),
-                              _scalar(nu, "nu", out.device), t_save if t_save is not None else torch.empty(0))
+                              _scalar(nu, "nu", out.device), t_save if t_save is not None else torch.empty(0),
+                              fw if fw is not None else torch.empty(0))
         ctx.has_t = t_save is not None
+        ctx.has_fw = fw is not None
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        feat, a, b, w, rho, nu, t_save = ctx.saved_tensors
+        feat, a, b, w, rho, nu, t_save, fw = ctx.saved_tensors
         want_feat = ctx.needs_input_grad[0]
         want_params = any(ctx.needs_input_grad[1:4])
         d_x, d_a, d_b, d_w = se3conv_backward(ctx.geom, feat, a, b, w, rho, nu, t_save if ctx.has_t else None,
-                                              grad_out, want_feat, want_params, precision=ctx.precision)
+                                              grad_out, want_feat, want_params, precision=ctx.precision,
+                                              feat_words=fw if ctx.has_fw else None)
         if d_x is not None:
             d_x = d_x.to(ctx.in_dtype)
         ng = ctx.needs_input_grad
