@@ -710,6 +710,86 @@ def run_rank(args):
             result["down_up"] = {"error": str(exc)[:200]}
             torch.cuda.synchronize()
 
+        # Everything the library owns of one DFaust training step (BASELINE config 2): what the task script
+        # rebuilds every step -- create_hierarchy (grid sub-samples, 16-NN + PCA frames on every level, the output cloud;
+        # tasks/SemSeg/train_dfaust_rot.py:108-158) and the twelve neighbourhoods of the network with the source-major lists
+        # backward reads -- then the network's 21 convolution calls forward + backward (call list recorded from the reference,
+        # tests/golden/network_faust_calls.npz) and the row-wise glue of its eight ResNetFormer blocks (the blocks with their
+        # convolution taken out: batch norm, skip + drop path, the two dense layers).  The geometry runs eagerly -- the
+        # hierarchy build reads each level's size back (one host synchronisation per level) -- the convolutions and the glue
+        # as captured graphs; `ms` is their sum.  Loss, optimizer and data loading are the task script's.  Not part of `value`.
+        mark("faust_step")
+
+        def faust_step_leg():
+            fixture = os.path.join(ROOT, "tests", "golden", "network_faust_calls.npz")
+            bodies = 32
+            pts_raw, bid_raw = W.faust_raw_batch(device, bodies)
+            calls = W.faust_network_calls(fixture)
+            clouds = W.faust_clouds(pts_raw, bid_raw)
+            nbhs = W.faust_neighbourhoods(clouds, calls)
+            caps = {k: int(nb.num_edges() * 1.25) + 64 for k, nb in nbhs.items()}
+            reps_g = 10
+            ms_clouds = timed(lambda: W.faust_clouds(pts_raw, bid_raw), reps_g, 2) / reps_g * 1e3
+            ms_nbhs = timed(lambda: W.faust_neighbourhoods(clouds, calls, caps), reps_g, 2) / reps_g * 1e3
+            recs = W.build_faust_network_convs(device, fixture, bodies=bodies)
+            for r in recs:
+                r["own_clouds"] = False
+            rec_clouds = {id(c): c for r in recs for c in (r["pc_in"], r["pc_out"])}
+
+            def all_convs(_lv=None):
+                for c in rec_clouds.values():
+                    amd.ops.invalidate_prepared(c)
+                for r in recs:
+                    step_two_clouds(r)
+
+            reps_c = max(10, args.steps // 2)
+            run_convs = all_convs if args.no_graph else GraphedStep(None, fn=all_convs)
+            ms_convs = timed(run_convs, reps_c, 3) / reps_c * 1e3
+
+            class NoConv(torch.nn.Module):  # the block's convolution is in `convolutions` already
+                def forward(self, p_pc_in, p_pc_out, p_in_features, p_neighborhood):
+                    return p_in_features
+
+            fac = amd.PNEConvLayerRotEquivFactory(9, 32, "mlp_gelu")
+            glue = []
+            for level, width in ((1, 32), (2, 64), (3, 128), (4, 256)):  # NUM_BLOCKS [2,2,2,2], NUM_FEATURES [32,64,128,256]
+                pc = clouds[level]
+                rows = pc.pts_.shape[0] * 2
+                for _ in range(2):
+                    blk = amd.ResNetFormer(width, width, fac, amd.BatchNormPC, 0.1).to(device)
+                    blk.spatial_conv_ = NoConv()
+                    blk.train()
+                    glue.append((blk, pc, torch.randn(rows, width, device=device, requires_grad=True),
+                                 torch.randn(rows, width, device=device)))
+
+            def all_glue(_lv=None):
+                for blk, pc, x, g in glue:
+                    x.grad = None
+                    blk.zero_grad(set_to_none=True)
+                    blk(pc, x, None).backward(g)
+
+            run_glue = all_glue if args.no_graph else GraphedStep(None, fn=all_glue)
+            ms_glue = timed(run_glue, reps_c, 3) / reps_c * 1e3
+            n_lv0 = int(clouds[0].pts_.shape[0])
+            total = ms_clouds + ms_nbhs + ms_convs + ms_glue
+            return {"ms": round(total, 3), "value": round(n_lv0 / total / 1e3, 3), "unit": "Mpoints/s (level-0 points)",
+                    "bodies": bodies, "points_per_level": [int(c.pts_.shape[0]) for c in clouds],
+                    "parts_ms": {"hierarchy_and_frames": round(ms_clouds, 3), "neighbourhoods": round(ms_nbhs, 3),
+                                 "convolutions": round(ms_convs, 3), "block_glue": round(ms_glue, 3)},
+                    "share": {"geometry": round((ms_clouds + ms_nbhs) / total, 3), "convolutions": round(ms_convs / total, 3),
+                              "block_glue": round(ms_glue / total, 3)},
+                    "note": "one DFaust training step as far as the library owns it: create_hierarchy + 12 neighbourhoods (eager: "
+                            "one host read-back per level) + 21 convolutions fwd+bwd + glue of 8 ResNetFormer blocks (captured "
+                            "graphs); the sum of the four parts"}
+
+        try:
+            if not extra or args.workload != "headline":
+                raise RuntimeError("skipped")
+            result["faust_step"] = faust_step_leg()
+        except RuntimeError as exc:
+            result["faust_step"] = {"error": str(exc)[:200]}
+            torch.cuda.synchronize()
+
         mark("fp32 leg")
         if not args.no_fp32 and not args.no_extra and args.precision != "fp32":
             amd.set_precision("fp32")

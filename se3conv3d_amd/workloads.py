@@ -234,6 +234,55 @@ def faust_network_calls(fixture_path: str) -> List[dict]:
     return calls
 
 
+def faust_raw_batch(device, bodies: int = 32, sampled: int = 4096, seed: int = 0):
+    """A DFaust-sized batch as the loader hands it over: ``sampled`` points per body on thin shells of a torso's
+    proportions, bodies 3 m apart, one batch id per body."""
+    torch.manual_seed(seed)
+    u = torch.randn(bodies * sampled, 3, device=device)
+    u = u / u.norm(dim=1, keepdim=True)
+    scale = 1.0 + 0.15 * torch.rand(bodies, 1, device=device).repeat_interleave(sampled, 0)
+    pts = u * torch.tensor([0.27, 0.9, 0.17], device=device) * scale + 0.01 * torch.randn(bodies * sampled, 3, device=device)
+    pts = pts + torch.arange(bodies, device=device, dtype=torch.float32).repeat_interleave(sampled)[:, None] * torch.tensor([3.0, 0.0, 0.0], device=device)
+    bid = torch.arange(bodies, device=device, dtype=torch.int32).repeat_interleave(sampled)
+    return pts, bid
+
+
+def faust_clouds(pts: torch.Tensor, bid: torch.Tensor) -> list:
+    """create_hierarchy of the task script (tasks/SemSeg/train_dfaust_rot.py:108-158, confs/dfaust/dfaust_I_rot_pca_2F.yaml):
+    init sub-sample 0.04, PCA frames from 16-NN (F = 2) on every level, grid sub-samples 0.05 .. 0.4, and the randomly
+    sub-sampled output cloud -> [level 0 .. level 4, output cloud]."""
+    from . import pc as _pc
+
+    cfg = {"pca": True, "n_frames": 2, "fixed_axis": False, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
+    raw = _pc.Pointcloud(pts, bid)
+    samp = _pc.GridSubSample(raw, 0.04)
+    pc0 = _pc.PointcloudRotEquiv(samp.__subsample_tensor__(raw.pts_, "avg"), samp.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
+    hier = _pc.PointHierarchyRotEquiv(pc0, 4, "grid_avg", grid_radii=[0.05, 0.1, 0.2, 0.4])
+    samp_out = _pc.GridSubSample(raw, 0.04, p_rnd_sample=True)
+    out_pc = _pc.PointcloudRotEquiv(samp_out.__subsample_tensor__(raw.pts_, "avg"),
+                                    samp_out.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
+    return list(hier.pcs_) + [out_pc]
+
+
+def faust_neighbourhoods(clouds: list, calls: List[dict], capacities: dict = None) -> dict:
+    """The neighbourhoods the network's calls use, one per (input level, output level, radius) as the reference's hierarchy
+    memoises them (PointHierarchy.py:60-79), with the source-major list backward reads where the clouds differ.
+    ``capacities`` (same keys -> rows): capacity-bounded builds without a host synchronisation."""
+    from . import pc as _pc
+
+    nbhs = {}
+    for c in calls:
+        key = (c["level_in"], c["level_out"], c["radius"])
+        if key in nbhs:
+            continue
+        cap = None if capacities is None else capacities[key]
+        nb = _pc.BQNeighborhood(clouds[c["level_in"]], clouds[c["level_out"]], c["radius"], p_capacity=cap)
+        if c["level_in"] != c["level_out"] and cap is not None:
+            nb.source_major()
+        nbhs[key] = nb
+    return nbhs
+
+
 def build_faust_network_convs(device, fixture_path: str, bodies: int = 32, sampled: int = 4096, seed: int = 0) -> List[dict]:
     """The hierarchy the task script builds for a DFaust batch (tasks/SemSeg/train_dfaust_rot.py:108-158 with
     confs/dfaust/dfaust_I_rot_pca_2F.yaml: 4096 sampled points per body, init / output sub-sample 0.04, grid sub-samples
@@ -242,30 +291,15 @@ def build_faust_network_convs(device, fixture_path: str, bodies: int = 32, sampl
     ball-query neighbourhood with the call's radius, a layer with converged EMA buffers, features and an output gradient."""
     from . import layers, pc as _pc
 
-    torch.manual_seed(seed)
-    cfg = {"pca": True, "n_frames": 2, "fixed_axis": False, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
-    u = torch.randn(bodies * sampled, 3, device=device)
-    u = u / u.norm(dim=1, keepdim=True)
-    scale = 1.0 + 0.15 * torch.rand(bodies, 1, device=device).repeat_interleave(sampled, 0)
-    pts = u * torch.tensor([0.27, 0.9, 0.17], device=device) * scale + 0.01 * torch.randn(bodies * sampled, 3, device=device)
-    pts = pts + torch.arange(bodies, device=device, dtype=torch.float32).repeat_interleave(sampled)[:, None] * torch.tensor([3.0, 0.0, 0.0], device=device)
-    bid = torch.arange(bodies, device=device, dtype=torch.int32).repeat_interleave(sampled)
-    raw = _pc.Pointcloud(pts, bid)
-    samp = _pc.GridSubSample(raw, 0.04)
-    pc0 = _pc.PointcloudRotEquiv(samp.__subsample_tensor__(raw.pts_, "avg"), samp.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
-    hier = _pc.PointHierarchyRotEquiv(pc0, 4, "grid_avg", grid_radii=[0.05, 0.1, 0.2, 0.4])
-    samp_out = _pc.GridSubSample(raw, 0.04, p_rnd_sample=True)
-    out_pc = _pc.PointcloudRotEquiv(samp_out.__subsample_tensor__(raw.pts_, "avg"),
-                                    samp_out.__subsample_tensor__(raw.batch_ids_, "max"), cfg)
-    clouds = list(hier.pcs_) + [out_pc]
+    pts, bid = faust_raw_batch(device, bodies, sampled, seed)
+    clouds = faust_clouds(pts, bid)
     factory = layers.PNEConvLayerRotEquivFactory(9, NUM_BASIS, "mlp_gelu")
-    recs, nbhs = [], {}
-    for i, c in enumerate(faust_network_calls(fixture_path)):
+    calls = faust_network_calls(fixture_path)
+    nbhs = faust_neighbourhoods(clouds, calls)  # the network builds a neighbourhood once and shares it between the convolutions that use it
+    recs = []
+    for i, c in enumerate(calls):
         pc_in, pc_out = clouds[c["level_in"]], clouds[c["level_out"]]
-        key = (c["level_in"], c["level_out"], c["radius"])
-        if key not in nbhs:  # the network builds a neighbourhood once and shares it between the convolutions that use it
-            nbhs[key] = _pc.BQNeighborhood(pc_in, pc_out, c["radius"])
-        nbh = nbhs[key]
+        nbh = nbhs[(c["level_in"], c["level_out"], c["radius"])]
         conv = factory.create_conv_layer(c["c_in"], c["c_out"]).to(device)
         conv.norm_neigh_dist_.fill_(1.0 / c["radius"])
         conv.norm_num_neighs_.fill_(nbh.start_ids_.shape[0] / max(nbh.num_edges(), 1))
