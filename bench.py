@@ -424,7 +424,8 @@ def run_rank(args):
         ev_layer = timed_events(run_layer, max(args.steps, 50))
         ms_eager = timed(lambda: step(levels), args.steps, max(1, args.warmup // 2)) / args.steps * 1e3
 
-        stages = profile_level(lib, lv0, reps=5)
+        prof_reps = 5
+        stages = profile_level(lib, lv0, reps=prof_reps)
         fl = W.layer_flops(lv0["n"], lv0["e"], frames, lv0["c"])
         own = W.stage_owned_bytes(lv0["n"], lv0["e"], frames, lv0["c"])
         peak_tf = PEAK_MFMA_TFLOPS[args.precision]
@@ -455,7 +456,7 @@ def run_rank(args):
                         "algorithmic_bytes_per_launch": own[dom],
                         "traffic_over_algorithmic": round(traffic / own[dom], 3) if traffic else None,
                         "mfma_frac": round(tf / peak_tf, 4), "avg_launch_ms": round(core[dom][0], 4),
-                        "launches": core[dom][1], "launches_per_step": core[dom][1] // 5, "stage_ms_per_step": round(core[dom][2], 4),
+                        "launches": core[dom][1], "launches_per_step": core[dom][1] // prof_reps, "stage_ms_per_step": round(core[dom][2], 4),
                         "note": "achieved = SURVEY 8d bytes this launch owns (geometry + gathered rows; no row-sized "
                                 "intermediates) / its HIP-event time; intermediates appear in traffic only",
                         "stages_ms": {t: round(v[2], 4) for t, v in sorted(stages.items())},

@@ -510,7 +510,7 @@ int se3_profile_enable(int on);
  * that was captured without an eager step in front of it.  stats[5]: [0] caller streams that own an internal side
  * stream, [1] spare (stream, events) sets ready on the current device, [2] sets created so far in this process, [3]
  * backward passes that wanted to fork inside a capture and could not (no set prepared: that graph replays its two
- * branches back to back -- correct, slower on 4 k - 32 k-row levels), [4] sets the 16-owner cap handed back to the
+ * branches back to back -- the same results; with the fork opt-in since round 5 that is also the default schedule), [4] sets the 16-owner cap handed back to the
  * spares.  Sets are only created by calls whose stream is NOT being captured. */
 int se3_side_stream_stats(int32_t* stats);
 /* Process-wide switch of state (2): se3conv_bwd runs its feature branch on the internal side stream for layers of at most

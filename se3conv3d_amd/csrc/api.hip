@@ -430,8 +430,9 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
 // in round 1).  It also keeps the library out of a hazard of this HIP runtime: a fork FROM A FORKED STREAM inside a graph
 // capture segfaults in hipStreamEndCapture (tools/probes/nested_fork_capture.py: torch streams and events alone do it), which
 // is what a caller who captures the library on a side stream of its own would have triggered.  SE3_OVERLAP=1 (every size) /
-// SE3_OVERLAP_ROWS=n (up to n output rows) / se3_set_overlap_rows(n) turn it on; levels of fewer than kOverlapMinRows rows
-// fork only when the limit was raised explicitly.
+// SE3_OVERLAP_ROWS=n / se3_set_overlap_rows(n) turn it on for levels of MORE than kOverlapMinRows and at most n output rows;
+// smaller levels fork only when the limit is 2^40 or more (what SE3_OVERLAP=1 sets: "every size") -- below ~4 k rows the fork
+// and join cost more than the branches overlap.
 constexpr int kOverlapRows = 0, kOverlapMinRows = 4096;
 std::atomic<int64_t> g_overlap_rows{-1};  // se3_set_overlap_rows: >= 0 overrides the environment
 int64_t overlap_rows_limit() {

@@ -1457,7 +1457,12 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
   if (gt16 && !edge_param_grad_bf16_t16_rows(g, channels)) return SE3_ERR_UNSUPPORTED;
   ProfScope prof(tag, stream);
   *n_used = n_partials;
-  if (channels % 16 == 0 && channels > 0) {
+  // Rows of fewer than 16 channels (the networks' first layers: C_in = 1 for DFaust, 3 for ScanNet colours) take the MFMA
+  // form with one k-step too (round 6): a lane's eight feature words then run past its own row into the next rows', and meet
+  // grad_T fragments that are zero there (the row's buffer ends behind its channels: out-of-range loads return 0), so
+  // gphi = f . gT is exact -- 0.153 -> see profiles/r06_faust_network_convs.txt for call 00 -- instead of the generic kernel's
+  // scalar loads and VALU outer products.
+  if (channels > 0 && (channels % 16 == 0 || channels < 16)) {
     int shift = -1;
     for (int sft = 0; sft < 8; ++sft)
       if ((1 << sft) == g.f_nb) shift = sft;
@@ -1543,7 +1548,7 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
     else if (shift >= 0) SE3_PG_L(CH16, 1, true, 256);     \
     else SE3_PG_L(CH16, 1, false, 256);                    \
   } while (0)
-    switch (channels >= 64 ? 4 : channels / 16) {
+    switch (channels >= 64 ? 4 : (channels + 15) / 16) {
       case 1: SE3_PG(1); break;
       case 2: SE3_PG(2); break;
       case 3: SE3_PG(3); break;

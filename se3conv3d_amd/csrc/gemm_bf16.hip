@@ -11,6 +11,8 @@
 // as long as the MFMA side reaches ~1/3 of its peak.
 #include <cstdlib>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace se3 {
@@ -1286,10 +1288,19 @@ static int gemm_nn_bf16_rows(const uint32_t* a, const uint16_t* bt_hi, const uin
 #define SE3_NN_LAUNCH24_KG(MODE, NBV, KGV, OUT)                                                                       \
   do {                                                                                                                \
     constexpr int lds_bytes = gemm_nn_t24_lds_bytes(NBV, KGV);                                                         \
-    if (lds_bytes > 64 * 1024) {  /* beyond the default dynamic-LDS limit: raise it once per instantiation */           \
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nn_t24_kernel<MODE, NBV, KGV>), \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);     \
-      if (attr != hipSuccess) return SE3_ERR_LAUNCH;                                                                   \
+    if (lds_bytes > 64 * 1024) {  /* beyond the default dynamic-LDS limit: raised once per (device, instantiation) -- a \
+                                     runtime that keeps the attribute per device must see it on every device the      \
+                                     process uses; a failure is not cached */                                          \
+      static std::atomic<uint64_t> raised{0};                                                                          \
+      int dev_ = 0;                                                                                                   \
+      if (hipGetDevice(&dev_) != hipSuccess) return SE3_ERR_LAUNCH;                                                   \
+      const uint64_t bit_ = 1ull << (dev_ & 63);                                                                      \
+      if (!(raised.load(std::memory_order_relaxed) & bit_)) {                                                         \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nn_t24_kernel<MODE, NBV, KGV>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)                 \
+          return SE3_ERR_LAUNCH;                                                                                      \
+        raised.fetch_or(bit_, std::memory_order_relaxed);                                                             \
+      }                                                                                                               \
     }                                                                                                                 \
     hipLaunchKernelGGL((gemm_nn_t24_kernel<MODE, NBV, KGV>), grid24, dim3(256 * KGV), lds_bytes, stream, (const uint8_t*)a, \
                        bt_hi, bt_lo, (void*)(OUT), m, n, k, st_per, alpha_num, alpha_scale);                          \

@@ -25,6 +25,12 @@ TOLS = {"fp32": 2e-5, "bf16x3": 5e-5, "bf16x3_t16": 5e-5}  # the T16 mode is hel
 TOL = 2e-5  # tests of the fp32-only ops (FeatBasisProj, rot tensors)
 
 
+# the opt-in third mode ("NOT the headline") runs where its own code is: the golden layer files, the random
+# shapes and the full-size headline subset (it used to carry a third of this module)
+T16_TESTS = ("test_layer_forward_backward_matches_golden", "test_random_shapes_against_oracle",
+             "test_headline_subset_against_oracle")
+
+
 @pytest.fixture(scope="module", params=["bf16x3", "fp32", "bf16x3_t16"])
 def amd(built_library, request):
     import se3conv3d_amd
@@ -32,6 +38,12 @@ def amd(built_library, request):
     se3conv3d_amd.set_precision(request.param)
     yield se3conv3d_amd
     se3conv3d_amd.set_precision("bf16x3")
+
+
+@pytest.fixture(autouse=True)
+def _t16_only_where_it_has_code(request):
+    if "amd" in request.fixturenames and "bf16x3_t16" in request.node.name and request.node.originalname not in T16_TESTS:
+        pytest.skip("bf16x3_t16 runs the golden files, the random shapes and the full-size subset only")
 
 
 def tol(amd):
@@ -236,7 +248,8 @@ def test_large_preactivations_saturate_like_the_reference(amd, scale):
     for key, err in errs.items():
         # dA / dbeta at +-10^4: GELU' is a step there, and the gradient is carried by the few pre-activations inside its
         # |z| < 3 transition, where the 2^-17 relative rounding of z = A desc + beta is an absolute 0.02 (1.1e-4 measured in
-        # bf16x3, with either GELU form: the parameter-gradient kernel keeps the 7.1.26 one) -- conditioning, not saturation
+        # bf16x3 with the 7.1.26 form of GELU' and with the polynomial form the parameter-gradient kernel runs since round 5,
+        # common.h gelu_scaled_dgrad: the bound is about the rounding of z, not about the form) -- conditioning, not saturation
         bound = tol(amd) * (10 if scale > 100 and key in ("dA", "dbeta") else 1)
         assert err < bound, (key, err, scale)
 
