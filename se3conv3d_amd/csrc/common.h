@@ -238,14 +238,19 @@ __device__ __forceinline__ void gelu_scaled_core(float xp, float& a, float& e, f
   hq2 = fmaf(-(p * t), e, 1.0f);           // 1 - 2 Phi(-|x|)
 }
 // Value only (the forward and transposed edge passes, the edge-major feature gradient): 2 Phi(-|x|) = exp2(P(|x'|)) with P a
-// degree-7 polynomial (round 5; weighted minimax fit of log2(2 Phi(-a)) on |x| <= 6.2 for the absolute error of
-// |x| * 2 Phi(-|x|), leading coefficient pinned negative so that P keeps falling beyond the fitted range: no clamp, no
-// overflow into the result for any finite input).  |error| <= 6.1e-8 on GELU before rounding, the same as the 7.1.26 form
-// after it (max 4.5e-7 / rms 7.5e-8 on [-3, 3] in fp32 against 5.6e-7 / 1.05e-7).  No v_rcp_f32: 9 full-rate ops +
-// v_exp_f32 = 44 issue cycles per wavefront instead of 52.  SE3_GELU_POLY=0 builds the 7.1.26 form, =6 a degree-6 fit
-// (4.9e-7; 40 cycles).
+// polynomial (round 5: degree 7; round 6: degree 5).  Weighted minimax fit of log2(2 Phi(-a)) on |x| <= 6.4 for the
+// absolute error of |x| * 2 Phi(-|x|) (Lawson iteration on the linearised problem, tools/fit_gelu_poly.py).  The degree-5
+// fit's leading coefficient comes out negative by itself and P' < 0 on the whole half line (checked to |x'| = 2000 and
+// symbolically beyond: every term of P' is negative past |x'| = 10.2), so exp2(P) keeps falling beyond the fitted range:
+// no clamp, no overflow into the result for any finite input.  |error| on GELU in fp32: max 7.2e-7 / rms 2.7e-7 on
+// [-7, 7] (degree 7: 5.7e-7 / 0.9e-7, the 7.1.26 form 5.6e-7 / 1.05e-7) -- a fifth of the 2^-17 relative rounding the
+// split-bf16 operands put on a phi of typical size (3e-6), and the maximum is the fp32 rounding of the final fused step
+// in every form.  7 full-rate ops + v_exp_f32 = 36 issue cycles per value instead of 44 (degree 7) / 52 (7.1.26).  Once the
+// chunk-stream kernel had taken the wave's idle time out, the edge passes follow their VALU count at ~2/3 of the
+// proportional rate (degree 6 instead of 7: -3 % on edge_t, profiles/r06_gelu_degree_ab.txt).
+// SE3_GELU_POLY=7 builds the degree-7 fit, =0 the 7.1.26 form.
 #ifndef SE3_GELU_POLY
-#define SE3_GELU_POLY 7
+#define SE3_GELU_POLY 5
 #endif
 __device__ __forceinline__ float gelu_scaled(float xp) {
 #if SE3_GELU_POLY == 0
@@ -263,12 +268,11 @@ __device__ __forceinline__ float gelu_scaled(float xp) {
   p = fmaf(p, a, -1.355453730e+00f);
   p = fmaf(p, a, 8.137106306e-06f);
 #else
-  float p = fmaf(-9.999999747e-06f, a, -9.957919829e-04f);
-  p = fmaf(p, a, 1.340281218e-02f);
-  p = fmaf(p, a, -8.431199938e-02f);
-  p = fmaf(p, a, -6.378662586e-01f);
-  p = fmaf(p, a, -1.354898334e+00f);
-  p = fmaf(p, a, -4.209694816e-05f);
+  float p = fmaf(-1.070951186e-03f, a, 1.361500331e-02f);
+  p = fmaf(p, a, -8.459421670e-02f);
+  p = fmaf(p, a, -6.376852093e-01f);
+  p = fmaf(p, a, -1.354949055e+00f);
+  p = fmaf(p, a, -3.763227806e-05f);
 #endif
   const float q2 = __builtin_amdgcn_exp2f(p);  // 2 Phi(-|x|)
   return fmaf(-a, q2, a + xp);                 // |x'| (1 - q2) + x'
@@ -286,8 +290,10 @@ __device__ __forceinline__ void gelu_scaled_grad(float xp, float& y2, float& dy2
 // the absolute error of H on |x| <= 6.4, leading coefficient negative: P keeps falling beyond the range, no clamp).
 // |error| <= 1.85e-7 on 2 GELU' before rounding; in fp32 max 4.2e-7 / rms 1.5e-7 on [-3, 3] (7.1.26 form: 5.6e-7 / 1.0e-7).
 // 11 full-rate ops + v_exp_f32 = 52 issue cycles per wavefront instead of 12 + v_rcp_f32 + v_exp_f32 = 64.
+// (degree 7 here: the derivative's degree-6 fit is not monotone beyond the fitted range and its degree-5 fit is 1e-5 off,
+// tools/fit_gelu_poly.py)
 #ifndef SE3_GELU_DPOLY
-#define SE3_GELU_DPOLY SE3_GELU_POLY  // 0: the 7.1.26 form
+#define SE3_GELU_DPOLY (SE3_GELU_POLY ? 7 : 0)  // 0: the 7.1.26 form
 #endif
 __device__ __forceinline__ float gelu_scaled_dgrad(float xp) {
 #if SE3_GELU_DPOLY == 0

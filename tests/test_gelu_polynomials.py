@@ -57,17 +57,20 @@ def test_value_polynomial_matches_erf_gelu_and_saturates():
     body = function_body("gelu_scaled")
     c7 = horner_coefficients(body, "#if SE3_GELU_POLY == 7")
     assert len(c7) == 8 and c7[0] < 0  # leading coefficient negative: exp2(P) -> 0 beyond the fitted interval
-    xs = np.linspace(-3.0, 3.0, 240001)
-    err = np.abs(gelu_value(xs, c7) - xs * ndtr(xs))
-    assert err.max() < 6e-7 and np.sqrt(np.mean(err ** 2)) < 1.2e-7  # the rounding level of the erf form it replaced
-    xs = np.linspace(-7.0, 7.0, 280001)
-    assert np.abs(gelu_value(xs, c7) - xs * ndtr(xs)).max() < 1.2e-6  # half an ulp of the values near 7
-    big = np.array([8.0, 20.0, 1e3, 1e6, 1e12, 1e30])
-    assert np.allclose(gelu_value(big, c7), big, rtol=2e-7) and np.all(np.abs(gelu_value(-big, c7)) < 1e-12)
-    c6 = horner_coefficients(body[body.index("#if SE3_GELU_POLY == 7"):], "#else")
-    assert len(c6) == 7 and c6[0] < 0
-    xs = np.linspace(-3.0, 3.0, 240001)
-    assert np.abs(gelu_value(xs, c6) - xs * ndtr(xs)).max() < 1.2e-6  # the unshipped degree-6 fit: 4.9e-7 + rounding
+    c5 = horner_coefficients(body[body.index("#if SE3_GELU_POLY == 7"):], "#else")  # the shipped form (round 6)
+    assert len(c5) == 6 and c5[0] < 0
+    assert "#define SE3_GELU_POLY 5" in SRC
+    for coeffs, max_mid, rms_mid, max_wide in ((c7, 6e-7, 1.2e-7, 1.2e-6), (c5, 9e-7, 3.5e-7, 1.2e-6)):
+        xs = np.linspace(-3.0, 3.0, 240001)
+        err = np.abs(gelu_value(xs, coeffs) - xs * ndtr(xs))
+        assert err.max() < max_mid and np.sqrt(np.mean(err ** 2)) < rms_mid  # the rounding level of the erf form they replaced
+        xs = np.linspace(-7.0, 7.0, 280001)
+        assert np.abs(gelu_value(xs, coeffs) - xs * ndtr(xs)).max() < max_wide  # half an ulp of the values near 7
+        big = np.array([8.0, 20.0, 1e3, 1e6, 1e12, 1e30])
+        assert np.allclose(gelu_value(big, coeffs), big, rtol=2e-7) and np.all(np.abs(gelu_value(-big, coeffs)) < 1e-12)
+    # the degree-5 P falls on the whole half line: nothing it returns beyond the fitted range can grow back
+    a = np.linspace(0.0, 3000.0, 3000001)
+    assert np.all(np.diff(np.polyval(np.array(c5, dtype=np.float64), a)) < 0)
 
 
 def test_derivative_polynomial_matches_erf_gelu_and_saturates():

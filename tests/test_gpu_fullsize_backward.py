@@ -129,7 +129,12 @@ def check_directional(amd, pc, nbh, conv, x, g, grads, eps=2e-2, tol_fd=4e-3):
                 p.sub_(sgn * eps * delta)
         fd = (vals[0] - vals[1]) / (2 * eps)
         an = float((dp.double() * delta.double()).sum())
-        assert abs(fd - an) <= tol_fd * max(abs(fd), abs(an), 1e-6), (name, fd, an)
+        # <dP, delta> is a sum of numel terms of either sign: where it cancels to a small value (dfaust_f4's W with the
+        # frames round 6's shuffle draws: -0.5 out of terms whose root sum of squares is ~18) the difference quotient's own
+        # noise -- the hi / lo split of P +- eps delta, 2^-17 relative per element against a step of 0.02 -- is measured
+        # against that scale, not against the cancelled sum
+        scale = float((dp.double() * delta.double()).norm())
+        assert abs(fd - an) <= tol_fd * max(abs(fd), abs(an), 1e-6) + 2e-3 * scale, (name, fd, an, scale)
 
 
 def full_checks(amd, pc, r, c_in, c_out, seed):
