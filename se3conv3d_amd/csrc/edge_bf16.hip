@@ -511,12 +511,20 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
   const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
   const __amdgpu_buffer_rsrc_t nbr_rs = buffer_of(g.nbr, g.n_edges * g.nbr_stride * 4);  // ids past the list read 0
   const uint32_t groups = (uint32_t)g.f_ctr / 2u;
-  const uint32_t item0 = item_lo + blockIdx.x;
-  const int n_mine = (int)((item_hi - item0 + gridDim.x - 1) / gridDim.x);  // >= 1: the grid has at most one workgroup per item
+  const uint32_t item0_wg = item_lo + blockIdx.x;
+  const int n_mine = (int)((item_hi - item0_wg + gridDim.x - 1) / gridDim.x);  // >= 1: the grid has at most one workgroup per item
   const int fmask = (1 << fnb_shift) - 1;
   const int hb = 16 * h;
 
-  // row extents of this workgroup's items (at most 64: the launcher sizes the grid): lane l holds the extents of local item l
+  f32x16 acc[2] = {zero16(), zero16()};
+  int buf = 0;
+  // The workgroup's items in windows of 64: the row extents of a window sit in two registers (lane l = the window's l-th
+  // item), the chunk pipeline is drained and restarted between two windows (one exposed round trip per 64 items).  A
+  // level of up to 64 items per resident workgroup -- 131 072 items, the headline's 65 536 among them -- is one window.
+  const int n_all = n_mine;
+  for (int win0 = 0; win0 < n_all; win0 += 64) {
+  const int n_mine = min(64, n_all - win0);  // (the loop body below sees one window as "its" items)
+  const uint32_t item0 = item0_wg + (uint32_t)win0 * gridDim.x;
   int v_lo, v_hi;
   {
     const uint32_t item = item0 + (uint32_t)min(lane, n_mine - 1) * gridDim.x;
@@ -585,8 +593,6 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
   }
   float yc[3], rc[9];
   centre(cur, yc, rc);
-  f32x16 acc[2] = {zero16(), zero16()};
-  int buf = 0;
 
   while (cur.j < n_mine) {
     const int cnt = min(32, cur.n_total - cur.c0);  // <= 0: a row without neighbours
@@ -692,6 +698,7 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
     cur = n1, n1 = n2, n2 = advance(n2);
     buf ^= 1;
   }
+  }  // windows
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1362,8 +1369,7 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
       }
       constexpr int per_cu = 2 * SE3_PAIR_WAVES;  // 18 KB of LDS and <= 128 VGPRs: eight two-wavefront workgroups per CU
-      int64_t wgs = (int64_t)n_cu * per_cu;
-      if (wgs < (n_range + 63) / 64) wgs = (n_range + 63) / 64;  // a workgroup keeps the extents of <= 64 items (one per lane)
+      int64_t wgs = (int64_t)n_cu * per_cu;  // resident workgroups only, whatever the level's size (windows of 64 items inside)
       if (wgs > n_range) wgs = n_range;
       const dim3 sgrid((unsigned)wgs), sblock(128);
       if (g.transposed)
@@ -1505,10 +1511,10 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
         return e ? atoi(e) : (SE3_PG_PAIR_LEAN ? 8 : 6);  // 19 KB / 26 KB of LDS per workgroup
       }();
       int64_t wgs = (int64_t)n_cu * per_cu;
-      // extents in lane registers (pipe): a workgroup walks at most 64 items -- more workgroups than resident ones where
-      // the partial-sum slots allow it, the per-item extent loads otherwise
-      // (measured: profiles/r06_param_grad_pipeline_ab.txt -- the extent loads were never what the kernel waited on)
-      if (wgs < (n_range + 63) / 64) wgs = (n_range + 63) / 64;
+      // extents in lane registers (pipe) where a resident workgroup walks at most 64 items; the per-item extent loads
+      // otherwise -- never more workgroups than the chip holds at once for the registers' sake: 3 450 workgroups of 64 items
+      // on dfaust_f4's level 0 ran as 2.25 rounds of 1 536 and took 1.52 instead of 1.23 ms, and the extent loads were never
+      // what the kernel waited on (profiles/r06_param_grad_pipeline_ab.txt)
       if (wgs > n_partials) wgs = n_partials;
       if (wgs > n_range) wgs = n_range;
       if (wgs < 1) wgs = 1;
