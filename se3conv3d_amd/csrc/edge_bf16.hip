@@ -486,6 +486,26 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
 // neighbouring extents and write neighbouring rows, and a cloud's dense regions are spread over all of them.
 // Rows without neighbours are one chunk of zero frame-edges (every lane reads out of bounds: zero rows are stored).
 // ------------------------------------------------------------------------------------------------
+// Rotating wave priority (round 6).  The SIMD's arbiter prefers the OLDEST wavefront among equals, so the resident
+// wavefronts of a SIMD do not advance at one rate: stamped, the four of a SIMD finish at 0.59 / 0.70 / 0.89 / 1.00 of its
+// span although they hold the same work to 5 % (profiles/r06_edge_timeline.txt) -- a fifth of the slot time is idle and the
+// last wavefront runs alone, where nothing covers its latencies.  Every wavefront therefore takes priority
+// (step + its slot) mod 4 and moves on by one every chunk: each is the preferred one a quarter of the time.
+#ifndef SE3_ROTATE_PRIO
+#define SE3_ROTATE_PRIO 1
+#endif
+__device__ __forceinline__ void rotate_priority(int step_plus_slot) {
+#if SE3_ROTATE_PRIO
+  switch (step_plus_slot & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+#endif
+}
+__device__ __forceinline__ int wave_slot_id() { return (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) ; }  // HW_ID[3:0]
+
 struct ChunkCursor {
   int j;        // local item index; n_mine = past the end
   int c0;       // first frame-edge of the chunk
@@ -502,6 +522,8 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
   constexpr int C = 64, row_bytes = C * 4;
   __shared__ __attribute__((aligned(16))) uint32_t lds_w[1][2][64][4];
   __shared__ __attribute__((aligned(16))) uint32_t lds_phi[2][2][2][2][64][4];  // [buffer][frame][k-step][hi/lo][lane]
+  // (timeline build: entry / exit stamps and the chunk count of every wavefront -- how evenly the resident workgroups finish)
+  TL(__shared__ uint32_t tl_lds[2][kTlWords]; uint32_t* tl_rec = tl_lds[threadIdx.x >> 6]; tl_rec[threadIdx.x & 63] = 0u; tl_mark(tl_rec, 0); uint32_t tl_chunks = 0;)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kcol = lane & 31, h = lane >> 5;
   if (threadIdx.x < 64) mlp_weights_to_lds<1>(lds_w, axes_ext, threadIdx.x);
@@ -518,6 +540,7 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
 
   f32x16 acc[2] = {zero16(), zero16()};
   int buf = 0;
+  int prio_step = wave_slot_id();
   // The workgroup's items in windows of 64: the row extents of a window sit in two registers (lane l = the window's l-th
   // item), the chunk pipeline is drained and restarted between two windows (one exposed round trip per 64 items).  A
   // level of up to 64 items per resident workgroup -- 131 072 items, the headline's 65 536 among them -- is one window.
@@ -595,6 +618,7 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
   centre(cur, yc, rc);
 
   while (cur.j < n_mine) {
+    rotate_priority(prio_step++);
     const int cnt = min(32, cur.n_total - cur.c0);  // <= 0: a row without neighbours
     // rows past the end of the neighbour list read out of bounds (buffer loads return 0): their phi needs no mask
     const int qoff = cur.c0 + kcol < cur.n_total ? q_cur * row_bytes : kOobOffset;
@@ -697,8 +721,12 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
     for (int i = 0; i < 9; ++i) rc[i] = rnc[i];
     cur = n1, n1 = n2, n2 = advance(n2);
     buf ^= 1;
+    TL(++tl_chunks;)
   }
   }  // windows
+  TL(tl_mark(tl_rec, 9); __builtin_amdgcn_s_waitcnt(0); tl_mark(tl_rec, 10);
+     tl_rec[11] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tl_rec[12] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+     tl_rec[14] = tl_chunks; tl_rec[15] = (uint32_t)n_all; tl_flush(TR == 1 ? 1 : 0, blockIdx.x * 2 + wv, tl_rec);)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1001,6 +1029,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
                             : __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0);
       }
   };
+  int prio_step = wave_slot_id();
   bool have = find_item();
   TL(tl_seg(tl_rec, tl_prev, 1);)  // 1: item set-up (extents, rows)
   if (have) issue_item_loads();
@@ -1035,6 +1064,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     TL(tl_seg(tl_rec, tl_prev, 7);)  // 7: barrier (image complete)
 
     for (int c0 = c_first; c0 < n_total; c0 += CSTEP) {
+      if (PAIR) rotate_priority(prio_step++);  // resident workgroups: see rotate_priority
       const int cnt = min(32, n_total - c0);
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;

@@ -36,6 +36,20 @@ def report_edge_t(name, rec):
     print(f"== {name}: {len(r)} wavefronts; life (entry -> stores issued) median {med(life):.0f} cycles, mean {life.mean():.0f}; "
           f"stores retired {med((r[:, 10] - r[:, 9]) & 0xffffffff):.0f} later")
     slot_occupancy(r[:, 11], r[:, 12], r[:, 0], r[:, 10])
+    if int(r[:, 14].max()) > 8:  # resident workgroups (the chunk-stream kernel): entry / exit stamps and chunk counts only
+        by_x = {}
+        for x in range(8):
+            m = r[:, 12] == x
+            if m.any():
+                t0 = r[m, 0].min()
+                end = (r[m, 10] - t0) & 0xffffffff
+                start = (r[m, 0] - t0) & 0xffffffff
+                by_x[x] = (start, end, r[m, 14])
+        for x, (start, end, ch) in sorted(by_x.items()):
+            print(f"   XCD {x}: {len(end)} wavefronts; entered within {np.percentile(start, 99):.0f} cycles (99 %); finished at "
+                  f"{np.percentile(end, 1):.0f} / {np.median(end):.0f} / {end.max()} cycles (1 % / median / last); chunks per wavefront "
+                  f"{ch.min()} .. {ch.max()} (mean {ch.mean():.1f}); cycles per chunk {np.median((end - start) / ch):.0f}")
+        return
     for nch in sorted(set(r[:, 14].tolist())):
         sel = r[r[:, 14] == nch]
         if len(sel) < 200 or nch > 5:
@@ -84,13 +98,15 @@ def slot_occupancy(hw_id, xcc, t_start, t_end):
     order = np.argsort(simd, kind="stable")
     simd, ts, te, wid = simd[order], t_start[order], t_end[order], (hw_id[order] & 0xf)
     bounds = np.flatnonzero(np.diff(simd)) + 1
-    conc, gaps, per_simd = [], [], []
+    conc, gaps, per_simd, ends = [], [], [], []
     for lo, hi in zip(np.r_[0, bounds], np.r_[bounds, len(simd)]):
         s0 = ts[lo]
         a = ((ts[lo:hi] - s0 + 2 ** 31) & 0xffffffff) - 2 ** 31  # wrap-safe, relative to one wavefront of the SIMD
         b = ((te[lo:hi] - s0 + 2 ** 31) & 0xffffffff) - 2 ** 31
         span = b.max() - a.min()
         conc.append((b - a).sum() / span)
+        if hi - lo <= 8:  # resident workgroups: when the SIMD's wavefronts finish, as fractions of its span
+            ends.append(np.sort((b - a.min()) / span)[:4] if hi - lo >= 4 else np.full(4, np.nan))
         per_simd.append(hi - lo)
         w = wid[lo:hi]
         for slot in np.unique(w):
@@ -101,6 +117,9 @@ def slot_occupancy(hw_id, xcc, t_start, t_end):
     gaps = np.array(gaps)
     print(f"   SIMDs seen {len(conc)}, wavefronts per SIMD {np.mean(per_simd):.1f}; resident wavefronts per SIMD (wavefront-cycles / span): "
           f"mean {np.mean(conc):.2f}, 10 % / 90 % {np.percentile(conc, 10):.2f} / {np.percentile(conc, 90):.2f}")
+    if ends:
+        e = np.nanmean(np.array(ends), axis=0)
+        print(f"   wavefronts of a SIMD finish at {e[0]:.2f} / {e[1]:.2f} / {e[2]:.2f} / {e[3]:.2f} of its span (mean over SIMDs)")
     if len(gaps):
         print(f"   a slot between two wavefronts: idle median {np.median(gaps):.0f} cycles, mean {gaps.mean():.0f}, 90 % {np.percentile(gaps, 90):.0f}")
 
