@@ -357,6 +357,26 @@ __device__ __forceinline__ void load_geom_record(const __amdgpu_buffer_rsrc_t rs
   for (int i = 0; i < 4; ++i) r[i] = __uint_as_float(v1[i]), r[4 + i] = __uint_as_float(v2[i]);
 }
 
+// Rotating wave priority (round 6).  The SIMD's arbiter prefers the OLDEST wavefront among equals, so the resident
+// wavefronts of a SIMD do not advance at one rate: stamped, the four of a SIMD finish at 0.59 / 0.70 / 0.89 / 1.00 of its
+// span although they hold the same work to 5 % (profiles/r06_edge_timeline.txt) -- a fifth of the slot time is idle and the
+// last wavefront runs alone, where nothing covers its latencies.  Every wavefront therefore takes priority
+// (step + its slot) mod 4 and moves on by one every chunk: each is the preferred one a quarter of the time.
+#ifndef SE3_ROTATE_PRIO
+#define SE3_ROTATE_PRIO 1
+#endif
+__device__ __forceinline__ void rotate_priority(int step_plus_slot) {
+#if SE3_ROTATE_PRIO
+  switch (step_plus_slot & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+#endif
+}
+__device__ __forceinline__ int wave_slot_id() { return (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) ; }  // HW_ID[3:0]
+
 inline int check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH;

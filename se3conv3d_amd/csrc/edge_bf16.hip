@@ -486,26 +486,6 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
 // neighbouring extents and write neighbouring rows, and a cloud's dense regions are spread over all of them.
 // Rows without neighbours are one chunk of zero frame-edges (every lane reads out of bounds: zero rows are stored).
 // ------------------------------------------------------------------------------------------------
-// Rotating wave priority (round 6).  The SIMD's arbiter prefers the OLDEST wavefront among equals, so the resident
-// wavefronts of a SIMD do not advance at one rate: stamped, the four of a SIMD finish at 0.59 / 0.70 / 0.89 / 1.00 of its
-// span although they hold the same work to 5 % (profiles/r06_edge_timeline.txt) -- a fifth of the slot time is idle and the
-// last wavefront runs alone, where nothing covers its latencies.  Every wavefront therefore takes priority
-// (step + its slot) mod 4 and moves on by one every chunk: each is the preferred one a quarter of the time.
-#ifndef SE3_ROTATE_PRIO
-#define SE3_ROTATE_PRIO 1
-#endif
-__device__ __forceinline__ void rotate_priority(int step_plus_slot) {
-#if SE3_ROTATE_PRIO
-  switch (step_plus_slot & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-  }
-#endif
-}
-__device__ __forceinline__ int wave_slot_id() { return (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) ; }  // HW_ID[3:0]
-
 struct ChunkCursor {
   int j;        // local item index; n_mine = past the end
   int c0;       // first frame-edge of the chunk

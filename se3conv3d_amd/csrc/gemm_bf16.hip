@@ -709,6 +709,8 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void gemm_strip_bf16_kernel(c
   int n0 = n_lo + (int)(((blockIdx.x * 4 + wave) * (unsigned)SE3_STRIP_ROT) % (unsigned)n_tiles) * 32;
   load_b(n0);
   SE3_WAIT_B(0);
+  // (rotating wave priority, common.h rotate_priority, was measured here too -- every strip is resident for the whole
+  // launch -- and loses 2 %: the kernel is bound by its stores, not by issue slots; profiles/r06_rotate_priority_ab.txt)
   for (int it = 0; it < n_tiles; ++it) {
     f32x16 acc = zero16();
 #pragma unroll
