@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     TL(tl_seg(tl_rec, tl_prev, 7);)  // 7: barrier (image complete)
 
     for (int c0 = c_first; c0 < n_total; c0 += CSTEP) {
-      if (PAIR) rotate_priority(prio_step++);  // resident workgroups: see rotate_priority
+      rotate_priority(prio_step++);  // resident workgroups (every form of this kernel walks its items grid-stride): common.h
       const int cnt = min(32, n_total - c0);
       // rows past the end of the edge list read zeros (out-of-bounds buffer loads): gphi = 0 there, no mask needed
       const int qoff = c0 + kcol < n_total ? q_a * row_bytes + c_off * 4 : kOobOffset;
