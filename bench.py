@@ -41,7 +41,7 @@ METRIC = "Mpoints/sec fwd+bwd PNEConvLayerRotEquiv (N=64k,k=32,F=2)"
 # In "bf16x3" every multiply costs 3 bf16 MFMA products, so mfma_frac <= 1/3 by construction there.
 PEAK_MFMA_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3_t16": 2500.0}
 PEAK_HBM_GBPS = 8000.0          # HBM3E spec
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06_traffic.json")
 
 
 def library_source_sha() -> str:

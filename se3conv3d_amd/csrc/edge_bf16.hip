@@ -57,8 +57,8 @@ __device__ __forceinline__ void tl_pin(const T& x) { asm volatile("" ::"v"(x)); 
 __device__ __forceinline__ void tl_mark(uint32_t* rec, int slot) { const uint32_t t = tl_now(); if (slot < kTlWords) rec[slot] = t; }
 // persistent kernels: the time since the previous stamp is added to segment `slot`
 __device__ __forceinline__ void tl_seg(uint32_t* rec, uint32_t& prev, int slot) { const uint32_t t = tl_now(); rec[slot] += t - prev; prev = t; }
-__device__ __forceinline__ void tl_flush(int region, uint32_t idx, const uint32_t* rec) {
-  if (g_tl_buf == nullptr || idx >= g_tl_cap) return;
+__device__ __forceinline__ void tl_flush(int region, uint32_t idx, const uint32_t* rec, int n_words = kTlWords) {
+  if (g_tl_buf == nullptr || idx >= g_tl_cap || (int)(threadIdx.x & 63) >= n_words) return;
   g_tl_buf[((size_t)region * g_tl_cap + idx) * kTlWords + (threadIdx.x & 63)] = rec[threadIdx.x & 63];
 }
 }  // namespace se3
@@ -878,7 +878,8 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
   float(*lds_red)[kDescExt][kBasis] = reinterpret_cast<float(*)[kDescExt][kBasis]>(&lds_gt[0][0][0][0][0][0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (parameter-gradient timeline: segment sums, words 0 .. 15 as named at the stamps; [16] items, [17] chunks, [18] first stamp, [19] last)
-  TL(__shared__ uint32_t tl_lds[NW][kTlWords]; uint32_t* tl_rec = tl_lds[wave]; tl_rec[lane] = 0u; uint32_t tl_prev = tl_now(); tl_rec[18] = tl_prev;)
+  // (32 words per wavefront: with 64 the pair form's workgroup crosses an LDS allocation granule and only five fit a CU)
+  TL(__shared__ uint32_t tl_lds[NW][32]; uint32_t* tl_rec = tl_lds[wave]; if (lane < 32) tl_rec[lane] = 0u; uint32_t tl_prev = tl_now(); tl_rec[18] = tl_prev;)
   const int img = PAIR ? 0 : wave;  // which grad_T image this wavefront reads
   const int kcol = lane & 31, h = lane >> 5;
   // MLP weights [A; beta] as the MFMA B operand.  LEAN: arrangement 0 (lane half 0 holds descriptor dims 0..7, half 1
@@ -1261,7 +1262,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
   }
   TL(tl_seg(tl_rec, tl_prev, 15); tl_rec[19] = tl_prev;  // 15: accumulator drain + workgroup reduction
      tl_rec[20] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); tl_rec[21] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
-     tl_flush(2, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave, tl_rec);)
+     tl_flush(2, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave, tl_rec, 32);)
 }
 
 // [N,3] points + [N,F,9] frames -> one 64-byte record per (point, frame) row, see load_geom_record

@@ -34,6 +34,9 @@ def main():
             name = m.group(1)
             counts[name] = collections.Counter()
             continue
+        if line.startswith(".Lfunc_end"):  # (not s_endpgm: the exit block may be laid out in front of the loop body)
+            name = None
+            continue
         if name is None or not line.startswith("\t"):
             continue
         op = line.strip().split()[0] if line.strip() else ""
@@ -45,8 +48,6 @@ def main():
         c["scratch"] += op.startswith("scratch_")
         c["mfma"] += op.startswith("v_mfma")
         c["waitcnt"] += op == "s_waitcnt"
-        if op == "s_endpgm":
-            name = None
     print(f"{'kernel':70s} {'VGPR':>5s} {'spill':>5s} {'LDS':>6s} {'w/SIMD':>6s} {'instr':>6s} {'branch':>6s} {'scratch':>7s} {'mfma':>5s}")
     for k, u in usage.items():
         if filt not in k:
