@@ -361,7 +361,9 @@ __global__ __launch_bounds__(256 * KG) void gemm_nn_t24_kernel(const uint8_t* __
   store_half(NEXT, 0, 0);                \
   __syncthreads();
   int st = 0;
+  const int prio_slot = wave_slot_id();
   for (; st + 4 <= ns; st += 2) {  // no conditions around the loads (see gemm_nn_bf16_kernel)
+    rotate_priority(prio_slot + (st >> 1));
     SE3_T24_STEP_FULL(t0, t1, st)
     SE3_T24_STEP_FULL(t1, t0, st + 1)
   }
@@ -1080,7 +1082,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const uint32_t* __res
     __syncthreads();                                                 \
   }
     int64_t st = 0;
+    const int prio_slot = wave_slot_id();
     for (; st + 6 <= nst; st += 3) {
+      rotate_priority(prio_slot + (int)(st / 3));  // every workgroup of this product is resident for the whole launch (common.h)
       SE3_TN_STEP_FULL(st, t0, t1)
       SE3_TN_STEP_FULL(st + 1, t1, t2)
       SE3_TN_STEP_FULL(st + 2, t2, t0)
