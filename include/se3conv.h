@@ -537,8 +537,8 @@ int se3_profile_tags(char* buf, size_t len);
  *   SE3_OVERLAP, SE3_OVERLAP_ROWS   two-stream backward pass (see se3_set_overlap_rows; opt-in since round 5)
  *   SE3_BWD_BRANCH_ORDER  backward kernels branch by branch instead of writers first
  *   SE3_NO_PAIR, SE3_FC1  single-wavefront edge kernel instead of the wave pair / one frame per wavefront
- *   SE3_EDGE_STREAM       chunk-stream form of the wave-pair edge kernel (round 6): n > 0 = from n items up (default 4096,
- *                         1 = every size), 0 = never
+ *   SE3_EDGE_STREAM       chunk-stream forms of the edge kernel (round 6: 64-channel rows with two frames per item, 32-channel
+ *                         rows with two frames per item): n > 0 = from n items up (default 4096, 1 = every size), 0 = never
  *   SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32)   forms of the parameter-gradient kernel
  *   SE3_NN_SPLITS         split-K count of the dense products (default: cost model)
  *   SE3_NN_KG             =2: two k groups per workgroup in the dense products over 3-byte rows of under-filled levels

@@ -710,6 +710,241 @@ __global__ __launch_bounds__(128, SE3_PAIR_WAVES) void edge_t_stream_bf16_kernel
 }
 
 // ------------------------------------------------------------------------------------------------
+// Chunk-stream form of the single-wavefront kernel (round 6; rows of 32 * VW channels in one pass, power-of-two neighbour
+// frame count, 3-byte rows; launched for <VW, FC> = <1, 2> -- 32-channel rows, two frames per item -- the other forms
+// measured no better than their one-item kernels, see launch_edge_t_bf16).  Same idea as the
+// wave-pair stream above, and simpler: the four wavefronts of a workgroup share nothing but the MLP weights in LDS, so
+// each walks the chunks of ITS items (item_lo + wavefront index + j * wavefronts of the grid) with no barrier in the loop.
+// FC = 2: lane half h builds descriptors against centre frame a0 + h, whose record it holds in registers -- selected from
+// the two records that came through the scalar cache one chunk ahead; FC = 1: the centre record stays in SGPRs.
+// ------------------------------------------------------------------------------------------------
+template <int VW, int FC, int TR>
+__global__ __launch_bounds__(256, (VW == 1 && FC == 1) ? 4 : 3) void edge_t_stream1_bf16_kernel(
+    EdgeGeom g, const uint32_t* __restrict__ feat, int64_t feat_rows, const float* __restrict__ axes_ext,
+    const float* __restrict__ rho_p, char* __restrict__ t_out, uint32_t item_lo, uint32_t item_hi, int fnb_shift) {
+  constexpr int C = 32 * VW, row_bytes = C * 4;
+  __shared__ __attribute__((aligned(16))) uint32_t lds_w[FC][2][64][4];
+  const int lane = threadIdx.x & 63;
+  const int kcol = lane & 31, h = lane >> 5;
+  if (threadIdx.x < 64) mlp_weights_to_lds<FC>(lds_w, axes_ext, threadIdx.x);
+  __syncthreads();
+  const float rho = *rho_p;
+  const __amdgpu_buffer_rsrc_t feat_rs = buffer_of(feat, feat_rows * row_bytes);
+  const __amdgpu_buffer_rsrc_t nbg_rs = buffer_of(g.nb_geom, g.n_nb * g.f_nb * 64);
+  const __amdgpu_buffer_rsrc_t nbr_rs = buffer_of(g.nbr, g.n_edges * g.nbr_stride * 4);  // ids past the list read 0
+  const uint32_t groups = (uint32_t)g.f_ctr / (uint32_t)FC;
+  const uint32_t n_waves = gridDim.x * 4u;
+  const uint32_t item0_wave = item_lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+  // (a wavefront past the end of the range -- the last workgroup's -- has no items and falls through both loops)
+  const int n_all = item0_wave < item_hi ? (int)((item_hi - item0_wave + n_waves - 1) / n_waves) : 0;
+  const int fmask = (1 << fnb_shift) - 1;
+  const int hb = 16 * h;
+  const int cb4 = VW * kcol * 4;
+
+  f32x16 acc[FC][VW];
+#pragma unroll
+  for (int a = 0; a < FC; ++a)
+#pragma unroll
+    for (int t = 0; t < VW; ++t) acc[a][t] = zero16();
+  int prio_step = wave_slot_id();
+  for (int win0 = 0; win0 < n_all; win0 += 64) {  // windows of 64 items, as above
+  const int n_mine = min(64, n_all - win0);
+  const uint32_t item0 = item0_wave + (uint32_t)win0 * n_waves;
+  int v_lo, v_hi;
+  {
+    const uint32_t item = item0 + (uint32_t)min(lane, n_mine - 1) * n_waves;
+    const uint32_t ctr = item / groups;
+    v_hi = g.ends[ctr];
+    v_lo = g.ends[max((int)ctr - 1, 0)];
+    if (ctr == 0) v_lo = 0;
+  }
+  auto uni = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  auto enter = [&](int j, int crow_keep, uint32_t item_keep) {  // first chunk of local item j, or the end mark
+    ChunkCursor c;
+    c.j = j, c.c0 = 0, c.start = 0, c.n_total = 0;
+    c.crow = crow_keep, c.item = item_keep;
+    if (j < n_mine) {
+      const int lo = __builtin_amdgcn_readlane(v_lo, j), hi = __builtin_amdgcn_readlane(v_hi, j);
+      c.start = lo, c.n_total = (hi - lo) << fnb_shift;
+      c.item = item0 + (uint32_t)j * n_waves;
+      const uint32_t ctr = c.item / groups;
+      c.crow = uni((int)(ctr * (uint32_t)g.f_ctr + (c.item - ctr * groups) * (uint32_t)FC));  // the item's first centre row
+    }
+    return c;
+  };
+  auto advance = [&](const ChunkCursor& c) {
+    ChunkCursor r = c;
+    if (c.c0 + 32 < c.n_total) r.c0 = c.c0 + 32;
+    else if (c.j < n_mine) r = enter(c.j + 1, c.crow, c.item);
+    r.j = uni(r.j), r.c0 = uni(r.c0), r.start = uni(r.start), r.n_total = uni(r.n_total), r.item = (uint32_t)uni((int)r.item);
+    return r;
+  };
+  auto fe_of = [&](const ChunkCursor& c) { return max(min(c.c0 + kcol, c.n_total - 1), 0); };
+  auto nbr_of = [&](const ChunkCursor& c) {
+    const int e = c.start + (fe_of(c) >> fnb_shift);
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(nbr_rs, (e * g.nbr_stride + g.nbr_offset) * 4, 0, 0);
+  };
+  auto row_of = [&](int nb, const ChunkCursor& c) { return (nb << fnb_shift) + (fe_of(c) & fmask); };
+  typedef const f32x4 __attribute__((address_space(4))) * crec_t;
+  const crec_t ctr_rec = (crec_t)(uintptr_t)g.ctr_geom;
+  // the centre record(s) of chunk c: through the scalar cache; FC = 2: the record of frame a0 + h per lane half
+  auto centre = [&](const ChunkCursor& c, float yc[3], float rc[9]) {
+    const int row = c.crow;
+    const f32x4 v0 = ctr_rec[row * 4], v1 = ctr_rec[row * 4 + 1], v2 = ctr_rec[row * 4 + 2];
+    if constexpr (FC == 2) {
+      const f32x4 w0 = ctr_rec[row * 4 + 4], w1 = ctr_rec[row * 4 + 5], w2 = ctr_rec[row * 4 + 6];
+      yc[0] = h ? w0[0] : v0[0], yc[1] = h ? w0[1] : v0[1], yc[2] = h ? w0[2] : v0[2], rc[8] = h ? w0[3] : v0[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rc[i] = h ? w1[i] : v1[i], rc[4 + i] = h ? w2[i] : v2[i];
+    } else {
+      yc[0] = v0[0], yc[1] = v0[1], yc[2] = v0[2], rc[8] = v0[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rc[i] = v1[i], rc[4 + i] = v2[i];
+    }
+  };
+
+  ChunkCursor cur, n1, n2;
+  cur = enter(0, 0, 0u);
+  n1 = advance(cur);
+  n2 = advance(n1);
+  int q_cur, q_n1;
+  float xn_nx[3], rn_nx[9];
+  {
+    const int nb_cur = nbr_of(cur);
+    const int nb_n1 = nbr_of(n1);
+    q_cur = row_of(nb_cur, cur);
+    load_geom_record(nbg_rs, q_cur, xn_nx, rn_nx);
+    q_n1 = row_of(nb_n1, n1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(xn_nx[i]));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(rn_nx[i]));
+  }
+  float yc[3], rc[9];
+  centre(cur, yc, rc);
+
+  while (cur.j < n_mine) {
+    rotate_priority(prio_step++);
+    const int cnt = min(32, cur.n_total - cur.c0);  // <= 0: a row without neighbours
+    const int qoff = cur.c0 + kcol < cur.n_total ? q_cur * row_bytes : kOobOffset;
+    float xn[3], rn[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xn[i] = xn_nx[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rn[i] = rn_nx[i];
+    const int nb_n2 = nbr_of(n2);  // ids two chunks ahead
+
+    uint32_t fw[2][VW][8];  // gathered feature words of the chunk's two k-steps (shared by the FC rows)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
+        if constexpr (VW == 2) {
+          const auto v = __builtin_amdgcn_raw_buffer_load_b64(feat_rs, src_off + cb4, 0, 0);
+          fw[s][0][j] = v[0], fw[s][1][j] = v[1];
+        } else {
+          fw[s][0][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, src_off + cb4, 0, 0);
+        }
+      }
+    load_geom_record(nbg_rs, q_n1, xn_nx, rn_nx);  // record one chunk ahead
+    float yn[3], rnc[9];
+    centre(n1, yn, rnc);  // the next chunk's centre (the same record until the item changes)
+
+    if (TR == 0)
+      edge_descriptor(xn, rn, yc, rc, rho, d);
+    else
+      edge_descriptor(yc, rc, xn, rn, rho, d);
+
+    // MLP A operand pieces of this lane (edge_bf16_body.h): its own dims 0..7, and {dim 8 of the row it serves as "other" half, 1}
+    u32x4 own_hi, own_lo, oth_hi, oth_lo;
+    frags_from_floats(d, own_hi, own_lo);
+    {
+      float d8 = d[8];
+      if constexpr (FC == 2) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d8), __float_as_uint(d8), false, false);
+        d8 = __uint_as_float(h ? sw[0] : sw[1]);
+      }
+      uint32_t p_hi, p_lo;
+      split2(d8, 1.0f, p_hi, p_lo);
+      oth_hi = u32x4{p_hi, 0u, 0u, 0u};
+      oth_lo = u32x4{p_lo, 0u, 0u, 0u};
+    }
+    u32x4 fa_hi[2][VW], fa_lo[2][VW];
+#pragma unroll
+    for (int a = 0; a < FC; ++a) {
+      const bool dims07 = FC == 1 ? h == 0 : h == a;
+      u32x4 a_hi, a_lo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a_hi[i] = dims07 ? own_hi[i] : oth_hi[i];
+        a_lo[i] = dims07 ? own_lo[i] : oth_lo[i];
+      }
+      const u32x4 wb_hi = *reinterpret_cast<const u32x4*>(&lds_w[a][0][lane][0]);
+      const u32x4 wb_lo = *reinterpret_cast<const u32x4*>(&lds_w[a][1][lane][0]);
+      const f32x16 phi = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s * 16 < cnt) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
+          u32x4 b_hi, b_lo;
+          frags_from_floats(pv, b_hi, b_lo);
+#pragma unroll
+          for (int t = 0; t < VW; ++t) {
+            if (a == 0) frags_from_words(fw[s][t], fa_hi[s][t], fa_lo[s][t]);
+            acc[a][t] = mfma_bf16x3(fa_hi[s][t], fa_lo[s][t], b_hi, b_lo, acc[a][t]);
+          }
+        }
+      }
+    }
+    // every load of this chunk is consumed here, in front of the stores (see the wave-pair stream)
+    q_cur = q_n1;
+    q_n1 = row_of(nb_n2, n2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(xn_nx[i]));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(rn_nx[i]));
+    if (n1.j != cur.j) {
+      // the item's last chunk: acc[a][t] register r, lane (kcol, h) = T[row FC item + a][VW acc_row(r, h) + t][kcol] leaves
+      // as 3-byte rows (two adjacent channels of this lane = one hi word + one lo half-word), non-temporal
+#pragma unroll
+      for (int a = 0; a < FC; ++a) {
+        char* row = t_out + ((int64_t)cur.item * FC + a) * t24_row_bytes(C);
+        if constexpr (VW == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            uint32_t hp, lp;
+            t24_pack2(acc[a][0][r], acc[a][1][r], hp, lp);
+            const int idx = acc_row(r, h) * kBasis + kcol;
+            __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
+            __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2) + idx);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            uint32_t hp, lp;
+            t24_pack2(acc[a][0][r], acc[a][0][r + 1], hp, lp);
+            const int idx = (acc_row(r, h) >> 1) * kBasis + kcol;
+            __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
+            __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2) + idx);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < VW; ++t) acc[a][t] = zero16();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yc[i] = yn[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rc[i] = rnc[i];
+    cur = n1, n1 = n2, n2 = advance(n2);
+  }
+  }  // windows
+}
+
+// ------------------------------------------------------------------------------------------------
 // Gradient of the kernel-MLP parameters (cf. edge_param_grad_kernel in edge_kernels.hip):
 //   gphi[n,k] = sum_i feat[q(n), i] * gT[m][i,k]   rows n, cols k, k-dim = channels, 16 per MFMA:
 //               A: lane (n,h) reads words feat[q(n)][i0 + 8h .. +7]  (32 contiguous bytes)
@@ -1333,6 +1568,29 @@ bool edge_t_bf16_t16_rows(const EdgeGeom& g, int channels) {
   return channels % 64 == 0 && edge_t_bf16_uses_pair(g, channels);
 }
 
+#ifndef SE3_STREAM1
+#define SE3_STREAM1 1  // 0: diagnostic build without the single-wavefront chunk-stream kernel (A/B against the one-item form)
+#endif
+// items below which the chunk-stream kernels are not used (SE3_EDGE_STREAM=n: n items; 0: never)
+static int edge_stream_min_items() {
+  static const int v = [] {
+    const char* e = getenv("SE3_EDGE_STREAM");
+    return e ? (atoi(e) > 0 ? atoi(e) : INT32_MAX) : 4096;
+  }();
+  return v;
+}
+
+static int device_cu_count() {  // of the current device (the resident grids are sized by it); <= 0: the query failed
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+
 // row_lo / row_hi (multiples of 2 for even F; < 0: everything): only the rows in that range are produced -- the
 // wave-pair kernel supports it (edge_t_bf16_row_ranges), which lets the caller interleave producer and consumer
 // launches over slices of the rows
@@ -1366,19 +1624,10 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
     if (n_range <= 0) return SE3_OK;
     // chunk-stream form (resident workgroups, the chunk pipeline running across item boundaries): 64-channel rows, two
     // frames per item, power-of-two neighbour frame count, 3-byte rows; SE3_EDGE_STREAM=0 keeps the one-item workgroups
-    static const int stream_min_items = [] {
-      const char* e = getenv("SE3_EDGE_STREAM");
-      return e ? (atoi(e) > 0 ? atoi(e) : INT32_MAX) : 4096;
-    }();
-    if (channels == 64 && two && shift >= 0 && rowfmt == 1 && n_range >= stream_min_items && g.n_edges > 0 &&
+    if (channels == 64 && two && shift >= 0 && rowfmt == 1 && n_range >= edge_stream_min_items() && g.n_edges > 0 &&
         g.n_edges * g.nbr_stride * 4 < (int64_t)kOobOffset && item_hi < (1ll << 31)) {
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      }
+      const int n_cu = device_cu_count();
+      if (n_cu <= 0) return SE3_ERR_LAUNCH;
       constexpr int per_cu = 2 * SE3_PAIR_WAVES;  // 18 KB of LDS and <= 128 VGPRs: eight two-wavefront workgroups per CU
       int64_t wgs = (int64_t)n_cu * per_cu;  // resident workgroups only, whatever the level's size (windows of 64 items inside)
       if (wgs > n_range) wgs = n_range;
@@ -1419,6 +1668,27 @@ int launch_edge_t_bf16(const char* tag, const EdgeGeom& g, const uint32_t* feat,
   // row range: items of fc rows each
   const int64_t s_item_lo = row_lo >= 0 ? row_lo / fc : 0, s_item_hi = row_lo >= 0 ? row_hi / fc : items;
   if (s_item_hi <= s_item_lo) return SE3_OK;
+  // chunk-stream form of the single-wavefront kernel: rows of 32 channels, two frames per item.  Measured per form
+  // (profiles/r06_edge_stream1_ab.txt): <1, 2> -8 % at two frames (items of ~2 chunks: dfaust_f2 0.191 -> 0.177 ms), -1 % at
+  // four; <2, 1> (64-channel rows at one frame, the ScanNet scene: items of ONE chunk, so every chunk ends in its stores
+  // and there is no pipeline to carry across) +1 %, and +6 % when squeezed to four wavefronts per SIMD (7 spilled
+  // registers) -- those rows keep the one-item form.
+  if (SE3_STREAM1 && t24 && shift >= 0 && channels == 32 && fc == 2 && s_item_hi - s_item_lo >= edge_stream_min_items() &&
+      g.n_edges > 0 && g.n_edges * g.nbr_stride * 4 < (int64_t)kOobOffset && s_item_hi < (1ll << 31)) {
+    const int n_cu = device_cu_count();
+    if (n_cu <= 0) return SE3_ERR_LAUNCH;
+    constexpr int per_cu = 3;  // = the kernel's launch bounds: resident workgroups only
+    int64_t wgs = (int64_t)n_cu * per_cu;
+    if (wgs > (s_item_hi - s_item_lo + 3) / 4) wgs = (s_item_hi - s_item_lo + 3) / 4;
+    const dim3 sgrid((unsigned)wgs);
+    if (g.transposed)
+      hipLaunchKernelGGL((edge_t_stream1_bf16_kernel<1, 2, 1>), sgrid, block, 0, stream, g, feat, feat_rows, axes_ext, rho,
+                         reinterpret_cast<char*>(t_out), (uint32_t)s_item_lo, (uint32_t)s_item_hi, shift);
+    else
+      hipLaunchKernelGGL((edge_t_stream1_bf16_kernel<1, 2, 0>), sgrid, block, 0, stream, g, feat, feat_rows, axes_ext, rho,
+                         reinterpret_cast<char*>(t_out), (uint32_t)s_item_lo, (uint32_t)s_item_hi, shift);
+    return check_launch();
+  }
   const dim3 grid((unsigned)((s_item_hi - s_item_lo + 3) / 4));
 #define SE3_LAUNCH(VW, FC, FULL, T24)                                                                                 \
   hipLaunchKernelGGL((edge_t_bf16_kernel<VW, FC, FULL, T24>), grid, block, 0, stream, g, feat, channels, feat_rows,     \
@@ -1510,13 +1780,8 @@ int launch_edge_param_grad_bf16(const char* tag, const EdgeGeom& g, const uint32
       return e == nullptr || atoi(e) != 0;
     }();
     if (pair_on && two && (channels >= 64 || (channels == 32 && pair32_on))) {
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return SE3_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      }
+      const int n_cu = device_cu_count();
+      if (n_cu <= 0) return SE3_ERR_LAUNCH;
       static const int per_cu = [] {
         const char* e = getenv("SE3_PG_PAIR_WGS");
         return e ? atoi(e) : (SE3_PG_PAIR_LEAN ? 8 : 6);  // 19 KB / 26 KB of LDS per workgroup

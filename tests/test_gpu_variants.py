@@ -9,9 +9,10 @@ re-running a slice of the parity suite in a child process with the variable set:
   SE3_BWD_BRANCH_ORDER=1  backward kernels branch by branch instead of writers first
   SE3_DX_PATH=1     feature gradient edge-major (edge_dx.hip) wherever it is implemented (the default decides by the bytes
                     either form moves -- down-convolutions and sparse levels only -- so the rest of the suite runs the U form)
-  SE3_EDGE_STREAM=1 the chunk-stream form of the wave-pair edge kernel (round 6: resident workgroups, the chunk pipeline running
-                    across item boundaries) at every size -- by default it takes levels of 4 096 items and up, so the small
-                    parity cases would never reach it
+  SE3_EDGE_STREAM=1 the chunk-stream forms of the edge kernel (round 6: resident workgroups, the chunk pipeline running across
+                    item boundaries; the wave-pair form for 64-channel rows and the single-wavefront form for 32-channel
+                    rows, two frames per item) at every size -- by default they take levels of 4 096 items and up, so the
+                    small parity cases would never reach them
   SE3_NN_KG=2       the dense products over 3-byte rows of under-filled levels with two k groups per workgroup (round 5; lost
                     its A/B, profiles/r05_nn_kgroups_ab.txt)
   SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2  the row-sliced schedule of round 5 (every producer -> consumer pair per slice of the
