@@ -446,6 +446,13 @@ int se3_knn_query_grid(const float* pts, const int32_t* batch_ids, const float* 
                        size_t workspace_bytes, void* stream);
 int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, int32_t axis_fixed,
                    float* frames, void* stream);
+/* The random choice among a point's PCA frames (point_cloud_lib/pc/PointcloudRotEquiv.py:100-117, 146-167: torch.multinomial
+ * without replacement on equal weights, then a gather): out[p, j] = all_frames[p, perm_p[j]] for j < n_frames, perm_p = the
+ * order of point p's n_all uniform draws (ascending; ties to the lower index) -- a uniformly random permutation per point,
+ * the draws being the caller's (torch.rand on the device: the library owns no generator).  all_frames [n, n_all, 9],
+ * draws [n, n_all] f32 -> out [n, n_frames, 9]; n_all <= 8.  One launch instead of the sort + gather (round 6). */
+int se3_shuffle_frames(const float* all_frames, const float* draws, int64_t n, int32_t n_all, int32_t n_frames, float* out,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row-wise glue of a block around the convolution (scope row f-3)  <-  the torch element-wise / reduction passes of

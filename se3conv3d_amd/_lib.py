@@ -88,6 +88,7 @@ SIGNATURES = {
     "se3_knn_grid_params": (C.c_int, [_P, _I64, _P, _P, _I32, _I32, C.c_float, _P, _P, _P, _P]),
     "se3_knn_query_grid": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_size_t, _P]),
     "se3_pca_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
+    "se3_shuffle_frames": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "se3_glue_workspace_bytes": (_SZ, [_I32]),
     "se3_bn_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "se3_affine_act": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),

@@ -345,6 +345,47 @@ extern "C" int se3_knn_query_pair(const float* src_pts, const int32_t* src_batch
   return launch_knn_bruteforce(src_pts, src_batch, n_src, q_pts, q_batch, n_q, (int)k, out, (hipStream_t)stream);
 }
 
+namespace se3 {
+namespace {
+// out[p, j] = all[p, perm_p[j]], perm_p = the order of point p's n_all uniform draws (ascending value, ties to the lower
+// index): a uniformly random permutation per point.  One thread per (point, output frame).
+__global__ __launch_bounds__(256) void shuffle_frames_kernel(const float* __restrict__ all, const float* __restrict__ rnd,
+                                                             int64_t n, int n_all, int n_frames, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * n_frames) return;
+  const int64_t p = t / n_frames;
+  const int j = (int)(t - p * n_frames);
+  // the draw of rank j: the one with exactly j draws in front of it
+  int src = 0;
+  for (int a = 0; a < n_all; ++a) {
+    const float va = rnd[p * n_all + a];
+    int rank = 0;
+    for (int b = 0; b < n_all; ++b) {
+      const float vb = rnd[p * n_all + b];
+      rank += (vb < va || (vb == va && b < a)) ? 1 : 0;
+    }
+    if (rank == j) src = a;
+  }
+  const float* f = all + (p * n_all + src) * 9;
+  float* o = out + t * 9;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o[i] = f[i];
+}
+}  // namespace
+}  // namespace se3
+
+extern "C" int se3_shuffle_frames(const float* all_frames, const float* draws, int64_t n, int32_t n_all, int32_t n_frames,
+                                  float* out, void* stream) {
+  if (n < 0 || n_all < 1 || n_frames < 1 || n_frames > n_all) return SE3_ERR_INVALID_ARGUMENT;
+  if (n_all > 8) return SE3_ERR_UNSUPPORTED;  // the reference's PCA frames come in sets of 4 (2 with a fixed axis)
+  if (n == 0) return SE3_OK;
+  if (!all_frames || !draws || !out) return SE3_ERR_INVALID_ARGUMENT;
+  const int64_t threads = n * n_frames;
+  hipLaunchKernelGGL(se3::shuffle_frames_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     all_frames, draws, n, (int)n_all, (int)n_frames, out);
+  return check_launch();
+}
+
 extern "C" int se3_pca_frames(const float* pts, const int32_t* knn, int64_t n, int32_t k, int32_t axis_fixed,
                               float* frames, void* stream) {
   if (n < 0 || k < 1 || axis_fixed > 2) return SE3_ERR_INVALID_ARGUMENT;

@@ -366,11 +366,28 @@ __global__ __launch_bounds__(256) void batch_aabb_kernel(const float* __restrict
         const float v = pts[ic * 3 + d];
         lo[d] = fminf(lo[d], v), hi[d] = fmaxf(hi[d], v);
       }
-    } else if (ok) {
+    } else {
+      // a 64-point group that straddles batch elements (ids are sorted: two of them, rarely more): one reduction and six
+      // atomics per element present -- per-point atomics here were 56 us on a 32-body batch of 58 k points, all of it on
+      // the 31 straddling groups (6 x 64 atomics on one line each)
+      flush();
+      cur = -1;
+      float v[3];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const float v = pts[ic * 3 + d];
-        atomic_min_f(&mn[b * 3 + d], v), atomic_max_f(&mx[b * 3 + d], v);
+      for (int d = 0; d < 3; ++d) v[d] = pts[ic * 3 + d];
+      uint64_t todo = __ballot(1);
+      while (todo) {
+        const int first = __builtin_ctzll(todo);
+        const int be = __shfl(b, first);
+        const bool mine = b == be;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          float l = mine ? v[d] : inf, h = mine ? v[d] : -inf;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) l = fminf(l, __shfl_xor(l, off)), h = fmaxf(h, __shfl_xor(h, off));
+          if ((threadIdx.x & 63) == 0) atomic_min_f(&mn[be * 3 + d], l), atomic_max_f(&mx[be * 3 + d], h);
+        }
+        todo &= ~__ballot(mine);
       }
     }
   }
@@ -599,8 +616,8 @@ static int batch_aabb_impl(const float* pts, const int32_t* batch_ids, int64_t n
   hipLaunchKernelGGL(batch_aabb_init_kernel, dim3((n_batches * 3 + 255) / 256), dim3(256), 0, stream, aabb_min, aabb_max,
                      n_batches * 3, num_cells_to_zero);
   if (n > 0) {
-    int64_t blocks = (n + 4095) / 4096;  // 16 groups of 64 points per wavefront before it issues its 6 atomics
-    if (blocks > 256) blocks = 256;
+    int64_t blocks = (n + 1023) / 1024;  // 4 groups of 64 points per wavefront before it issues its 6 atomics
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(batch_aabb_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pts, batch_ids, n, aabb_min,
                        aabb_max);
   }

@@ -601,6 +601,27 @@ def pca_frames(pts, knn_ids, axis_fixed=None) -> torch.Tensor:
     return frames
 
 
+def shuffle_frames(all_frames, n_frames: int, draws=None) -> torch.Tensor:
+    """``n_frames`` of each point's frames in a uniformly random order (``se3_shuffle_frames``; the ``torch.multinomial``
+    + gather of PointcloudRotEquiv.py:100-117, 146-167).  ``draws`` ``[N, n_all]`` uniform numbers (``torch.rand`` on
+    the device by default)."""
+    lib = _lib.load()
+    all_frames = _as(all_frames, torch.float32)
+    n, n_all = all_frames.shape[0], all_frames.shape[1]
+    dev = all_frames.device
+    if draws is None:
+        draws = torch.rand((n, n_all), device=dev)
+    draws = _as(draws, torch.float32)
+    if tuple(draws.shape) != (n, n_all):
+        raise ValueError(f"shuffle_frames: draws {tuple(draws.shape)}, expected {(n, n_all)}")
+    out = torch.empty((n, int(n_frames), all_frames.shape[2]), dtype=torch.float32, device=dev)
+    if all_frames.shape[2] != 9:
+        raise ValueError("shuffle_frames: frames are [N, n_all, 9]")
+    _lib.check(lib.se3_shuffle_frames(_ptr(all_frames, torch.float32, "all_frames"), _ptr(draws, torch.float32, "draws", dev), n,
+                                      n_all, int(n_frames), _ptr(out, torch.float32, "out"), _stream(dev)), "se3_shuffle_frames")
+    return out
+
+
 # ------------------------------------------------------------------- the operator's geometry bundle
 class PreparedRecords:
     """The packed 64-byte geometry records of one cloud (include/se3conv.h, struct se3conv_prepared): a function of the

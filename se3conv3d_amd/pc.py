@@ -59,12 +59,29 @@ def sample_reference_frames(n_origins: int, n_frames: int, axis_fixed=None, dtyp
 
 
 # ------------------------------------------------------------------------------------------ clouds
+def _repeat_rows(t, times):
+    """``t.repeat_interleave(times)`` for a 1-D tensor as one copy kernel (repeat_interleave is four launches and, without
+    an output size, a read-back)."""
+    return t[:, None].expand(-1, int(times)).reshape(-1)
+
+
+def _batches_of(cloud):
+    """The batch count a grid sub-sample of ``cloud`` has: its own (every batch element that holds a point keeps a cell, so
+    the largest id survives); None for foreign cloud objects."""
+    return cloud.num_batches() if hasattr(cloud, "num_batches") else None
+
+
 class Pointcloud(object):
     def __init__(self, p_pts, p_batch_ids, **kwargs):
         self.pts_with_grads_ = bool(kwargs.pop("requires_grad", False))
+        # num_batches (extension): the batch count when the caller knows it (a hierarchy level has its parent's) -- spares
+        # the read-back of batch_size_ the native calls' table sizes would otherwise cost once per cloud
+        known_batches = kwargs.pop("num_batches", None)
         self.pts_ = torch.as_tensor(p_pts, **kwargs)
         self.batch_ids_ = torch.as_tensor(p_batch_ids, **kwargs)
         self.batch_size_ = torch.max(self.batch_ids_) + 1
+        if known_batches is not None:
+            self._num_batches = int(known_batches)
         if self.pts_with_grads_:
             self.pts_.requires_grad = True
 
@@ -111,6 +128,7 @@ class PointcloudRotEquiv(Pointcloud):
 
     def __init__(self, p_pts, p_batch_ids, p_ref_frames_config, ref_frames_pts=None, standard_knn=False, **kwargs):
         super().__init__(p_pts, p_batch_ids, **kwargs)
+        kwargs.pop("num_batches", None)  # (consumed by Pointcloud.__init__; the rest are torch.as_tensor keywords)
         self.neigh_cache_ = {}
         self.local_frames_pca_cache_ = {}
         self.local_frames_config_ = p_ref_frames_config
@@ -119,7 +137,7 @@ class PointcloudRotEquiv(Pointcloud):
         frames = self.get_local_ref_frames()
         self.n_frames_ = frames.shape[1]
         self.local_frames_ = torch.as_tensor(frames, **kwargs)
-        self.batch_ids_considering_frames_ = self.batch_ids_.repeat_interleave(self.n_frames_)
+        self.batch_ids_considering_frames_ = _repeat_rows(self.batch_ids_, self.n_frames_)
 
     def get_ref_frame_neighborhood(self, p_neigh_method, **kwargs):
         """kNN / ball-query neighbourhood used to build PCA frames, memoised (PointcloudRotEquiv.py:54-75)."""
@@ -160,9 +178,16 @@ class PointcloudRotEquiv(Pointcloud):
             # PointcloudRotEquiv.py:131-167: all PCA frames once ("se3-all"), then a random permutation per point
             # (torch.multinomial without replacement) and the first n_frames
             if "se3-all" not in self.local_frames_pca_cache_:
-                nbh = self.get_ref_frame_neighborhood(cfg["neigh_method"], **cfg["neigh_kwargs"])
-                self.local_frames_pca_cache_["se3-all"] = sample_reference_frames_pca(
-                    self.pts_, nbh, axis_fixed=cfg.get("fixed_axis"), device=self.pts_.device)
+                if cfg["neigh_method"] == "knn" and "neigh_k" in cfg["neigh_kwargs"]:
+                    # the [N, k] id table straight into the PCA kernel; the neighbourhood OBJECT (its (sample, source)
+                    # list and offsets: seven more launches) is built from the same table when somebody asks for it
+                    # (get_ref_frame_neighborhood)
+                    ids = self._self_knn_ids(cfg["neigh_kwargs"]["neigh_k"])
+                    self.local_frames_pca_cache_["se3-all"] = ops.pca_frames(self.pts_, ids, cfg.get("fixed_axis"))
+                else:
+                    nbh = self.get_ref_frame_neighborhood(cfg["neigh_method"], **cfg["neigh_kwargs"])
+                    self.local_frames_pca_cache_["se3-all"] = sample_reference_frames_pca(
+                        self.pts_, nbh, axis_fixed=cfg.get("fixed_axis"), device=self.pts_.device)
             return self._shuffled_pca_frames(cfg["n_frames"])
         return sample_reference_frames(self.pts_.shape[0], cfg["n_frames"], axis_fixed=cfg.get("fixed_axis"),
                                        device=self.pts_.device)
@@ -171,12 +196,22 @@ class PointcloudRotEquiv(Pointcloud):
         """A random permutation of the cached PCA frames per point (torch.multinomial without replacement), first
         ``n_frames`` kept (PointcloudRotEquiv.py:100-117, 146-167)."""
         all_frames = self.local_frames_pca_cache_["se3-all"]
-        n_points, n_all = all_frames.shape[0], all_frames.shape[1]
         # a uniformly random permutation per point = the order of n_all independent uniform draws (the distribution of
-        # multinomial without replacement on equal weights; three launches instead of the ~15 of torch.multinomial's top-k
-        # path -- 0.14 ms per cloud of a DFaust step's six, profiles/r06_frames_ctor_kernel_stats.csv)
-        perm = torch.rand((n_points, n_all), device=self.pts_.device).argsort(dim=1)[:, :n_frames]
-        return torch.gather(all_frames, 1, perm[:, :, None].expand(-1, -1, all_frames.shape[-1]))
+        # multinomial without replacement on equal weights): torch.rand + one launch (se3_shuffle_frames) instead of the
+        # ~15 launches of torch.multinomial's top-k path (0.14 ms per cloud of a DFaust step's six,
+        # profiles/r06_frames_ctor_kernel_stats.csv) or the sort + gather that first replaced it
+        return ops.shuffle_frames(all_frames, n_frames)
+
+    def _self_knn_ids(self, k):
+        """``[N, k]`` int32 ids of the cloud's self-k-NN (``ops.knn_query``), memoised per k; what KnnNeighborhood builds
+        its lists from."""
+        cache = self.__dict__.setdefault("_se3_knn_ids", {})
+        key = (int(k), self.pts_.data_ptr(), self.pts_._version)
+        if key not in cache:
+            grid = self.pts_.shape[0] >= ops.KNN_GRID_MIN_POINTS and k <= 32
+            cache.clear()
+            cache[key] = ops.knn_query(self.pts_, self.batch_ids_, int(k), self.num_batches(), box=self.aabb() if grid else None)
+        return cache[key]
 
     @classmethod
     def from_frames(cls, p_pts, p_batch_ids, p_frames, p_ref_frames_config=None):
@@ -188,7 +223,7 @@ class PointcloudRotEquiv(Pointcloud):
         self.local_frames_config_ = p_ref_frames_config or {"pca": False, "n_frames": self.n_frames_,
                                                             "fixed_axis": False}
         self.ref_frames_pts = None
-        self.batch_ids_considering_frames_ = self.batch_ids_.repeat_interleave(self.n_frames_)
+        self.batch_ids_considering_frames_ = _repeat_rows(self.batch_ids_, self.n_frames_)
         return self
 
     def to_device(self, p_device):
@@ -371,9 +406,12 @@ class KnnNeighborhood(Neighborhood):
             # the op behind ops.KNNQuery (which stays for code that uses it directly), with what the cloud already knows:
             # its batch count and its boxes (no device read-back, no second pass over the points)
             pc = self.pc_src_
-            grid = pc.pts_.shape[0] >= ops.KNN_GRID_MIN_POINTS and self.k_ <= 32 and hasattr(pc, "aabb")
-            ids = ops.knn_query(pc.pts_, pc.batch_ids_, self.k_, pc.num_batches() if hasattr(pc, "num_batches") else None,
-                                box=pc.aabb() if grid else None)
+            if hasattr(pc, "_self_knn_ids"):
+                ids = pc._self_knn_ids(self.k_)  # the table the cloud's PCA frames were built from, when they were
+            else:
+                grid = pc.pts_.shape[0] >= ops.KNN_GRID_MIN_POINTS and self.k_ <= 32 and hasattr(pc, "aabb")
+                ids = ops.knn_query(pc.pts_, pc.batch_ids_, self.k_, pc.num_batches() if hasattr(pc, "num_batches") else None,
+                                    box=pc.aabb() if grid else None)
         else:
             ids = ops.knn_query_pair(self.pc_src_.pts_, self.pc_src_.batch_ids_, self.samples_.pts_,
                                      self.samples_.batch_ids_, self.k_)
@@ -471,7 +509,7 @@ class PointHierarchy(object):
         samp = _make_sub_sample(p_point_cloud, p_samp_method, p_id, **kwargs)
         new_pts = samp.__subsample_tensor__(p_point_cloud.pts_, "avg")
         new_bid = samp.__subsample_tensor__(p_point_cloud.batch_ids_, "max")
-        return Pointcloud(new_pts, new_bid), samp
+        return Pointcloud(new_pts, new_bid, num_batches=_batches_of(p_point_cloud)), samp
 
     def create_neighborhood(self, p_pc_src_id, p_pc_dest_id, p_neigh_method, **kwargs):
         """Memoised per (source level, destination level, method + its parameter), pc/PointHierarchy.py:60-79 (the k-NN
@@ -508,4 +546,5 @@ class PointHierarchyRotEquiv(PointHierarchy):
         samp = _make_sub_sample(p_point_cloud, p_samp_method, p_id, **kwargs)
         new_pts = samp.__subsample_tensor__(p_point_cloud.pts_, "avg")
         new_bid = samp.__subsample_tensor__(p_point_cloud.batch_ids_, "max")
-        return PointcloudRotEquiv(new_pts, new_bid, p_point_cloud.local_frames_config_), samp
+        return PointcloudRotEquiv(new_pts, new_bid, p_point_cloud.local_frames_config_,
+                                  num_batches=_batches_of(p_point_cloud)), samp

@@ -8,6 +8,7 @@ compared up to sign.  Points whose covariance has nearly equal eigenvalues are s
 comparison (ill-conditioned eigenvectors) but not for orthonormality / handedness."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -211,3 +212,62 @@ def test_global_frames_from_ref_frames_pts_and_standard_knn(built_library):
     a = amd.pc.PointcloudRotEquiv(pts, bid, cfg)
     s = amd.pc.PointcloudRotEquiv(pts, bid, cfg, standard_knn=True)
     assert torch.equal(a.local_frames_pca_cache_["se3-all"], s.local_frames_pca_cache_["se3-all"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_all,n_frames", [(5000, 4, 2), (3000, 4, 4), (777, 2, 1), (1, 4, 1), (0, 4, 2)])
+def test_shuffle_frames_is_the_order_of_the_draws(built_library, n, n_all, n_frames):
+    """se3_shuffle_frames against numpy: out[p, j] = all[p, argsort(draws[p])[j]] (stable: ties to the lower index), i.e.
+    the multinomial-without-replacement + gather of PointcloudRotEquiv.py:100-117, 146-167 with the draws given."""
+    import se3conv3d_amd as amd
+
+    g = torch.Generator().manual_seed(n + n_all)
+    allf = torch.randn(n, n_all, 9, generator=g)
+    draws = torch.rand(n, n_all, generator=g)
+    if n > 10:
+        draws[3] = 0.25          # all equal: input order
+        draws[4, -1] = draws[4, 0]
+    out = amd.ops.shuffle_frames(allf.to(DEV), n_frames, draws.to(DEV)).cpu()
+    perm = np.argsort(draws.numpy(), axis=1, kind="stable")[:, :n_frames]
+    want = np.take_along_axis(allf.numpy(), perm[:, :, None], axis=1)
+    assert out.shape == (n, n_frames, 9) and np.array_equal(out.numpy(), want)
+    if n >= 3000:  # the device's own draws: every frame position is taken about equally often
+        own = amd.ops.shuffle_frames(allf.to(DEV), n_frames).cpu()
+        first = (own[:, 0, None, :] == allf).all(-1).float().mean(0)
+        assert float((first - 1.0 / n_all).abs().max()) < 0.05
+    with pytest.raises(ValueError):
+        amd.ops.shuffle_frames(allf.to(DEV), n_frames, draws[:, :1].to(DEV))
+
+
+@pytest.mark.gpu
+def test_frame_neighbourhood_is_built_from_the_id_table_on_demand(built_library):
+    """A PCA-frame cloud keeps only the [N, k] id table of its k-NN; get_ref_frame_neighborhood builds the reference's
+    neighbourhood object (PointcloudRotEquiv.py:54-75) from that table when asked, and a hierarchy level inherits its
+    parent's batch count (no read-back), several batch elements of uneven size included."""
+    import se3conv3d_amd as amd
+
+    torch.manual_seed(8)
+    sizes = [700, 1, 2300, 64, 935]
+    pts = torch.cat([torch.rand(s, 3) + 2.0 * i for i, s in enumerate(sizes)]).to(DEV)
+    bid = torch.cat([torch.full((s,), i, dtype=torch.int32) for i, s in enumerate(sizes)]).to(DEV)
+    cfg = {"pca": True, "n_frames": 2, "fixed_axis": False, "neigh_method": "knn", "neigh_kwargs": {"neigh_k": 16}}
+    pc = amd.pc.PointcloudRotEquiv(pts, bid, cfg)
+    assert pc.neigh_cache_ == {}
+    ids = pc._self_knn_ids(16)
+    assert ids.shape == (4000, 16) and bool((ids[:, 0] == torch.arange(4000, device=DEV)).all())
+    nbh = pc.get_ref_frame_neighborhood("knn", neigh_k=16)
+    assert nbh.neighbors_.shape == (4000 * 16, 2)
+    assert bool((nbh.neighbors_[:, 1].reshape(4000, 16) == ids).all())
+    assert bool((nbh.neighbors_[:, 0].reshape(4000, 16) == torch.arange(4000, device=DEV)[:, None]).all())
+    assert bool((nbh.start_ids_ == torch.arange(1, 4001, device=DEV) * 16).all())
+    assert bool((ids[700] == torch.tensor([700] + [-1] * 15, device=DEV)).all())   # the one-point element: itself, then padding
+    # boxes per batch element (64-point groups that straddle elements take the segmented path of batch_aabb_kernel)
+    mn, mx = pc.aabb()
+    for i, s in enumerate(sizes):
+        sel = pts[bid == i]
+        assert torch.equal(mn[i], sel.amin(0)) and torch.equal(mx[i], sel.amax(0))
+    assert bool((pc.batch_ids_considering_frames_ == bid.repeat_interleave(2)).all())
+    hier = amd.pc.PointHierarchyRotEquiv(pc, 2, "grid_avg", grid_radii=[0.1, 0.2])
+    for lvl in hier.pcs_[1:]:
+        assert lvl._num_batches == 5 and int(lvl.batch_size_) == 5
+        assert lvl.local_frames_.shape == (lvl.pts_.shape[0], 2, 9)
