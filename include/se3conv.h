@@ -255,6 +255,19 @@ int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int
                            int64_t n_src, int64_t n_dst, int32_t n_batches, void* workspace, size_t workspace_bytes,
                            int64_t capacity, int32_t* neighbors, int32_t* sources, int32_t* ends, int32_t* info,
                            void* stream);
+/* The same with the SOURCE cloud's cell grid (cell keys, their sorted order, the points in that order) in a buffer of the
+ * caller's, so that the queries of a step that search one source cloud with one radius -- a level's same-level, down and
+ * up convolutions (PointHierarchy.create_neighborhood, pc/PointHierarchy.py:60-79, builds each from scratch) -- sort it
+ * once (round 6: 10 of the 26 queries of a DFaust step are such repeats, each ~50 us of key, sort and gather launches).
+ *   grid [se3_ball_query_grid_bytes(n_src)] (device), grid_valid: 0 = build the grid into it (then search), 1 = it holds
+ *   the grid an earlier call built from the same pts_src / batch_src / aabb_min / num_cells / radius / n_batches: search
+ *   only.  The workspace is sized as for se3_ball_query_bounded.  Same results, bit for bit. */
+size_t se3_ball_query_grid_bytes(int64_t n_src);
+int se3_ball_query_bounded_shared(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                  const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells, float radius,
+                                  int64_t n_src, int64_t n_dst, int32_t n_batches, void* grid, size_t grid_bytes,
+                                  int32_t grid_valid, void* workspace, size_t workspace_bytes, int64_t capacity,
+                                  int32_t* neighbors, int32_t* sources, int32_t* ends, int32_t* info, void* stream);
 
 /* Source-major (transposed) copy of an edge list, used by the backward pass in place of the
  * reference's global float atomics on the feature gradient (feat_basis_proj_grads.cu:126,140):
@@ -546,6 +559,8 @@ int se3_profile_tags(char* buf, size_t len);
  *   SE3_NO_PAIR, SE3_FC1  single-wavefront edge kernel instead of the wave pair / one frame per wavefront
  *   SE3_EDGE_STREAM       chunk-stream forms of the edge kernel (round 6: 64-channel rows with two frames per item, 32-channel
  *                         rows with two frames per item): n > 0 = from n items up (default 4096, 1 = every size), 0 = never
+ *   SE3_SHARED_GRIDS      (Python host side, se3conv3d_amd/ops.py) =0: every bounded ball query sorts its source cloud itself
+ *                         instead of sharing the grid per (cloud, radius) -- se3_ball_query_bounded_shared
  *   SE3_PG_SINGLE, SE3_PG_PAIR (+ _WGS, _C32)   forms of the parameter-gradient kernel
  *   SE3_NN_SPLITS         split-K count of the dense products (default: cost model)
  *   SE3_NN_KG             =2: two k groups per workgroup in the dense products over 3-byte rows of under-filled levels

@@ -65,6 +65,9 @@ SIGNATURES = {
     "se3_ball_query_count": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _P, _SZ, _P, _P]),
     "se3_ball_query_store": (C.c_int, [_P, _P, _F, _I64, _I64, _P, _SZ, _P, _I64, _P, _P]),
     "se3_ball_query_bounded": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _I32, _P, _SZ, _I64, _P, _P, _P, _P, _P]),
+    "se3_ball_query_grid_bytes": (_SZ, [_I64]),
+    "se3_ball_query_bounded_shared": (C.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _I64, _I32, _P, _SZ, _I32, _P, _SZ, _I64, _P,
+                                                _P, _P, _P, _P]),
     "se3_csr_transpose_workspace_bytes": (_SZ, [_I64]),
     "se3_csr_transpose": (C.c_int, [_P, _I64, _I64, _P, _SZ, _P, _P, _P, _P]),
     "se3_csr_transpose_bounded": (C.c_int, [_P, _I64, _P, _I64, _P, _SZ, _P, _P, _P, _P]),

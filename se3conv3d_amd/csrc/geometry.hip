@@ -816,10 +816,15 @@ extern "C" size_t se3_ball_query_workspace_bytes(int64_t n_src, int64_t n_dst) {
 
 // skip_scan: the all-pairs path of the bounded call with few samples leaves the per-sample counts in the workspace and
 // lets the store kernel form the offsets itself (scan_all_kernel<3>)
+// grid (may be NULL = inside the workspace): the source cloud's part of the layout -- keys, sorted keys / ids / records --
+// in a buffer of its own that outlives the call; grid_valid: it already holds this source cloud's grid for this radius
+// (built by an earlier call with the same pts_src / batch_src / aabb_min / num_cells / radius / key width), so the key,
+// sort and gather launches are skipped.
 static int ball_query_count_impl(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
                                  const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
                                  float radius, int64_t n_src, int64_t n_dst, void* workspace,
-                                 size_t workspace_bytes, int32_t* ends, bool skip_scan, int key_bits, void* stream_) {
+                                 size_t workspace_bytes, int32_t* ends, bool skip_scan, int key_bits, void* stream_,
+                                 void* grid = nullptr, bool grid_valid = false) {
   if (n_src < 0 || n_dst < 0 || !(radius > 0.f)) return SE3_ERR_INVALID_ARGUMENT;
   if (n_src >= (1ll << 31) || n_dst >= (1ll << 31) / 9) return SE3_ERR_UNSUPPORTED;
   if (n_dst == 0) return SE3_OK;
@@ -831,26 +836,28 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   char* ws = (char*)workspace;
+  char* gws = grid ? (char*)grid : ws;
   if (scan_all) {
     int32_t* counts = (int32_t*)(ws + l.counts);
     size_t temp_bytes = l.temp_bytes;
     const int64_t blocks = std::max((n_dst + 3) / 4, (n_src + 255) / 256);
     hipLaunchKernelGGL(scan_all_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, pts_src, batch_src,
-                       (float4*)(ws + l.spts), pts_dst, batch_dst, 1.0f / radius, (int)n_src, n_dst, counts,
+                       (float4*)(gws + l.spts), pts_dst, batch_dst, 1.0f / radius, (int)n_src, n_dst, counts,
                        (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr, (int32_t*)nullptr);
     if (skip_scan) return check_launch();
     if (hipcub::DeviceScan::InclusiveSum(ws + l.temp, temp_bytes, counts, ends, (int)n_dst, stream) != hipSuccess)
       return SE3_ERR_LAUNCH;
     return check_launch();
   }
-  int64_t* keys = (int64_t*)(ws + l.keys);
-  int64_t* skeys = (int64_t*)(ws + l.skeys);
-  int32_t* ids = (int32_t*)(ws + l.ids);
-  int32_t* sids = (int32_t*)(ws + l.sids);
-  float4* spts = (float4*)(ws + l.spts);
+  int64_t* keys = (int64_t*)(gws + l.keys);
+  int64_t* skeys = (int64_t*)(gws + l.skeys);
+  int32_t* ids = (int32_t*)(gws + l.ids);
+  int32_t* sids = (int32_t*)(gws + l.sids);
+  float4* spts = (float4*)(gws + l.spts);
   int2* ranges = (int2*)(ws + l.ranges);
   int32_t* counts = (int32_t*)(ws + l.counts);
   size_t temp_bytes = l.temp_bytes;
+  const bool build = n_src > 0 && !grid_valid;
   // A cloud against itself: the samples are walked in the cell order the sort just produced (`sids`), so that
   // neighbouring threads search for neighbouring keys and the wavefronts of a workgroup read the same candidate
   // windows.  Results are stored at the sample's own index: nothing changes but the order of the work.
@@ -860,7 +867,7 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
   if (key_bits > 0) {
     uint32_t* keys32 = (uint32_t*)keys;
     uint32_t* skeys32 = (uint32_t*)skeys;
-    if (n_src > 0) {
+    if (build) {
       hipLaunchKernelGGL(compute_keys32_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src,
                          aabb_min, num_cells, radius, n_src, keys32, ids);
       if (sort_pairs_no_scratch(ws + l.temp, temp_bytes, keys32, skeys32, ids, sids, (int)n_src, 0, key_bits,
@@ -872,7 +879,7 @@ static int ball_query_count_impl(const float* pts_src, const float* pts_dst, con
     hipLaunchKernelGGL(find_ranges32_kernel, dim3(blocks_for(n_dst * 9)), dim3(256), 0, stream, pts_dst, batch_dst,
                        aabb_min, num_cells, radius, skeys32, (int)n_src, n_dst, ranges, order);
   } else {
-    if (n_src > 0) {
+    if (build) {
       // cell size = radius in every dimension (BallQuery.py:39-40)
       hipLaunchKernelGGL(compute_keys_kernel, dim3(blocks_for(n_src)), dim3(256), 0, stream, pts_src, batch_src, aabb_min,
                          num_cells, (const float*)nullptr, radius, n_src, keys, ids);
@@ -906,18 +913,19 @@ extern "C" int se3_ball_query_count(const float* pts_src, const float* pts_dst, 
 static int ball_query_store_impl(const float* pts_dst, const int32_t* batch_dst, float radius, int64_t n_src,
                                  int64_t n_dst, const void* workspace, size_t workspace_bytes, int32_t* ends,
                                  int32_t* neighbors, int limit, int mode, int32_t* sources, int32_t* info, bool ordered,
-                                 void* stream) {
+                                 void* stream, const void* grid = nullptr) {
   const BqLayout l = bq_layout(n_src, n_dst);
   if (workspace_bytes < l.total) return SE3_ERR_WORKSPACE;
   const char* ws = (const char*)workspace;
-  const dim3 grid((unsigned)((n_dst + 3) / 4)), block(256);
+  const char* gws = grid ? (const char*)grid : ws;
+  const dim3 wgrid((unsigned)((n_dst + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (n_src <= kBqScanAllMax) {  // the count phase took the all-pairs path (and left the source records)
     if (!batch_dst) return SE3_ERR_INVALID_ARGUMENT;
-    float4* recs = (float4*)(ws + l.spts);
+    float4* recs = (float4*)(gws + l.spts);
     int32_t* counts = (int32_t*)(ws + l.counts);
 #define SE3_SCAN_ALL(M)                                                                                                 \
-  hipLaunchKernelGGL(scan_all_kernel<M>, grid, block, 0, st, (const float*)nullptr, (const int32_t*)nullptr, recs, pts_dst, \
+  hipLaunchKernelGGL(scan_all_kernel<M>, wgrid, block, 0, st, (const float*)nullptr, (const int32_t*)nullptr, recs, pts_dst, \
                      batch_dst, 1.0f / radius, (int)n_src, n_dst, counts, ends, neighbors, limit, sources, info)
     if (mode == 1) SE3_SCAN_ALL(1);
     else if (mode == 2) SE3_SCAN_ALL(2);
@@ -926,13 +934,13 @@ static int ball_query_store_impl(const float* pts_dst, const int32_t* batch_dst,
     return check_launch();
   }
   if (mode == 1)
-    hipLaunchKernelGGL(scan_candidates_kernel<1>, grid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
+    hipLaunchKernelGGL(scan_candidates_kernel<1>, wgrid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(gws + l.spts),
                        (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info,
-                       ordered ? (const int32_t*)(ws + l.sids) : (const int32_t*)nullptr);
+                       ordered ? (const int32_t*)(gws + l.sids) : (const int32_t*)nullptr);
   else
-    hipLaunchKernelGGL(scan_candidates_kernel<2>, grid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(ws + l.spts),
+    hipLaunchKernelGGL(scan_candidates_kernel<2>, wgrid, block, 0, st, pts_dst, 1.0f / radius, (const float4*)(gws + l.spts),
                        (const int2*)(ws + l.ranges), n_dst, (int32_t*)nullptr, ends, neighbors, limit, sources, info,
-                       ordered ? (const int32_t*)(ws + l.sids) : (const int32_t*)nullptr);
+                       ordered ? (const int32_t*)(gws + l.sids) : (const int32_t*)nullptr);
   return check_launch();
 }
 
@@ -946,11 +954,11 @@ extern "C" int se3_ball_query_store(const float* pts_dst, const int32_t* batch_d
                                const_cast<int32_t*>(ends), neighbors, 0x7fffffff, 1, nullptr, nullptr, false, stream);
 }
 
-extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
-                                      const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
-                                      float radius, int64_t n_src, int64_t n_dst, int32_t n_batches, void* workspace,
-                                      size_t workspace_bytes, int64_t capacity, int32_t* neighbors, int32_t* sources,
-                                      int32_t* ends, int32_t* info, void* stream) {
+static int ball_query_bounded_impl(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                   const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                                   float radius, int64_t n_src, int64_t n_dst, int32_t n_batches, void* workspace,
+                                   size_t workspace_bytes, int64_t capacity, int32_t* neighbors, int32_t* sources,
+                                   int32_t* ends, int32_t* info, void* stream, void* grid, bool grid_valid) {
   if (capacity < 0 || capacity >= (1ll << 31) || !info) return SE3_ERR_INVALID_ARGUMENT;
   if (n_dst == 0) return se3::launch_fill_words(info, 0u, 2, (hipStream_t)stream);
   if (capacity > 0 && !neighbors) return SE3_ERR_INVALID_ARGUMENT;
@@ -962,12 +970,35 @@ extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst
   // (count + prefix + store as one launch with a decoupled look-back was measured in round 4: slower, removed --
   // profiles/r04_ball_query_onepass_ab.txt)
   if (int rc = ball_query_count_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst,
-                                     workspace, workspace_bytes, ends, inline_prefix, key_bits, stream))
+                                     workspace, workspace_bytes, ends, inline_prefix, key_bits, stream, grid, grid_valid))
     return rc;
   // one store launch also clamps the offsets to the buffer and records total + overflow flag
   return ball_query_store_impl(pts_dst, batch_dst, radius, n_src, n_dst, workspace, workspace_bytes, ends, neighbors,
                                (int)capacity, inline_prefix ? 3 : 2, sources, info,
-                               pts_src == pts_dst && n_src == n_dst && batch_src == batch_dst, stream);
+                               pts_src == pts_dst && n_src == n_dst && batch_src == batch_dst, stream, grid);
+}
+
+extern "C" int se3_ball_query_bounded(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                      const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                                      float radius, int64_t n_src, int64_t n_dst, int32_t n_batches, void* workspace,
+                                      size_t workspace_bytes, int64_t capacity, int32_t* neighbors, int32_t* sources,
+                                      int32_t* ends, int32_t* info, void* stream) {
+  return ball_query_bounded_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst, n_batches,
+                                 workspace, workspace_bytes, capacity, neighbors, sources, ends, info, stream, nullptr, false);
+}
+
+extern "C" size_t se3_ball_query_grid_bytes(int64_t n_src) { return bq_layout(n_src, 0).ranges; }
+
+extern "C" int se3_ball_query_bounded_shared(const float* pts_src, const float* pts_dst, const int32_t* batch_src,
+                                             const int32_t* batch_dst, const float* aabb_min, const int32_t* num_cells,
+                                             float radius, int64_t n_src, int64_t n_dst, int32_t n_batches, void* grid,
+                                             size_t grid_bytes, int32_t grid_valid, void* workspace, size_t workspace_bytes,
+                                             int64_t capacity, int32_t* neighbors, int32_t* sources, int32_t* ends,
+                                             int32_t* info, void* stream) {
+  if (!grid || grid_bytes < bq_layout(n_src, 0).ranges) return SE3_ERR_WORKSPACE;
+  return ball_query_bounded_impl(pts_src, pts_dst, batch_src, batch_dst, aabb_min, num_cells, radius, n_src, n_dst, n_batches,
+                                 workspace, workspace_bytes, capacity, neighbors, sources, ends, info, stream, grid,
+                                 grid_valid != 0);
 }
 
 // ---- source-major copy of an edge list (se3_csr_transpose*) -----------------------------------------------------------

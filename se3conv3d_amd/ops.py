@@ -199,16 +199,67 @@ def ball_query(pts_src, pts_dst, batch_src, batch_dst, radius: float,
     return neighbors, ends
 
 
+SHARED_GRIDS = _os.environ.get("SE3_SHARED_GRIDS", "1") != "0"  # (A/B switch, tools/time_faust_geometry.py)
+
+
+class SourceGrids:
+    """The cell grids of one source cloud, one per search radius (``se3_ball_query_bounded_shared``): the queries of a step
+    that search the cloud with the same radius sort it once.  Kept on the cloud object (``source_grids``); a grid is
+    rebuilt when the cloud's points, batch ids or batch count are no longer the ones it was built from."""
+
+    __slots__ = ("grids",)
+
+    def __init__(self):
+        self.grids = {}
+
+    def slot(self, pts, batch_ids, radius, n_batches, nbytes):
+        """``(buffer, valid)`` for this radius; ``valid`` says the buffer already holds the grid (the call that gets
+        ``False`` builds it)."""
+        key = (pts.data_ptr(), pts._version, batch_ids.data_ptr(), batch_ids._version, int(pts.shape[0]), int(n_batches or 0),
+               str(pts.device))
+        hit = self.grids.get(float(radius))
+        if hit is not None and hit[0] == key and hit[1].numel() >= nbytes:
+            return hit[1], True
+        if len(self.grids) >= 8:  # (a cloud is searched with two or three radii; a sweep over many drops the oldest)
+            self.grids.pop(next(iter(self.grids)))
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=pts.device)
+        self.grids[float(radius)] = (key, buf)
+        return buf, False
+
+
+def source_grids(cloud) -> Optional["SourceGrids"]:
+    """The holder of ``cloud``'s source grids, created on first use and kept on the object; None when the object takes
+    no attribute."""
+    holder = getattr(cloud, "_se3_grids_", None)
+    if holder is None:
+        holder = SourceGrids()
+        try:
+            cloud._se3_grids_ = holder
+        except (AttributeError, TypeError):
+            return None
+    return holder
+
+
+def forget_source_grids(cloud) -> None:
+    """Drop ``cloud``'s source grids (what a new step's cloud starts without; timing loops that rebuild a step's
+    neighbourhoods on the same cloud objects call it per repetition)."""
+    holder = getattr(cloud, "_se3_grids_", None)
+    if holder is not None:
+        holder.grids.clear()
+
+
 def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, capacity: int,
                        n_batches: Optional[int] = None, want_sources: bool = False,
-                       neighbors_out: Optional[torch.Tensor] = None, src_box=None):
+                       neighbors_out: Optional[torch.Tensor] = None, src_box=None, grids: Optional[SourceGrids] = None):
     """The same query without the host round trip for the edge count (``se3_ball_query_bounded``): the caller sizes the
     edge buffer (``capacity`` rows, e.g. 1.25 x the previous step's count).  Returns ``(neighbors [capacity,2] int32,
     ends [M] int32, info [2] int32 on the device)`` with ``info[0]`` = true edge count and ``info[1]`` = 1 when it did
     not fit (the list is then truncated and ``ends`` clamped: rerun with a larger buffer).  Capturable in a HIP graph
     when ``n_batches`` is given.  ``want_sources``: a fourth result, the source ids as a dense ``[capacity]`` array
     (the source-major edge list of a cloud against itself).  ``neighbors_out``: a caller-owned contiguous
-    ``[capacity, 2]`` int32 buffer to write into (e.g. a slice of a larger arena) instead of a fresh allocation."""
+    ``[capacity, 2]`` int32 buffer to write into (e.g. a slice of a larger arena) instead of a fresh allocation.
+    ``grids``: the source cloud's ``SourceGrids`` -- its cell grid for this radius is then built once and shared by every
+    query that passes the holder (not while a HIP graph is being captured: a replay must not depend on what ran before)."""
     lib = _lib.load()
     pts_src = _as(pts_src, torch.float32)
     pts_dst = _as(pts_dst, torch.float32)
@@ -234,6 +285,17 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
     info = torch.empty(2, dtype=i32, device=dev)  # both words are written by the store pass
     mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches, src_box) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
     ws = _workspace(lib.se3_ball_query_workspace_bytes(n_src, n_dst), dev)
+    if grids is not None and mn is not None and src_box is not None and SHARED_GRIDS and not torch.cuda.is_current_stream_capturing():
+        # (src_box: the grid parameters are then a pure function of the cloud's cached boxes and the radius, so two calls
+        # with the same key search the same cells)
+        grid, valid = grids.slot(pts_src, bs, radius, n_batches, lib.se3_ball_query_grid_bytes(n_src))
+        _lib.check(lib.se3_ball_query_bounded_shared(
+            _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
+            _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius), n_src,
+            n_dst, int(n_batches or 0), C.c_void_p(grid.data_ptr()), grid.numel(), int(valid), C.c_void_p(ws.data_ptr()),
+            ws.numel(), int(capacity), _ptr(neighbors, i32, "neighbors"), _ptr(sources, i32, "sources"), _ptr(ends, i32, "ends"),
+            _ptr(info, i32, "info"), _stream(dev)), "se3_ball_query_bounded_shared")
+        return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)
     _lib.check(lib.se3_ball_query_bounded(
         _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
         _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius), n_src,

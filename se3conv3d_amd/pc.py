@@ -311,7 +311,8 @@ class BQNeighborhood(Neighborhood):
         if self.capacity_ is not None:
             res = ops.ball_query_bounded(self.pc_src_.pts_, self.samples_.pts_, self.pc_src_.batch_ids_,
                                          self.samples_.batch_ids_, self.radius_, int(self.capacity_),
-                                         self.pc_src_.num_batches(), want_sources=self.symmetric_, src_box=src_box)
+                                         self.pc_src_.num_batches(), want_sources=self.symmetric_, src_box=src_box,
+                                         grids=ops.source_grids(self.pc_src_))
             nb, self.start_ids_, self.edge_info_ = res[:3]
             if self.symmetric_:
                 self.sources_i32_ = res[3]
@@ -360,7 +361,7 @@ class BQNeighborhood(Neighborhood):
             box = self.samples_.aabb() if hasattr(self.samples_, "aabb") and ops.ball_query_needs_grid(n_smp) else None
             _, t_ends, info, t_samples = ops.ball_query_bounded(
                 self.samples_.pts_, self.pc_src_.pts_, self.samples_.batch_ids_, self.pc_src_.batch_ids_, self.radius_, rows,
-                self.samples_.num_batches(), want_sources=True, src_box=box)
+                self.samples_.num_batches(), want_sources=True, src_box=box, grids=ops.source_grids(self.samples_))
             cached = self._source_major = (t_samples, t_ends, info)
         return cached[0], cached[1]
 

@@ -156,3 +156,52 @@ def test_bounded_neighbourhood_between_two_clouds_runs_forward_and_backward(amd,
                                   conv.proj_biases_.detach().cpu(), conv.conv_weights_.detach().cpu(), 1.0 / r, n_out / e, g.cpu())
     for a, b, name in zip(got, ref, ("out", "dX", "dA", "dbeta", "dW")):
         assert rel_err(a, b) < 5e-5, name
+
+
+@pytest.mark.parametrize("batches", [1, 2, 5])
+def test_queries_that_share_a_source_grid_find_the_same_lists(amd, batches):
+    """se3_ball_query_bounded_shared: the second and third query against one source cloud with one radius reuse the grid the
+    first one sorted -- same lists, bit for bit, as three independent queries; another radius, a changed cloud and a
+    capture get a grid of their own."""
+    from se3conv3d_amd import pc as PC
+
+    g = torch.Generator().manual_seed(40 + batches)
+    n = 9000
+    pts = torch.rand(n, 3, generator=g)
+    bid = torch.sort(torch.randint(0, batches, (n,), generator=g, dtype=torch.int32)).values
+    bid[-1] = batches - 1
+    src = PC.Pointcloud(pts.to(DEV), bid.to(DEV))
+    dsts = []
+    for m in (9000, 2500, 700):
+        pd = torch.rand(m, 3, generator=g)
+        bd = torch.sort(torch.randint(0, batches, (m,), generator=g, dtype=torch.int32)).values
+        dsts.append(PC.Pointcloud(pd.to(DEV), bd.to(DEV)))
+    r = 0.06
+    box = src.aabb()
+    holder = amd.ops.source_grids(src)
+    assert holder is amd.ops.source_grids(src) and holder.grids == {}
+    for i, dst in enumerate([src] + dsts):
+        args = (src.pts_, dst.pts_, src.batch_ids_, dst.batch_ids_, r)
+        nb0, ends0, info0 = amd.ops.ball_query_bounded(*args, capacity=400000, n_batches=batches, src_box=box)
+        res = amd.ops.ball_query_bounded(*args, capacity=400000, n_batches=batches, src_box=box, grids=holder,
+                                         want_sources=dst is src)
+        e = int(info0[0])
+        assert e > 0 and info0.tolist() == res[2].tolist()
+        assert torch.equal(res[0][:e], nb0[:e]) and torch.equal(res[1], ends0)
+        if dst is src:
+            assert torch.equal(res[3][:e], nb0[:e, 1])
+        assert len(holder.grids) == 1
+    buf = holder.grids[r][1]
+    # the neighbourhood classes pass the holder themselves; another radius is another grid
+    nbh = PC.BQNeighborhood(src, dsts[0], r, p_capacity=400000)
+    ref, ends_ref = amd.ops.ball_query(src.pts_, dsts[0].pts_, src.batch_ids_, dsts[0].batch_ids_, r, batches)
+    assert torch.equal(nbh.neighbors_i32_[:ref.shape[0]], ref) and torch.equal(nbh.start_ids_, ends_ref)
+    assert holder.grids[r][1] is buf
+    PC.BQNeighborhood(src, dsts[1], 2 * r, p_capacity=900000)
+    assert set(holder.grids) == {r, 2 * r}
+    # points changed in place: the version counter invalidates the grid
+    src.pts_.mul_(0.5)
+    src._se3_aabb = None
+    nbh2 = PC.BQNeighborhood(src, dsts[0], r, p_capacity=400000)
+    ref2, _ = amd.ops.ball_query(src.pts_, dsts[0].pts_, src.batch_ids_, dsts[0].batch_ids_, r, batches)
+    assert torch.equal(nbh2.neighbors_i32_[:ref2.shape[0]], ref2) and holder.grids[r][1] is not buf

@@ -44,9 +44,25 @@ clouds = list(hier.pcs_) + [out_pc]
 calls = W.faust_network_calls(os.path.join(ROOT, "tests", "golden", "network_faust_calls.npz"))
 nbhs = W.faust_neighbourhoods(clouds, calls)
 caps = {k: int(nb.num_edges() * 1.25) + 64 for k, nb in nbhs.items()}
+
+
+def fresh(call_list):
+    # a step's clouds are new objects: no source grid survives from the step before (round 6: the queries of ONE step that
+    # search a cloud with one radius share its grid)
+    for c in clouds:
+        amd.ops.forget_source_grids(c)
+    return W.faust_neighbourhoods(clouds, call_list, caps)
+
+
 for key in nbhs:
     one = [c for c in calls if (c["level_in"], c["level_out"], c["radius"]) == key][:1]
-    ms, _ = timed(lambda: W.faust_neighbourhoods(clouds, one, caps))
+    ms, _ = timed(lambda: fresh(one))
     print(f"neighbourhood {key}: {ms:.3f} ms  ({nbhs[key].num_edges()} edges)")
-ms, _ = timed(lambda: W.faust_neighbourhoods(clouds, calls, caps))
+ms, _ = timed(lambda: fresh(calls))
 print(f"all {len(nbhs)} neighbourhoods: {ms:.3f} ms")
+# the same with every query sorting its own source cloud (round 5's form), alternating
+for rep in range(3):
+    for on in (False, True):
+        amd.ops.SHARED_GRIDS = on
+        ms, _ = timed(lambda: fresh(calls))
+        print(f"  all {len(nbhs)} neighbourhoods, source grids {'shared' if on else 'per query'}: {ms:.3f} ms")
