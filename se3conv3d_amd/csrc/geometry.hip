@@ -519,18 +519,31 @@ struct KeyLess {
   template <class K>
   __device__ __forceinline__ bool operator()(const K& a, const K& b) const { return a < b; }
 };
+// Clouds of a few thousand to a few hundred thousand points (every grid of a training step): rocPRIM's stable merge sort with
+// block-sorted runs of 4 096 pairs (512 threads x 8) instead of the 1 024 its radix-sort front end uses below 1 M items -- two
+// merge launches fewer per sort (58 k pairs: 1 + 4 launches instead of 1 + 6), and the grid builds of a step are bound by
+// launches (27 sorts per DFaust step).  Stable either way, so equal keys keep their input order: same result, bit for bit.
+#ifndef SE3_SORT_RUN
+#define SE3_SORT_RUN 4096  // 0: hipcub::DeviceRadixSort's own choice (A/B)
+#endif
+using GridSortConfig = rocprim::merge_sort_config<512, 512, (SE3_SORT_RUN ? SE3_SORT_RUN : 4096) / 512>;
 template <class Key>
 hipError_t sort_pairs_no_scratch(void* temp, size_t& temp_bytes, const Key* kin, Key* kout, const int32_t* vin, int32_t* vout,
                                  int n, int begin_bit = 0, int end_bit = (int)sizeof(Key) * 8, hipStream_t stream = nullptr) {
   static_assert(sizeof(Key) > 2, "rocPRIM sends 1- and 2-byte keys to the one-sweep sort from 100 000 items on");
-  if (temp == nullptr) {  // size query: the larger of the two forms
-    size_t a = 0, b = 0;
+  if (temp == nullptr) {  // size query: the largest of the forms
+    size_t a = 0, b = 0, c = 0;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, kin, kout, vin, vout, n, begin_bit, end_bit, stream);
     if (e != hipSuccess) return e;
     e = hipcub::DeviceMergeSort::StableSortPairs(nullptr, b, kout, vout, n, KeyLess(), stream);
+    if (e != hipSuccess) return e;
+    e = rocprim::merge_sort<GridSortConfig>(nullptr, c, kin, kout, vin, vout, (size_t)n, KeyLess(), stream);
     temp_bytes = a > b ? a : b;
+    if (c > temp_bytes) temp_bytes = c;
     return e;
   }
+  if (SE3_SORT_RUN && n <= kRadixIsMergeLimit)
+    return rocprim::merge_sort<GridSortConfig>(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, KeyLess(), stream);
   if (n <= kRadixIsMergeLimit) return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, stream);
   hipError_t e = hipMemcpyAsync(kout, kin, (size_t)n * sizeof(Key), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) return e;

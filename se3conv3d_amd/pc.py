@@ -116,9 +116,10 @@ class Pointcloud(object):
         """Per-batch bounding boxes ``(min, max) [B,3]`` of the points, computed once per cloud (the reference recomputes
         them in every ball query, BallQuery.py:35-36; a cloud is the source of three or four queries per step)."""
         box = getattr(self, "_se3_aabb", None)
-        if box is None or box[2] != self.pts_.data_ptr():
+        key = (self.pts_.data_ptr(), self.pts_._version)  # (points replaced or changed in place: new boxes)
+        if box is None or box[2] != key:
             mn, mx = ops.batch_aabb(self.pts_, self.batch_ids_, self.num_batches())
-            box = (mn, mx, self.pts_.data_ptr())
+            box = (mn, mx, key)
             self._se3_aabb = box
         return box[0], box[1]
 

@@ -201,7 +201,6 @@ def test_queries_that_share_a_source_grid_find_the_same_lists(amd, batches):
     assert set(holder.grids) == {r, 2 * r}
     # points changed in place: the version counter invalidates the grid
     src.pts_.mul_(0.5)
-    src._se3_aabb = None
     nbh2 = PC.BQNeighborhood(src, dsts[0], r, p_capacity=400000)
     ref2, _ = amd.ops.ball_query(src.pts_, dsts[0].pts_, src.batch_ids_, dsts[0].batch_ids_, r, batches)
     assert torch.equal(nbh2.neighbors_i32_[:ref2.shape[0]], ref2) and holder.grids[r][1] is not buf
