@@ -207,10 +207,11 @@ class SourceGrids:
     that search the cloud with the same radius sort it once.  Kept on the cloud object (``source_grids``); a grid is
     rebuilt when the cloud's points, batch ids or batch count are no longer the ones it was built from."""
 
-    __slots__ = ("grids",)
+    __slots__ = ("grids", "params")
 
     def __init__(self):
         self.grids = {}
+        self.params = {}  # per radius: (shifted box minima, cell counts) of the grid (se3_ball_query_grid_from_box)
 
     def slot(self, pts, batch_ids, radius, n_batches, nbytes):
         """``(buffer, valid)`` for this radius; ``valid`` says the buffer already holds the grid (the call that gets
@@ -221,9 +222,12 @@ class SourceGrids:
         if hit is not None and hit[0] == key and hit[1].numel() >= nbytes:
             return hit[1], True
         if len(self.grids) >= 8:  # (a cloud is searched with two or three radii; a sweep over many drops the oldest)
-            self.grids.pop(next(iter(self.grids)))
+            oldest = next(iter(self.grids))
+            self.grids.pop(oldest)
+            self.params.pop(oldest, None)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=pts.device)
         self.grids[float(radius)] = (key, buf)
+        self.params.pop(float(radius), None)
         return buf, False
 
 
@@ -246,6 +250,7 @@ def forget_source_grids(cloud) -> None:
     holder = getattr(cloud, "_se3_grids_", None)
     if holder is not None:
         holder.grids.clear()
+        holder.params.clear()
 
 
 def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, capacity: int,
@@ -283,12 +288,16 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
         info = torch.zeros(2, dtype=i32, device=dev)
         return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)
     info = torch.empty(2, dtype=i32, device=dev)  # both words are written by the store pass
-    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches, src_box) if lib.se3_ball_query_needs_grid(n_src) else (None, None)
+    needs_grid = bool(lib.se3_ball_query_needs_grid(n_src))
     ws = _workspace(lib.se3_ball_query_workspace_bytes(n_src, n_dst), dev)
-    if grids is not None and mn is not None and src_box is not None and SHARED_GRIDS and not torch.cuda.is_current_stream_capturing():
+    if grids is not None and needs_grid and src_box is not None and SHARED_GRIDS and not torch.cuda.is_current_stream_capturing():
         # (src_box: the grid parameters are then a pure function of the cloud's cached boxes and the radius, so two calls
-        # with the same key search the same cells)
+        # with the same key search the same cells -- and the parameters themselves are kept with the grid)
         grid, valid = grids.slot(pts_src, bs, radius, n_batches, lib.se3_ball_query_grid_bytes(n_src))
+        params = grids.params.get(float(radius)) if valid else None
+        if params is None:
+            params = grids.params[float(radius)] = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches, src_box)
+        mn, nc = params
         _lib.check(lib.se3_ball_query_bounded_shared(
             _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
             _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius), n_src,
@@ -296,6 +305,7 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
             ws.numel(), int(capacity), _ptr(neighbors, i32, "neighbors"), _ptr(sources, i32, "sources"), _ptr(ends, i32, "ends"),
             _ptr(info, i32, "info"), _stream(dev)), "se3_ball_query_bounded_shared")
         return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)
+    mn, nc = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches, src_box) if needs_grid else (None, None)
     _lib.check(lib.se3_ball_query_bounded(
         _ptr(pts_src, f32, "pts_src"), _ptr(pts_dst, f32, "pts_dst", dev), _ptr(bs, i32, "batch_src", dev),
         _ptr(bd, i32, "batch_dst", dev), _ptr(mn, f32, "aabb_min"), _ptr(nc, i32, "num_cells"), float(radius), n_src,
