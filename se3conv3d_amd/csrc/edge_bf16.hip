@@ -23,9 +23,6 @@
 // the kernel that follows it (the GEMM reading those rows) no longer runs against the write-back of ~300 MB of dirty
 // lines left in L2 and the memory-side cache: gemm_out 0.221 -> 0.188 ms.  (The strip GEMM is bound by its stores:
 // there the same flag costs 0.03 ms and buys 0.02 in the parameter-gradient kernel behind it -- not used.)
-#ifndef SE3_NT_STORES
-#define SE3_NT_STORES 1
-#endif
 #include "common.h"
 #include "edge_bf16_body.h"
 
@@ -163,13 +160,8 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
                                    t24_pack2(x0, ok1 ? x1 : 0.f, hp, lp);
                                    char* row = rows + a * t24_row_bytes(channels);
                                    const int idx = (ch0 >> 1) * kBasis + kcol;
-#if SE3_NT_STORES
                                    __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
                                    __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)row_words * 2) + idx);
-#else
-                                   reinterpret_cast<uint32_t*>(row)[idx] = hp;
-                                   reinterpret_cast<uint16_t*>(row + (int64_t)row_words * 2)[idx] = (uint16_t)lp;
-#endif
                                  });
   } else {
     uint32_t* t_rows = t_out + item * FC * (int64_t)channels * kBasis;  // rows FC*item .. FC*item + FC-1
@@ -177,13 +169,8 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
                                  [&](int a, int ch0, int ch1, float x0, float x1, bool ok0, bool ok1) {
                                    uint32_t w0, w1;
                                    split_pack2(x0, x1, w0, w1);
-#if SE3_NT_STORES
                                    if (ok0) __builtin_nontemporal_store(w0, &t_rows[a * row_words + ch0 * kBasis + kcol]);
                                    if (ok1) __builtin_nontemporal_store(w1, &t_rows[a * row_words + ch1 * kBasis + kcol]);
-#else
-                                   if (ok0) t_rows[a * row_words + ch0 * kBasis + kcol] = w0;
-                                   if (ok1) t_rows[a * row_words + ch1 * kBasis + kcol] = w1;
-#endif
                                  });
   }
 }
@@ -206,16 +193,9 @@ __global__ __launch_bounds__(256, VW == 4 ? 2 : (FC == 1 ? 3 : 2)) void edge_t_b
                            // 48 - 64 bytes per lane to scratch and was 1 % slower (dfaust_f2 stack 2.02 vs 2.00 ms, a 128-channel
                            // layer 4.67 vs 4.63 ms, profiles/r04_pair2_waves_ab.txt); no kernel the shipped configurations launch uses scratch now
 #endif
-#ifndef SE3_PG_ABLATE
-#define SE3_PG_ABLATE 0  // diagnostic builds of edge_param_grad_bf16_v2 (wrong results): 1 no GELU', 2 no feature gather, 4 no grad_T loads, 8 no d[A;beta] product,
-                         // 16 no geometry gathers / descriptor / descriptor split (upper bound of what a descriptor stash written by the forward could save)
-#endif
-#ifndef SE3_PAIR_ABLATE
-#define SE3_PAIR_ABLATE 0  // diagnostic builds (wrong results): 1 no GELU, 2 no feature gather, 4 no T stores, 8 no hi/lo split of phi, 64 no barrier between the partner wavefronts,
-                           // 128 the chunk's feature rows fetched as FOUR 16-byte loads per lane (8 rows x 128 B per instruction: the access
-                           // shape of an LDS-staged gather) instead of sixteen dword gathers -- same bytes, a quarter of the VMEM and
-                           // ds_bpermute instructions, without the LDS round trip a real version needs: the upper bound of that variant
-#endif
+// (The ablation builds of rounds 2 - 5 -- SE3_PAIR_ABLATE, SE3_PG_ABLATE, SE3_ABLATE: kernels with one ingredient taken out,
+// wrong results, for the "what bounds them" tables of profiles/README.md -- were removed in round 6 with the questions they
+// answered; the commits that produced a table hold the code that produced it.)
 #ifndef SE3_PAIR_PIN
 #define SE3_PAIR_PIN 1  // centre record passed through an empty asm at the top of every chunk: nothing derived from it is hoisted out
                         // of the loop (fewer live registers, another schedule).  Measured -2 % (0.366 / 0.360 -> 0.359 / 0.353 ms)
@@ -252,8 +232,8 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
   // rows < 2^31 (checked on the host), so 32-bit unsigned division is exact -- the 64-bit one is ~150 scalar instructions
   const int64_t ctr = (uint32_t)item / (uint32_t)groups;
   const int a0 = (int)((uint32_t)item - (uint32_t)ctr * (uint32_t)groups) * NF;
-  const int start = (SE3_PAIR_ABLATE & 32) ? (int)(ctr * 31) : (ctr > 0 ? g.ends[ctr - 1] : 0);
-  const int n_total = (SE3_PAIR_ABLATE & 32) ? 31 * g.f_nb : (g.ends[ctr] - start) * g.f_nb;
+  const int start = ctr > 0 ? g.ends[ctr - 1] : 0;
+  const int n_total = (g.ends[ctr] - start) * g.f_nb;
   float yc[3], rc[9];
   load_geom_record(ctrg_rs, (int)(ctr * g.f_ctr + a0 + (NF == 2 ? wv : 0)), yc, rc);  // this wavefront's frame
   TL(tl_mark(tl_rec, 2); asm volatile("" ::"s"(n_total)); tl_mark(tl_rec, 3); tl_rec[15] = (uint32_t)n_total;)  // [2] item set-up issued, [3] row extents in
@@ -264,7 +244,6 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
   auto nbr_of = [&](int c0) {
     const int fe = min(c0 + kcol, n_total - 1);
     const int e = start + (POW2 || fnb_shift >= 0 ? fe >> fnb_shift : fe / g.f_nb);
-    if (SE3_PAIR_ABLATE & 16) return (int)(((unsigned)e * 2654435761u) % (unsigned)g.n_nb);  // no id load
     return g.nbr[(int64_t)e * g.nbr_stride + g.nbr_offset];
   };
   auto row_of = [&](int nb, int c0) {
@@ -319,18 +298,6 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
       // gathered feature words for this wavefront's channels (shared by both frames): all loads go out now and are
       // only turned into MFMA fragments after the barrier below
       uint32_t fw[CT][2][8];
-      if (SE3_PAIR_ABLATE & 128) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int src_off = __builtin_amdgcn_ds_bpermute(4 * (8 * i + (lane >> 3)), qoff);
-#pragma unroll
-          for (int t = 0; t < CT; ++t) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, src_off + cbase * 4 + 128 * (CT * wv + t) + (lane & 7) * 16, 0, 0);
-            fw[t][i >> 1][4 * (i & 1)] = v[0], fw[t][i >> 1][4 * (i & 1) + 1] = v[1];
-            fw[t][i >> 1][4 * (i & 1) + 2] = v[2], fw[t][i >> 1][4 * (i & 1) + 3] = v[3];
-          }
-        }
-      } else
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -338,8 +305,7 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
           const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
 #pragma unroll
           for (int t = 0; t < CT; ++t)
-            fw[t][s][j] = (SE3_PAIR_ABLATE & 2) ? (uint32_t)(src_off + cb4[t]) * 2654435761u
-                                                : __builtin_amdgcn_raw_buffer_load_b32(feat_rs, ch_ok[t] ? src_off + cb4[t] : kOobOffset, 0, 0);
+            fw[t][s][j] = __builtin_amdgcn_raw_buffer_load_b32(feat_rs, ch_ok[t] ? src_off + cb4[t] : kOobOffset, 0, 0);
         }
       load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
       q_a = q_b;
@@ -370,21 +336,16 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
           if (s * 16 < cnt && (NF == 2 || s == wv)) {
             float pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] = (SE3_PAIR_ABLATE & 1) ? phi[8 * s + j] : gelu_scaled(phi[8 * s + j]);
+            for (int j = 0; j < 8; ++j) pv[j] = gelu_scaled(phi[8 * s + j]);
             u32x4 b_hi, b_lo;
-            if (SE3_PAIR_ABLATE & 8) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) b_hi[i] = __float_as_uint(pv[2 * i]), b_lo[i] = __float_as_uint(pv[2 * i + 1]);
-            } else {
-              frags_from_floats(pv, b_hi, b_lo);
-            }
+            frags_from_floats(pv, b_hi, b_lo);
             *reinterpret_cast<u32x4*>(&lds_phi[buf][NF == 2 ? wv : 0][s][0][lane][0]) = b_hi;
             *reinterpret_cast<u32x4*>(&lds_phi[buf][NF == 2 ? wv : 0][s][1][lane][0]) = b_lo;
           }
         }
       }
       TL(tl_mark(tl_rec, tl_ch + 4);)
-      if (!(SE3_PAIR_ABLATE & 64)) __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
+      __syncthreads();  // both frames' fragments of this chunk are published (other buffer is used next chunk)
       TL(tl_mark(tl_rec, tl_ch + 5); tl_pin(fw[0][0][7]); tl_mark(tl_rec, tl_ch + 6);)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -438,13 +399,8 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
             uint32_t hp, lp;
             t24_pack2(acc[a][t][r], (FULL || ch + 1 < C) ? acc[a][t][r + 1] : 0.f, hp, lp);
             const int idx = (ch >> 1) * kBasis + kcol;
-#if SE3_NT_STORES
             __builtin_nontemporal_store(hp, reinterpret_cast<uint32_t*>(row) + idx);
             __builtin_nontemporal_store((uint16_t)lp, reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2) + idx);
-#else
-            reinterpret_cast<uint32_t*>(row)[idx] = hp;
-            reinterpret_cast<uint16_t*>(row + (int64_t)C * kBasis * 2)[idx] = (uint16_t)lp;
-#endif
           }
           continue;
         }
@@ -453,14 +409,8 @@ __global__ __launch_bounds__(128, CT == 1 ? (POW2 ? SE3_PAIR_WAVES : 3) : (FULL 
         for (int r = 0; r < 16; r += 2) {
           uint32_t w0, w1;
           split_pack2(acc[a][t][r], acc[a][t][r + 1], w0, w1);
-          if ((SE3_PAIR_ABLATE & 4) && (w0 ^ w1) != 0x12345678u) continue;
-#if SE3_NT_STORES
           if (FULL || ch0 + acc_row(r, h) < C) __builtin_nontemporal_store(w0, &t_row[acc_row(r, h) * kBasis + kcol]);
           if (FULL || ch0 + acc_row(r + 1, h) < C) __builtin_nontemporal_store(w1, &t_row[acc_row(r + 1, h) * kBasis + kcol]);
-#else
-          if (FULL || ch0 + acc_row(r, h) < C) t_row[acc_row(r, h) * kBasis + kcol] = w0;
-          if (FULL || ch0 + acc_row(r + 1, h) < C) t_row[acc_row(r + 1, h) * kBasis + kcol] = w1;
-#endif
         }
       }
     if (cbase + 64 * CT < C) __syncthreads();  // the next pass reuses the phi buffers from their start
@@ -1195,7 +1145,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     return false;
   };
   auto issue_item_loads = [&]() {
-    if (!LEAN && !(SE3_PG_ABLATE & 16)) load_geom_record(ctrg_rs, ctr_row, yc, rc);  // LEAN: fetched again per chunk (a cache hit; 12 registers)
+    if (!LEAN) load_geom_record(ctrg_rs, ctr_row, yc, rc);  // LEAN: fetched again per chunk (a cache hit; 12 registers)
     nb_a = nbr_of(c_first);
     nb_b = nbr_of(c_first + CSTEP);
   };
@@ -1241,8 +1191,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         for (int st = 0; st < CH16; ++st)
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            gw[ab][st][j] = (SE3_PG_ABLATE & 4) ? (uint32_t)(item + st + j) * 2654435761u
-                            : __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0);
+            gw[ab][st][j] = __builtin_amdgcn_raw_buffer_load_b32(gt_rs, (8 * h * kBasis + kcol) * 4, (16 * st + j) * kBasis * 4, 0);
       }
   };
   int prio_step = wave_slot_id();
@@ -1255,7 +1204,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
     TL(tl_pin(nb_a); tl_seg(tl_rec, tl_prev, 4);)  // 4: ids in
     int q_a = row_of(nb_a, c_first);
     float xn_nx[3], rn_nx[9];
-    if (!(SE3_PG_ABLATE & 16)) load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
+    load_geom_record(nbg_rs, q_a, xn_nx, rn_nx);
     TL(tl_pin(gw[NBUILD - 1][CH16 - 1][7]); tl_seg(tl_rec, tl_prev, 5);)  // 5: grad_T words in
 #pragma unroll
     for (int ab = 0; ab < NBUILD; ++ab)
@@ -1294,11 +1243,6 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
 #pragma unroll
       for (int st = 0; st < CH16; ++st) {
         const int voff = c_off + 16 * st < row_ch ? qoff + (16 * st + 8 * h) * 4 : kOobOffset;  // past the row: zeros
-        if (SE3_PG_ABLATE & 2) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) fw[st][j] = (uint32_t)(voff + j) * 2654435761u;
-          continue;
-        }
         const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
         const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff + 16, 0, 0);
         fw[st][0] = v0[0], fw[st][1] = v0[1], fw[st][2] = v0[2], fw[st][3] = v0[3];
@@ -1308,22 +1252,15 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
       q_a = q_b;
       TL(tl_seg(tl_rec, tl_prev, 8); tl_pin(xn_nx[0]); tl_pin(rn_nx[7]); tl_pin(rn_nx[8]); tl_seg(tl_rec, tl_prev, 9); tl_rec[17] += 1;)  // 8: gathers issued, 9: this chunk's record in
 
-      if (SE3_PG_ABLATE & 16) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) d[i] = 0.25f;
-      } else if (!g.transposed)
+      if (!g.transposed)
         edge_descriptor(xn_nx, rn_nx, yc, rc, rho, d);
       else
         edge_descriptor(yc, rc, xn_nx, rn_nx, rho, d);
       // the next chunk's record goes out once this chunk's has been consumed (issuing it only at the
       // end of the chunk body -- measured slower, 0.434 vs 0.419 ms)
-      if (!(SE3_PG_ABLATE & 16) && !LEAN) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
+      if (!LEAN) load_geom_record(nbg_rs, q_b, xn_nx, rn_nx);
 
       u32x4 own_hi, own_lo, oth_hi = {0u, 0u, 0u, 0u}, oth_lo = {0u, 0u, 0u, 0u};
-      if (SE3_PG_ABLATE & 16) {  // what the stash would deliver: the split descriptor as two 16-byte words per plane
-        own_hi = u32x4{(uint32_t)q_a, (uint32_t)q_a * 3u, (uint32_t)q_a * 5u, (uint32_t)q_a * 7u} & 0x3f803f80u;
-        own_lo = own_hi >> 3;
-      } else
       frags_from_floats(d, own_hi, own_lo);
       // descriptor image: half h writes the rows of frame a0+h -- the split pairs above are the rows of the two planes
       uint32_t own8_hi, own8_lo;
@@ -1396,8 +1333,7 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         const f32x16 pre = mfma_bf16x3(a_hi, a_lo, wb_hi, wb_lo, zero16());
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (SE3_PG_ABLATE & 1) dy[r] = pre[r];
-          else dy[r] = gelu_scaled_dgrad(pre[r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
+          dy[r] = gelu_scaled_dgrad(pre[r]);  // 2 GELU': the 0.5 is applied where the partials are reduced
         }
       };
       // gphi = F gT on the gathered rows, gpre = gphi * GELU', and the d[A;beta] product of frame a
@@ -1411,11 +1347,6 @@ __global__ __launch_bounds__(PAIR ? 128 : (NFR == 2 ? 512 : 256), PAIR ? SE3_PG_
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          if (SE3_PG_ABLATE & 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dacc[j] += gphi[8 * s + j] * dy[8 * s + j];
-            continue;
-          }
           if (s * 16 < cnt) {
             float gp[8];
 #pragma unroll

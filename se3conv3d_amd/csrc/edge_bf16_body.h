@@ -2,13 +2,6 @@
 // See edge_bf16.hip for the scheme.
 #pragma once
 
-#ifndef SE3_ABLATE
-#define SE3_ABLATE 0  // diagnostic builds only (tools/ab.sh with a variant build): 1 no GELU, 2 no feature gather, 3 no geometry gather, 4 no stores
-#endif
-#ifndef SE3_ABLATE_MASK
-#define SE3_ABLATE_MASK (SE3_ABLATE ? (1 << (SE3_ABLATE - 1)) : 0)
-#endif
-
 #include "common.h"
 
 namespace se3 {
@@ -82,14 +75,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
       return nb * g.f_nb + (fnb_shift >= 0 ? fe & ((1 << fnb_shift) - 1) : fe % g.f_nb);
     };
     auto geom_of = [&](int nb, int q, float xn[3], float rn[9]) {
-#if SE3_ABLATE_MASK & 4
-#pragma unroll
-      for (int i = 0; i < 3; ++i) xn[i] = (float)(nb & 255) * 0.001f + i;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) rn[i] = (float)(q & 127) * 0.002f - i;
-#else
       load_geom_record(nbg_rs, q, xn, rn);
-#endif
     };
     // Software pipeline (as in the wave-pair kernel): neighbour ids are fetched two chunks ahead and geometry records
     // one chunk ahead, and the chunk's own feature words go out at its top and are only turned into MFMA fragments
@@ -128,12 +114,6 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
           // byte offset of the source row of frame-edge acc_row(8s+j, h), fetched from the lane that owns it
           const int src_off = __builtin_amdgcn_ds_bpermute(hb + 4 * acc_row(8 * s + j, 0), qoff);
           const int voff = ch_ok ? src_off + cb4 : kOobOffset;
-#if SE3_ABLATE_MASK & 2
-          if constexpr (VW >= 1) {
-#pragma unroll
-            for (int t = 0; t < VW; ++t) fw[s][t][j] = (uint32_t)voff * 2654435761u + t;
-          } else
-#endif
           if constexpr (VW == 4) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(feat_rs, voff, 0, 0);
             fw[s][0][j] = v[0], fw[s][1][j] = v[1], fw[s][2][j] = v[2], fw[s][3][j] = v[3];
@@ -188,12 +168,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
             float pv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-#if SE3_ABLATE_MASK & 1
-              float y = phi[8 * s + j];
-#else
-              float y = gelu_scaled(phi[8 * s + j]);
-#endif
-              pv[j] = y;
+              pv[j] = gelu_scaled(phi[8 * s + j]);
             }
             u32x4 b_hi, b_lo;
             frags_from_floats(pv, b_hi, b_lo);
@@ -215,12 +190,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ch0 = cbase + 2 * acc_row(r, h);
-#if SE3_ABLATE_MASK & 8
-          asm volatile("" ::"v"(acc[a][0][r]), "v"(acc[a][1][r]));
-          if (__float_as_uint(acc[a][0][r]) == 0x12345678u) sink(a, ch0, ch0 + 1, acc[a][0][r], acc[a][1][r], true, true);
-#else
           sink(a, ch0, ch0 + 1, acc[a][0][r], acc[a][1][r], FULL || ch0 < channels, FULL || ch0 + 1 < channels);
-#endif
         }
       } else {
 #pragma unroll
@@ -228,12 +198,7 @@ __device__ __forceinline__ void edge_item_bf16(const EdgeGeom& g, const __amdgpu
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int ch0 = cbase + VW * acc_row(r, h) + t, ch1 = cbase + VW * acc_row(r + 1, h) + t;
-#if SE3_ABLATE_MASK & 8
-            asm volatile("" ::"v"(acc[a][t][r]), "v"(acc[a][t][r + 1]));
-            if (__float_as_uint(acc[a][t][r]) == 0x12345678u) sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], true, true);
-#else
             sink(a, ch0, ch1, acc[a][t][r], acc[a][t][r + 1], FULL || ch0 < channels, FULL || ch1 < channels);
-#endif
           }
       }
     }
