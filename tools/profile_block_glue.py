@@ -45,3 +45,22 @@ for _ in range(20):
     all_glue()
 torch.cuda.synchronize()
 print(f"block glue, eager: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per repetition (8 blocks, forward + backward)")
+
+# the same as one captured graph (what bench.py's faust_step reports as block_glue)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        all_glue()
+torch.cuda.current_stream().wait_stream(side)
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    all_glue()
+for _ in range(3):
+    graph.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    graph.replay()
+torch.cuda.synchronize()
+print(f"block glue, one captured graph: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms per replay")
