@@ -127,7 +127,11 @@ def load() -> C.CDLL:
         raise Se3LibraryError(f"{LIB_PATH} has ABI version {lib.se3_abi_version()}, this binding expects {ABI_VERSION}: "
                               "rebuild it (`python -m se3conv3d_amd.build`)")
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:  # same ABI number, older build of it (entry points are added within a version): say so
+            raise Se3LibraryError(f"{LIB_PATH} does not export {name}: it was built from older sources -- rebuild it "
+                                  "(`python -m se3conv3d_amd.build`)") from None
         fn.restype = res
         fn.argtypes = args
     _lib = lib
