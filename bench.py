@@ -159,7 +159,7 @@ def profile_level(lib, lv, reps, fn=None):
             continue
         ms, cnt = C.c_double(0), C.c_int64(0)
         lib.se3_profile_read(tag.encode(), C.byref(ms), C.byref(cnt))
-        # (average per launch, launches, total per step): a row-sliced schedule (SE3_SLICE_MB) launches a stage once per slice
+        # (average per launch, launches, total per step)
         stages[tag] = (ms.value / max(cnt.value, 1), cnt.value, ms.value / reps)
     lib.se3_profile_reset()
     return stages

@@ -568,9 +568,6 @@ int se3_profile_tags(char* buf, size_t len);
  *   SE3_TR_MERGE_SORT     se3_csr_transpose*: the merge-sort form for every graph, same result
  *   SE3_DX_PATH           feature gradient edge-major: 1 wherever implemented, 0 never; default: the two-term cost model of
  *                         DESIGN.md section 4.11 (microseconds of either form; never above 20 edges per source row)
- *   SE3_SLICE_MB (+ _STREAMS)   row-sliced schedule: every producer -> consumer pair of a row-sized intermediate per slice of
- *                         at most that many MB, consumers on the side stream with SE3_SLICE_STREAMS=2 (se3conv_fwd then uses
- *                         the side-stream set of (2) too).  SE3_SLICE_STREAMS=2 forks from the caller's stream: do NOT use it
- *                         on a stream that is itself a forked branch of a graph capture (hipStreamEndCapture of this HIP
- *                         runtime segfaults on nested forks, tools/probes/nested_fork_capture.py)
+ * (Removed in round 6 with their code: SE3_SLICE_MB / SE3_SLICE_STREAMS, the row-sliced schedule of round 5 that lost every
+ *  A/B -- profiles/r05_slice_ab.txt; SE3_PAIR_PERSIST / SE3_PAIR_OCC.)
  */

@@ -258,49 +258,6 @@ FwdLayout fwd_layout(const se3conv_shape* s, int save_t) {
   return l;
 }
 
-// ---- row slices (round 5): producer -> consumer per slice of the rows --------------------------------------------------
-// The row-sized intermediates (T, U, grad_T) are written by one kernel and read by the next.  Whole, each is ~1 GB at the
-// headline shape: the reader finds nothing of it in the 256 MiB memory-side cache.  SE3_SLICE_MB=n runs every such pair
-// per slice of at most n MB of the produced tensor (tools/probes/mall_pingpong.hip: read-after-write of <= 256 MB runs at
-// 6.8 TB/s, of 0.4 - 1 GB at 3.6 - 4.4), SE3_SLICE_STREAMS=2 puts the consumers on the side stream so that slice j + 1's
-// producer runs under slice j's consumer.  0 / unset: whole tensors (what profiles/r05_slice_ab.txt measured as faster or
-// not -- see DESIGN.md).
-struct SliceCfg { int64_t bytes; int streams; };
-const SliceCfg& slice_cfg() {
-  static const SliceCfg c = [] {
-    SliceCfg v{0, 1};
-    if (const char* e = getenv("SE3_SLICE_MB")) v.bytes = (int64_t)atoll(e) << 20;
-    if (const char* e = getenv("SE3_SLICE_STREAMS")) v.streams = atoi(e) >= 2 ? 2 : 1;
-    return v;
-  }();
-  return c;
-}
-// rows per slice of a tensor with `rows` rows of `row_bytes`: a multiple of 128 (the GEMMs' row tile; holds whole points
-// for 1, 2 or 4 frames); 0 = do not slice (off, frame count not a divisor of 128, or fewer than two slices' worth of rows)
-int64_t slice_rows(int64_t rows, int64_t row_bytes, int frames) {
-  const SliceCfg& c = slice_cfg();
-  if (c.bytes <= 0 || row_bytes <= 0 || 128 % frames != 0) return 0;
-  int64_t per = c.bytes / row_bytes / 128 * 128;
-  if (per < 1024) per = 1024;
-  if (rows < per + per / 2) return 0;
-  // equal slices: the last one must not be a sliver that under-fills the chip
-  const int64_t n = (rows + per - 1) / per;
-  per = ((rows + n - 1) / n + 127) / 128 * 128;
-  return per;
-}
-
-// rows per slice of grad_T (packed words; strip GEMM -> pair form of the parameter-gradient kernel) and of U (transposed
-// wave-pair edge kernel -> grad_X GEMM); 0 = whole.  From the shape alone: bwd_layout and se3conv_bwd must agree.
-int64_t sliced_rows_grad_t(const se3conv_shape* s) {
-  EdgeGeom g{};
-  g.f_ctr = s->f_out, g.f_nb = s->f_in;
-  const int64_t rows_out = s->n_out * s->f_out;
-  const int ck = s->c_in * s->num_basis;
-  if (!edge_param_grad_bf16_row_ranges(g, s->c_in) || !gemm_strip_bf16_applicable(rows_out, ck, s->c_out)) return 0;
-  const int64_t per = slice_rows(rows_out, (int64_t)ck * 4, s->f_out);
-  return per >= 2048 ? per : 0;  // the strip GEMM wants >= 2048 rows per launch
-}
-
 struct BwdLayout {
   size_t axes_ext, wt, w2, big, t, param_partials, tn_partials, featpk, gpk, bt_hi, bt_lo, split, geom_in, geom_out, total;
   size_t dx_rows;  // edge-major feature gradient (use_edge_dx): D [edge rows * F_in, C_in] fp32
@@ -409,10 +366,6 @@ BwdLayout bwd_layout(const se3conv_shape* s, int want_feat, int want_params, int
   l.dx_rows = dx ? take((size_t)s->n_edges * s->f_in * s->c_in * 4) : 0;
   l.t = (want_params && !have_t && !dw_u) ? take(rows_out * s->c_in * kb * 4) : 0;
   l.n_param_partials = edge_param_grad_blocks((int64_t)rows_out);
-  if (fast && want_params && want_feat && !dx) {  // every slice's launch leaves its own partial sums (sliced_rows_grad_t)
-    const int64_t per = sliced_rows_grad_t(s);
-    if (per > 0) l.n_param_partials *= (int)((rows_out + per - 1) / per);
-  }
   l.param_partials = want_params ? take((size_t)l.n_param_partials * edge_param_grad_bf16_channel_blocks(s->c_in) *
                                          kDescExt * kBasis * 4) : 0;
   l.tn_splits = dw_u ? gemm_tn_splits((int64_t)rows_in, s->c_out * (int)kb, s->c_in)
@@ -454,11 +407,9 @@ int64_t overlap_rows_limit() {
 // spare (stream, events) sets per device ready, a capturing caller stream that is new to the table takes one of those,
 // and when there is none -- the library was never called outside a capture in this process -- the backward pass simply
 // does not fork (same results, the two branches back to back).  INTEGRATION.md: warm up eagerly before capturing.
-constexpr int kSideEvents = 4;  // hand-over events of the row-slice schedules (producer -> consumer and back)
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  hipEvent_t ev[kSideEvents] = {nullptr, nullptr, nullptr, nullptr};
   bool ok = false;
   uint64_t last_use = 0;  // SideTable::clock at the last fork (LRU order)
   int pins = 0;           // calls between side_stream_for and release_side_stream on this set: never evicted while > 0
@@ -488,7 +439,6 @@ SideStream make_side_stream(SideTable& t) {  // t.mu held
   v.ok = hipStreamCreateWithFlags(&v.stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&v.fork, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&v.join, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < kSideEvents && v.ok; ++i) v.ok = hipEventCreateWithFlags(&v.ev[i], hipEventDisableTiming) == hipSuccess;
   return v;
 }
 bool stream_is_capturing(hipStream_t s) {
@@ -628,14 +578,6 @@ struct ForkJoin {
     }
     return rc;
   }
-  // hand-over inside a forked region: everything enqueued on `from` so far happens before what `to` gets from here on
-  // (event i of the set; an event may be reused once the wait on its previous record has been enqueued)
-  int signal(int i, hipStream_t from, hipStream_t to) {
-    if (hipEventRecord(side.ev[i], from) != hipSuccess || hipStreamWaitEvent(to, side.ev[i], 0) != hipSuccess) return SE3_ERR_LAUNCH;
-    return SE3_OK;
-  }
-  int record(int i, hipStream_t from) { return hipEventRecord(side.ev[i], from) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH; }
-  int wait(int i, hipStream_t to) { return hipStreamWaitEvent(to, side.ev[i], 0) == hipSuccess ? SE3_OK : SE3_ERR_LAUNCH; }
   ~ForkJoin() { (void)join(); }
 };
 
@@ -983,32 +925,6 @@ extern "C" int se3conv_fwd_prepared(const float* pts_in, const float* pts_out, c
     if (int rc = pb.launch(stream)) return rc;
     g.ctr_geom = geom_out, g.nb_geom = geom_in;
   }
-  const int64_t t_row_bytes = t24 == 2 ? t16_row_bytes(s->c_in) : (int64_t)ck * (t24 == 1 ? 3 : 4);
-  const int64_t per = edge_t_bf16_row_ranges(g, s->c_in) ? slice_rows(rows_out, t_row_bytes, s->f_out) : 0;
-  if (per > 0) {
-    // T slice by slice: edge kernel on rows [r0, r1), then their contraction while the slice is still on chip
-    ForkJoin fj;
-    hipStream_t cs = stream;  // consumer stream
-    if (slice_cfg().streams == 2) {
-      SideStream side = side_stream_for(stream);
-      if (side.ok) {
-        if (int rc = fj.fork(side, stream)) return rc;
-        cs = side.stream;
-      }
-    }
-    for (int64_t r0 = 0; r0 < rows_out; r0 += per) {
-      const int64_t r1 = r0 + per < rows_out ? r0 + per : rows_out;
-      if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream,
-                                      r0, r1, t24))
-        return rc;
-      if (cs != stream)
-        if (int rc = fj.signal(0, stream, cs)) return rc;
-      if (int rc = launch_gemm_nn_bf16("gemm_out", reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t) + r0 * t_row_bytes),
-                                       bt_hi, bt_lo, out + r0 * s->c_out, false, r1 - r0, s->c_out, ck, nullptr, nu, inv_phi, cs, t24))
-        return rc;
-    }
-    return fj.join();
-  }
   if (int rc = launch_edge_t_bf16("edge_t_fwd", g, featpk, s->c_in, s->n_in * s->f_in, axes_ext, rho, (uint32_t*)t, stream,
                                   -1, -1, t24))
     return rc;
@@ -1262,72 +1178,6 @@ extern "C" int se3conv_bwd_prepared(const float* pts_in, const float* pts_out, c
       if (int rc = weight_gradient(stream)) return rc;
     }
     return final_sums.launch(stream);
-  }
-  // ---- row-sliced schedule (SE3_SLICE_MB, see slice_cfg): every producer -> consumer pair per slice of the rows ---------
-  if (feat_branch && want_params && l.big_u != 0 && strip_t && !gt16) {
-    const int64_t u_row_bytes = t24_u == 2 ? t16_row_bytes(s->c_out) : (int64_t)s->c_out * kb * (t24_u == 1 ? 3 : 4);
-    const int64_t per_u = edge_t_bf16_row_ranges(gt, s->c_out) ? slice_rows(rows_in, u_row_bytes, s->f_in) : 0;
-    const int64_t per_g = (grad_axes || grad_biases) ? sliced_rows_grad_t(s) : 0;
-    if (per_u > 0 || per_g > 0) {
-      ForkJoin sfj;
-      hipStream_t side_s = stream;
-      if (slice_cfg().streams == 2) {
-        SideStream side = side_stream_for(stream);
-        if (side.ok) {
-          if (int rc = sfj.fork(side, stream)) return rc;
-          side_s = side.stream;
-        }
-      }
-      const bool two = side_s != stream;
-      uint32_t* ubuf = (uint32_t*)(ws + l.big_u);
-      u_rows = ubuf;
-      // phase 1: U slices -- transposed edge pass on the caller's stream, their grad_X product behind it (side stream)
-      {
-        const int64_t step = per_u > 0 ? per_u : rows_in;
-        for (int64_t r0 = 0; r0 < rows_in; r0 += step) {
-          const int64_t r1 = r0 + step < rows_in ? r0 + step : rows_in;
-          if (int rc = launch_edge_t_bf16("edge_t_transposed", gt, gpk, s->c_out, rows_out, axes_ext, rho, ubuf, stream,
-                                          per_u > 0 ? r0 : -1, per_u > 0 ? r1 : -1, t24_u))
-            return rc;
-          if (two)
-            if (int rc = sfj.signal(0, stream, side_s)) return rc;
-          if (int rc = launch_gemm_nn_bf16("gemm_gradX", reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ubuf) + r0 * u_row_bytes),
-                                           bx_hi, bx_lo, grad_feat + r0 * s->c_in, false, r1 - r0, s->c_in, s->c_out * kb,
-                                           nullptr, nu, inv_phi, side_s, t24_u))
-            return rc;
-        }
-      }
-      // phase 2: grad_T slices -- strip GEMM (side stream), parameter-gradient kernel behind it (caller's stream); the GEMM is
-      // the faster of the two and may run at most two slices ahead
-      {
-        const int64_t step = per_g > 0 ? per_g : rows_out;
-        int n_part = 0, j = 0;
-        for (int64_t r0 = 0; r0 < rows_out; r0 += step, ++j) {
-          const int64_t r1 = r0 + step < rows_out ? r0 + step : rows_out;
-          if (two && j >= 2)
-            if (int rc = sfj.wait(2 + (j & 1), side_s)) return rc;
-          if (int rc = launch_gemm_strip_bf16("gemm_gradT", gpk + r0 * s->c_out, bt_hi, bt_lo, bigw + r0 * ck, r1 - r0, ck, s->c_out,
-                                              side_s, false))
-            return rc;
-          if (two)
-            if (int rc = sfj.signal(1, side_s, stream)) return rc;
-          if (grad_axes || grad_biases) {
-            int used = 0;
-            if (int rc = launch_edge_param_grad_bf16("edge_param_grad", g, featpk, s->c_in, rows_in, axes_ext, rho, bigw,
-                                                     partials + (int64_t)n_part * kDescExt * kBasis, l.n_param_partials - n_part, &used,
-                                                     stream, false, per_g > 0 ? r0 : -1, per_g > 0 ? r1 : -1))
-              return rc;
-            n_part += used;
-            if (two)
-              if (int rc = sfj.record(2 + (j & 1), stream)) return rc;
-          }
-        }
-        if (grad_axes || grad_biases) final_sums.params(partials, n_part, grad_axes, grad_biases, 0.5f);
-      }
-      if (int rc = weight_gradient(side_s)) return rc;
-      if (int rc = sfj.join()) return rc;
-      return final_sums.launch(stream);
-    }
   }
   bool branch_forked = false;
   ForkJoin fj;  // joins on every exit path from here on

@@ -15,11 +15,9 @@ re-running a slice of the parity suite in a child process with the variable set:
                     small parity cases would never reach them
   SE3_NN_KG=2       the dense products over 3-byte rows of under-filled levels with two k groups per workgroup (round 5; lost
                     its A/B, profiles/r05_nn_kgroups_ab.txt)
-  SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2  the row-sliced schedule of round 5 (every producer -> consumer pair per slice of the
-                    rows, consumers on the side stream; 1 MB so that the small shapes of the slice are cut too) -- lost its
-                    A/B at every slice size (profiles/r05_slice_ab.txt) and stays as a switch
 
-(The merged backward kernel, the fused edge + contraction kernel and the chunk-stream kernels of rounds 1-2 lost their A/B
+(The row-sliced schedule of round 5 -- SE3_SLICE_MB, SE3_SLICE_STREAMS -- lost its A/B at every slice size,
+profiles/r05_slice_ab.txt, and was removed in round 6.  The merged backward kernel, the fused edge + contraction kernel and the chunk-stream kernels of rounds 1-2 lost their A/B
 measurements -- profiles/r02_levels_fused.txt, r02_stream_kernel_ab.txt, r03_merged_backward_and_stash_ab.txt -- and were
 removed in round 3; so were round 3's in-kernel reductions, profiles/r03_in_kernel_reduction_ab.txt.)
 
@@ -38,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SLICE = "(golden or random_shapes or headline_subset or features_only or empty_rows) and bf16x3 and not t16"
 # independent switches share a child
 VARIANTS = ["SE3_NO_PAIR,SE3_PG_SINGLE", "SE3_NO_T24", "SE3_BWD_BRANCH_ORDER,SE3_NN_KG=2", "SE3_OVERLAP",
-            "SE3_DX_PATH=1,SE3_EDGE_STREAM=1", "SE3_SLICE_MB=1,SE3_SLICE_STREAMS=2"]
+            "SE3_DX_PATH=1,SE3_EDGE_STREAM=1"]
 
 
 @pytest.mark.gpu
