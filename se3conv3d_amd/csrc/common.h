@@ -499,45 +499,50 @@ int launch_knn_listed(const float* pts, const int32_t* batch_ids, int64_t n, int
 // sequence, log2(K) compare-exchange stages sort it.
 template <int K>
 struct TopK {
-  float d[K];
-  int i[K];
+  // Entry = (bits of the squared distance << 32) | index: distances are >= +0, so their bit patterns order as the values do
+  // and ONE unsigned 64-bit comparison is the lexicographic (distance, index) order -- a compare-exchange is a v_cmp_lt_u64
+  // and four v_cndmask instead of three compares, two logic ops and four v_cndmask on separate (float, int) arrays
+  // (round 6: the ordered insertion is what the cell-grid k-NN kernel spends its time on).
+  uint64_t key[K];
+  static __device__ __forceinline__ uint64_t pack(float d, int i) {
+    return ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)(uint32_t)i;
+  }
+  __device__ __forceinline__ float dist(int e) const { return __uint_as_float((uint32_t)(key[e] >> 32)); }
+  __device__ __forceinline__ int idx(int e) const { return (int)(uint32_t)key[e]; }
+  __device__ __forceinline__ void set(int e, float d, int i) { key[e] = pack(d, i); }
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int e = 0; e < K; ++e) d[e] = 3.0e38f, i[e] = 0x7fffffff;
-  }
-  static __device__ __forceinline__ bool less(float da, int ia, float db, int ib) {
-    return da < db || (da == db && ia < ib);
+    for (int e = 0; e < K; ++e) key[e] = pack(3.0e38f, 0x7fffffff);
   }
   __device__ __forceinline__ void cas(int a, int b) {  // afterwards entry a <= entry b
-    const bool sw = less(d[b], i[b], d[a], i[a]);
-    const float dl = sw ? d[b] : d[a], dh = sw ? d[a] : d[b];
-    const int il = sw ? i[b] : i[a], ih = sw ? i[a] : i[b];
-    d[a] = dl, d[b] = dh, i[a] = il, i[b] = ih;
+    const uint64_t x = key[a], y = key[b];
+    const bool sw = y < x;
+    key[a] = sw ? y : x, key[b] = sw ? x : y;
   }
   __device__ __forceinline__ void insert(float dd, int jj) {
-    if (!less(dd, jj, d[K - 1], i[K - 1])) return;
-    d[K - 1] = dd, i[K - 1] = jj;
+    const uint64_t k = pack(dd, jj);
+    if (!(k < key[K - 1])) return;
+    key[K - 1] = k;
 #pragma unroll
     for (int e = K - 1; e > 0; --e) cas(e - 1, e);
   }
   __device__ __forceinline__ void merge_xor(int mask) {  // both partner lanes end up with the merged list
+    uint64_t tmp[K];
 #pragma unroll
     for (int e = 0; e < K; ++e) {
-      const float pd = __shfl_xor(d[K - 1 - e], mask);
-      const int pi = __shfl_xor(i[K - 1 - e], mask);
-      tmp_d[e] = pd, tmp_i[e] = pi;
+      const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key[K - 1 - e], mask);
+      const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(key[K - 1 - e] >> 32), mask);
+      tmp[e] = ((uint64_t)hi << 32) | lo;
     }
 #pragma unroll
     for (int e = 0; e < K; ++e)
-      if (less(tmp_d[e], tmp_i[e], d[e], i[e])) d[e] = tmp_d[e], i[e] = tmp_i[e];
+      if (tmp[e] < key[e]) key[e] = tmp[e];
 #pragma unroll
     for (int s = K / 2; s > 0; s >>= 1)
 #pragma unroll
       for (int e = 0; e < K; ++e)
         if ((e & s) == 0) cas(e, e + s);
   }
-  float tmp_d[K];
-  int tmp_i[K];
 };
 
 // Batched operand preparation (prep.hip): collect the jobs of one call, launch them as one kernel.

@@ -280,21 +280,21 @@ __global__ __launch_bounds__(64 * kListedWaves) void knn_listed_kernel(const flo
     __syncthreads();  // previous query's LDS lists are consumed
     if (lane == 0) {
 #pragma unroll
-      for (int e = 0; e < K; ++e) w_d[wave][e] = best.d[e], w_i[wave][e] = best.i[e];
+      for (int e = 0; e < K; ++e) w_d[wave][e] = best.dist(e), w_i[wave][e] = best.idx(e);
     }
     __syncthreads();
     if (wave == 0) {
       best.init();
       if (lane < kListedWaves) {
 #pragma unroll
-        for (int e = 0; e < K; ++e) best.d[e] = w_d[lane][e], best.i[e] = w_i[lane][e];
+        for (int e = 0; e < K; ++e) best.set(e, w_d[lane][e], w_i[lane][e]);
       }
 #pragma unroll 1
       for (int m = 1; m < kListedWaves; m <<= 1) best.merge_xor(m);
       if (lane == 0) {
 #pragma unroll
         for (int e = 0; e < K; ++e)
-          if (e < k_out) out[i * k_out + e] = best.i[e] == 0x7fffffff ? -1 : best.i[e];
+          if (e < k_out) out[i * k_out + e] = best.idx(e) == 0x7fffffff ? -1 : best.idx(e);
       }
     }
   }

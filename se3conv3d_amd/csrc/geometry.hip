@@ -489,14 +489,14 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4* __restrict_
   float kth = 3.0e38f;
 #pragma unroll
   for (int e = 0; e < K; ++e)
-    if (e == k_out - 1) kth = best.d[e];
+    if (e == k_out - 1) kth = best.dist(e);
   const bool ok = found >= k_out && kth < c * c;
   if (writer) {
     if (!ok) list[atomicAdd(list_count, 1)] = qid;  // order of the list does not matter: each entry is recomputed alone
     if (ok) {
 #pragma unroll
       for (int e = 0; e < K; ++e)
-        if (e < k_out) out[(int64_t)qid * k_out + e] = best.i[e];
+        if (e < k_out) out[(int64_t)qid * k_out + e] = best.idx(e);
     }
   }
 }
