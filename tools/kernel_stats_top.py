@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The top of a rocprofv3 `*_kernel_stats.csv` (--kernel-trace --stats --output-format csv) in one screen: total kernel
+time, then per kernel name (cut to 100 characters) calls, average duration, share.   usage: tools/kernel_stats_top.py <csv>"""
 import csv,sys
 rows=list(csv.reader(open(sys.argv[1])))
 tot=sum(int(r[2]) for r in rows[1:])

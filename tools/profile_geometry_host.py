@@ -1,6 +1,10 @@
+#!/usr/bin/env python3
+"""Host side of the eager geometry of a DFaust step under cProfile: 20 x the 15 neighbourhoods (source grids forgotten per
+repetition, as a new step's clouds have none), then 20 x create_hierarchy -- where the Python above the C ABI spends its time
+(the builds are bound by the host's launch rate).   usage: tools/profile_geometry_host.py"""
 import os, sys, time, cProfile, pstats
 import torch
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import se3conv3d_amd as amd
 from se3conv3d_amd import pc as _pc, workloads as W
