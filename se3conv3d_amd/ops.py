@@ -7,6 +7,7 @@ reference's ``point_cloud_lib.custom_ops`` (FeatBasisProj.py, BallQuery.py, Comp
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from dataclasses import dataclass, field
 from typing import Callable, Optional, Tuple
 
@@ -59,6 +60,10 @@ def _ptr(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, device=None) 
     """Device pointer of a contiguous CUDA tensor of the given dtype (ValueError otherwise)."""
     if t is None:
         return C.c_void_p(0)
+    # (the good case first: an eager neighbourhood build passes ~11 tensors per query and is bound by the host,
+    # tools/host_split_neighbourhoods.py)
+    if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous() and (device is None or t.device == device):
+        return C.c_void_p(t.data_ptr())
     if not isinstance(t, torch.Tensor):
         raise ValueError(f"{name}: expected a tensor, got {type(t)}")
     if not t.is_cuda:
@@ -74,6 +79,8 @@ def _ptr(t: Optional[torch.Tensor], dtype: torch.dtype, name: str, device=None) 
 
 def _as(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Contiguous copy-if-needed in ``dtype`` (what the reference wrappers do with ``.to``)."""
+    if t.dtype == dtype and not t.requires_grad and t.is_contiguous():
+        return t  # (nothing to convert or to detach: three tensor objects less per argument)
     return t.detach().to(dtype).contiguous()
 
 
@@ -129,6 +136,14 @@ def batch_aabb(pts, batch_ids, n_batches: Optional[int] = None) -> Tuple[torch.T
                                   pts.shape[0], n_batches, _ptr(mn, torch.float32, "aabb_min"),
                                   _ptr(mx, torch.float32, "aabb_max"), _stream(pts.device)), "se3_batch_aabb")
     return mn, mx
+
+
+@functools.lru_cache(maxsize=4096)
+def _ball_query_sizes(n_src: int, n_dst: int) -> Tuple[bool, int, int]:
+    """(needs a cell grid, workspace bytes, grid bytes) of a query of this size: three library calls, asked once per size."""
+    lib = _lib.load()
+    return (bool(lib.se3_ball_query_needs_grid(n_src)), int(lib.se3_ball_query_workspace_bytes(n_src, n_dst)),
+            int(lib.se3_ball_query_grid_bytes(n_src)))
 
 
 def ball_query_needs_grid(n_src: int) -> bool:
@@ -288,12 +303,12 @@ def ball_query_bounded(pts_src, pts_dst, batch_src, batch_dst, radius: float, ca
         info = torch.zeros(2, dtype=i32, device=dev)
         return (neighbors, ends, info, sources) if want_sources else (neighbors, ends, info)
     info = torch.empty(2, dtype=i32, device=dev)  # both words are written by the store pass
-    needs_grid = bool(lib.se3_ball_query_needs_grid(n_src))
-    ws = _workspace(lib.se3_ball_query_workspace_bytes(n_src, n_dst), dev)
+    needs_grid, ws_bytes, grid_bytes = _ball_query_sizes(n_src, n_dst)
+    ws = _workspace(ws_bytes, dev)
     if grids is not None and needs_grid and src_box is not None and SHARED_GRIDS and not torch.cuda.is_current_stream_capturing():
         # (src_box: the grid parameters are then a pure function of the cloud's cached boxes and the radius, so two calls
         # with the same key search the same cells -- and the parameters themselves are kept with the grid)
-        grid, valid = grids.slot(pts_src, bs, radius, n_batches, lib.se3_ball_query_grid_bytes(n_src))
+        grid, valid = grids.slot(pts_src, bs, radius, n_batches, grid_bytes)
         params = grids.params.get(float(radius)) if valid else None
         if params is None:
             params = grids.params[float(radius)] = _batch_aabb_min_and_cells(pts_src, bs, radius, n_batches, src_box)
